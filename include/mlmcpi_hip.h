@@ -1,0 +1,183 @@
+/* mlmcpi_hip.h -- C ABI of the MI355X (gfx950) sweep engine.
+ *
+ * Drop-in boundary for the inner MCMC sweep of eikehmueller/mlmcpathintegral: every entry point
+ * replaces the body of one virtual method of the reference's Action / Sampler / QoI interfaces
+ * (cited per function, paths relative to the reference's src/), batched over B independent chains
+ * that live in HBM.  Plain pointers and sizes only; no C++ or torch types cross this boundary.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative mlmcpi_status otherwise;
+ *     mlmcpi_last_error() gives the message of the calling thread's last failure;
+ *   - pointers named d_* are DEVICE pointers (from mlmcpi_malloc or any HIP allocator, e.g. a
+ *     torch tensor's data_ptr()); everything else is host memory;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); calls are
+ *     asynchronous with respect to the host unless stated otherwise;
+ *   - state layout is the reference's SampleState layout, chain-major:
+ *       1-D paths      x[b*M + j]                         (common/samplestate.hh:19-53)
+ *       GFF            phi[b*Mt*Mx + Mt*j + i]            (lattice/lattice2d.hh:230-245)
+ *       Schwinger      theta[b*2*Mt*Mx + 2*Mt*j + 2*i + mu]  (lattice/lattice2d.hh:348-354)
+ *   - randomness is counter based: Philox4x32-10 keyed by `seed`, counter =
+ *     (site, chain0 + b, step, purpose<<24 | sub).  Results do not depend on grid shape, tile
+ *     size, number of fused sweeps or number of GPUs.  The contract is spelled out in DESIGN.md.
+ */
+#ifndef MLMCPI_HIP_H
+#define MLMCPI_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MLMCPI_ABI_VERSION 1
+
+enum mlmcpi_status {
+  MLMCPI_OK = 0,
+  MLMCPI_ERR_INVALID = -1,     /* bad argument (sizes, parity, NULL pointers) */
+  MLMCPI_ERR_HIP = -2,         /* HIP runtime error, see mlmcpi_last_error() */
+  MLMCPI_ERR_UNSUPPORTED = -3, /* operation not defined for this action (action/action.hh:73-96) */
+  MLMCPI_ERR_NO_DEVICE = -4
+};
+
+/* action kinds */
+enum mlmcpi_action_kind {
+  MLMCPI_HARMONIC = 0,  /* action/qm/harmonicoscillatoraction.{hh,cc} */
+  MLMCPI_QUARTIC = 1,   /* action/qm/quarticoscillatoraction.{hh,cc} */
+  MLMCPI_ROTOR = 2,     /* action/qm/rotoraction.{hh,cc} */
+  MLMCPI_GFF = 3,       /* action/qft/gffaction.{hh,cc} (n_gibbs_smooth = 0) */
+  MLMCPI_SCHWINGER = 4  /* action/qft/quenchedschwingeraction.{hh,cc} */
+};
+
+/* 1-D path action: lattice/lattice1d.hh:60-101 (M_lat, T_final, a = T_final/M_lat) + the action's
+ * own parameters (m0, mu2; lambda, x0 for the quartic oscillator). */
+typedef struct mlmcpi_path_action {
+  int32_t kind;
+  uint32_t M;
+  double T_final, m0, mu2, lambda, x0;
+} mlmcpi_path_action;
+
+/* 2-D lattice action on an unrotated Mt x Mx periodic lattice (lattice/lattice2d.hh:98-437).
+ * GFF uses `mass` (mu2 = (mass/Mt)^2, action/qft/gffaction.hh:174-181); Schwinger uses `beta`. */
+typedef struct mlmcpi_lattice_action {
+  int32_t kind;
+  uint32_t Mt, Mx;
+  double beta, mass;
+} mlmcpi_lattice_action;
+
+/* ---- runtime plumbing ---------------------------------------------------------------------- */
+int mlmcpi_abi_version(void);
+const char *mlmcpi_last_error(void);
+int mlmcpi_device_count(int *count);
+int mlmcpi_set_device(int device);
+int mlmcpi_device_name(char *buf, size_t len);
+int mlmcpi_malloc(void **d_ptr, size_t bytes);
+int mlmcpi_free(void *d_ptr);
+int mlmcpi_memset(void *d_ptr, int value, size_t bytes, void *stream);
+int mlmcpi_copy_h2d(void *d_dst, const void *src, size_t bytes, void *stream);
+int mlmcpi_copy_d2h(void *dst, const void *d_src, size_t bytes, void *stream);
+int mlmcpi_copy_d2d(void *d_dst, const void *d_src, size_t bytes, void *stream);
+int mlmcpi_stream_synchronize(void *stream);
+
+/* ---- index maps (host, integer, bit-exact) --------------------------------------------------
+ * lattice/lattice2d.hh:230-268 (vertex), :348-375 (link); rotated != 0 selects the 45-degree
+ * sublattice numbering. */
+uint32_t mlmcpi_vertex_cart2lin(uint32_t Mt, uint32_t Mx, int rotated, int i, int j);
+void mlmcpi_vertex_lin2cart(uint32_t Mt, uint32_t Mx, int rotated, uint32_t ell, int *i, int *j);
+uint32_t mlmcpi_link_cart2lin(uint32_t Mt, uint32_t Mx, int i, int j, int mu);
+void mlmcpi_link_lin2cart(uint32_t Mt, uint32_t Mx, uint32_t ell, int *i, int *j, int *mu);
+/* neighbour tables as the Lattice constructors build them: lattice/lattice1d.cc:11-18 (M x 2),
+ * lattice/lattice2d.cc:137-155 (nvertices x 8; +i,-i,+j,-j then the four diagonals) */
+int mlmcpi_neighbours_1d(uint32_t M, uint32_t *out);
+int mlmcpi_neighbours_2d(uint32_t Mt, uint32_t Mx, int rotated, uint32_t *out);
+
+/* ---- 1-D paths ------------------------------------------------------------------------------ */
+/* Action::evaluate (action/action.hh:60-61): d_S[b] = S[x_b]. */
+int mlmcpi_path_evaluate(const mlmcpi_path_action *act, const double *d_x, uint32_t B, double *d_S, void *stream);
+/* Action::force (action/action.hh:112-113): d_f[b*M+j] = dS/dx_j. */
+int mlmcpi_path_force(const mlmcpi_path_action *act, const double *d_x, double *d_f, uint32_t B, void *stream);
+/* Action::initialise_state (action/action.hh:122-123): rotor U(-pi,pi) per site
+ * (rotoraction.cc:82-89), zeros for HO / quartic. */
+int mlmcpi_path_initialise(const mlmcpi_path_action *act, double *d_x, uint32_t B, uint64_t seed, uint32_t chain0,
+                           void *stream);
+/* QoIXsquared::evaluate (qoi/qm/qoixsquared.cc:7-20) and QoISusceptibility::evaluate
+ * (qoi/qm/qoisusceptibility.cc:8-23); d_out[b]. */
+int mlmcpi_qoi_xsquared(const double *d_x, uint32_t M, uint32_t B, double *d_out, void *stream);
+int mlmcpi_qoi_susceptibility(const double *d_x, uint32_t M, double T_final, uint32_t B, double *d_out,
+                              void *stream);
+
+/* HMCSampler::draw (sampler/hmcsampler.cc:8-19) = n_rep x single_step (:22-69), fused: momenta,
+ * nt+1 force evaluations, both action evaluations, kinetic energies and the global Metropolis
+ * test run on the device; momenta never touch HBM.  Repetition r of this call uses Philox step
+ * traj0 + r; as in the reference, repetitions after the first acceptance are skipped.
+ *   d_x        [B*M]  current states, updated in place where accepted
+ *   d_work     workspace of mlmcpi_path_hmc_workspace_bytes() bytes
+ *   d_accept   [B] int32, 1 where the draw was accepted (MCMCStep::accepted, mcmcstep.hh:47)
+ *   d_energies optional [B*4]: S(x_cur), T(p_0), S(x_trial), T(p_end) of the last repetition run */
+int mlmcpi_path_hmc_workspace_bytes(const mlmcpi_path_action *act, uint32_t B, uint32_t nt, size_t *bytes);
+int mlmcpi_path_hmc_draw(const mlmcpi_path_action *act, double *d_x, uint32_t B, uint32_t nt, double dt,
+                         uint32_t n_rep, uint64_t seed, uint32_t chain0, uint32_t traj0, void *d_work,
+                         int32_t *d_accept, double *d_energies, void *stream);
+
+/* OverrelaxedHeatBathSampler::draw (sampler/overrelaxedheatbathsampler.cc:8-31) for the rotor:
+ * n_overrelax sweeps of RotorAction::overrelaxation_update (rotoraction.cc:40-56) then n_heatbath
+ * sweeps of heatbath_update (:20-37), even sites then odd sites within each sweep.  Sweep s of
+ * this call uses Philox step sweep0 + s.  d_x is updated in place; d_scratch is B*M doubles. */
+int mlmcpi_path_sweep_draw(const mlmcpi_path_action *act, double *d_x, double *d_scratch, uint32_t B,
+                           uint32_t n_overrelax, uint32_t n_heatbath, uint64_t seed, uint32_t chain0,
+                           uint32_t sweep0, void *stream);
+
+/* ---- 2-D lattices --------------------------------------------------------------------------- */
+int mlmcpi_lattice_state_size(const mlmcpi_lattice_action *act, uint32_t *n); /* Action::sample_size */
+int mlmcpi_lattice_evaluate(const mlmcpi_lattice_action *act, const double *d_phi, uint32_t B, double *d_S,
+                            void *stream);
+int mlmcpi_lattice_force(const mlmcpi_lattice_action *act, const double *d_phi, double *d_f, uint32_t B,
+                         void *stream);
+/* Schwinger: U(-pi,pi) per link (quenchedschwingeraction.cc:198-204).  GFF: N(0,1) per vertex (the
+ * reference's exact Cholesky draw, gffaction.cc:121-123, needs a dense N x N inverse and is out of
+ * scope). */
+int mlmcpi_lattice_initialise(const mlmcpi_lattice_action *act, double *d_phi, uint32_t B, uint64_t seed,
+                              uint32_t chain0, void *stream);
+/* OverrelaxedHeatBathSampler::draw on a 2-D action: n_overrelax overrelaxation sweeps then
+ * n_heatbath heat-bath sweeps (gffaction.cc:33-42,68-77; quenchedschwingeraction.cc:25-65 with
+ * distribution/expcosdistribution.hh:51-65), multicolour order (GFF: (i+j) even, odd; Schwinger:
+ * mu=0 & j even, mu=0 & j odd, mu=1 & i even, mu=1 & i odd).  Mt and Mx must be even.  Sweep s
+ * uses Philox step sweep0 + s.  d_phi is updated in place; d_scratch has the same size.
+ * `fuse` = max number of consecutive sweeps fused into one launch (0 = library default). */
+int mlmcpi_lattice_sweep_draw(const mlmcpi_lattice_action *act, double *d_phi, double *d_scratch, uint32_t B,
+                              uint32_t n_overrelax, uint32_t n_heatbath, uint64_t seed, uint32_t chain0,
+                              uint32_t sweep0, uint32_t fuse, void *stream);
+/* QoI2DPhiSquared (qoi/qft/qoi2dphisquared.cc:8-15), QoIAvgPlaquette (qoi/qft/qoiavgplaquette.cc:8-27),
+ * QoI2DSusceptibility (qoi/qft/qoi2dsusceptibility.cc:8-27); d_out[b]. */
+int mlmcpi_qoi_phi_squared(const double *d_phi, uint32_t n_vertices, uint32_t B, double *d_out, void *stream);
+int mlmcpi_qoi_avg_plaquette(const double *d_theta, uint32_t Mt, uint32_t Mx, uint32_t B, double *d_out,
+                             void *stream);
+int mlmcpi_qoi_2d_susceptibility(const double *d_theta, uint32_t Mt, uint32_t Mx, uint32_t B, double *d_out,
+                                 void *stream);
+
+/* Generic HMCSampler::draw for a 2-D action (streaming leapfrog: one fused force + momentum +
+ * position kernel per step).  Same contract as mlmcpi_path_hmc_draw. */
+int mlmcpi_lattice_hmc_workspace_bytes(const mlmcpi_lattice_action *act, uint32_t B, size_t *bytes);
+int mlmcpi_lattice_hmc_draw(const mlmcpi_lattice_action *act, double *d_phi, uint32_t B, uint32_t nt, double dt,
+                            uint32_t n_rep, uint64_t seed, uint32_t chain0, uint32_t traj0, void *d_work,
+                            int32_t *d_accept, double *d_energies, void *stream);
+
+/* ---- device-side statistics accumulation (common/statistics.cc:4-27, batched) ---------------
+ * d_acc holds, per chain, the packed sums [n, sum q, sum q^2, sum q^3, sum q^4] that the
+ * cross-rank reduction (one RCCL all-reduce of B*5 doubles) combines; see DESIGN.md. */
+int mlmcpi_stats_accumulate(double *d_acc, const double *d_q, uint32_t B, void *stream);
+
+/* ---- test hooks: raw RNG streams, single draws (used by parity tests only) -------------------- */
+int mlmcpi_test_philox(const uint32_t *ctr4, const uint32_t *key2, uint32_t *out4);
+/* d_out[4*k..] = (u0,u1,n0,n1) for site k of n sites */
+int mlmcpi_test_random(uint64_t seed, uint32_t chain, uint32_t step, uint32_t purpose, uint32_t sub, uint32_t n,
+                       double *d_out, void *stream);
+/* d_out[k] = ExpCos draw for site k with staples (d_xp[k], d_xm[k]); ExpSin2 draw with d_sigma[k] */
+int mlmcpi_test_expcos(uint64_t seed, uint32_t chain, uint32_t step, double beta, const double *d_xp,
+                       const double *d_xm, uint32_t n, double *d_out, void *stream);
+int mlmcpi_test_expsin2(uint64_t seed, uint32_t chain, uint32_t step, const double *d_sigma, uint32_t n,
+                        double *d_out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MLMCPI_HIP_H */

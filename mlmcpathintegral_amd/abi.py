@@ -1,0 +1,115 @@
+"""ctypes binding of the C ABI declared in include/mlmcpi_hip.h (libmlmcpi_hip.so).
+
+This is the only way Python (tests, bench.py, smoke) reaches the HIP kernels; the C++ host layer
+under include/mlmcpi/ binds the same symbols.  There is no CPU fallback: if the shared library is
+missing or a call fails, an exception is raised.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmlmcpi_hip.so")
+
+HARMONIC, QUARTIC, ROTOR, GFF, SCHWINGER = range(5)
+
+
+class MlmcpiError(RuntimeError):
+    pass
+
+
+class PathAction(C.Structure):
+    """mlmcpi_path_action"""
+    _fields_ = [("kind", C.c_int32), ("M", C.c_uint32), ("T_final", C.c_double), ("m0", C.c_double),
+                ("mu2", C.c_double), ("lam", C.c_double), ("x0", C.c_double)]
+
+
+class LatticeAction(C.Structure):
+    """mlmcpi_lattice_action"""
+    _fields_ = [("kind", C.c_int32), ("Mt", C.c_uint32), ("Mx", C.c_uint32), ("beta", C.c_double),
+                ("mass", C.c_double)]
+
+
+_vp, _u32, _u64, _i, _d, _sz = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int, C.c_double, C.c_size_t
+_PA, _LA = C.POINTER(PathAction), C.POINTER(LatticeAction)
+
+# name -> (restype, argtypes); must list EVERY symbol of include/mlmcpi_hip.h (tests check this)
+SIGNATURES = {
+    "mlmcpi_abi_version": (_i, []),
+    "mlmcpi_last_error": (C.c_char_p, []),
+    "mlmcpi_device_count": (_i, [C.POINTER(_i)]),
+    "mlmcpi_set_device": (_i, [_i]),
+    "mlmcpi_device_name": (_i, [C.c_char_p, _sz]),
+    "mlmcpi_malloc": (_i, [C.POINTER(_vp), _sz]),
+    "mlmcpi_free": (_i, [_vp]),
+    "mlmcpi_memset": (_i, [_vp, _i, _sz, _vp]),
+    "mlmcpi_copy_h2d": (_i, [_vp, _vp, _sz, _vp]),
+    "mlmcpi_copy_d2h": (_i, [_vp, _vp, _sz, _vp]),
+    "mlmcpi_copy_d2d": (_i, [_vp, _vp, _sz, _vp]),
+    "mlmcpi_stream_synchronize": (_i, [_vp]),
+    "mlmcpi_vertex_cart2lin": (_u32, [_u32, _u32, _i, _i, _i]),
+    "mlmcpi_vertex_lin2cart": (None, [_u32, _u32, _i, _u32, C.POINTER(_i), C.POINTER(_i)]),
+    "mlmcpi_link_cart2lin": (_u32, [_u32, _u32, _i, _i, _i]),
+    "mlmcpi_link_lin2cart": (None, [_u32, _u32, _u32, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "mlmcpi_neighbours_1d": (_i, [_u32, _vp]),
+    "mlmcpi_neighbours_2d": (_i, [_u32, _u32, _i, _vp]),
+    "mlmcpi_path_evaluate": (_i, [_PA, _vp, _u32, _vp, _vp]),
+    "mlmcpi_path_force": (_i, [_PA, _vp, _vp, _u32, _vp]),
+    "mlmcpi_path_initialise": (_i, [_PA, _vp, _u32, _u64, _u32, _vp]),
+    "mlmcpi_qoi_xsquared": (_i, [_vp, _u32, _u32, _vp, _vp]),
+    "mlmcpi_qoi_susceptibility": (_i, [_vp, _u32, _d, _u32, _vp, _vp]),
+    "mlmcpi_path_hmc_workspace_bytes": (_i, [_PA, _u32, _u32, C.POINTER(_sz)]),
+    "mlmcpi_path_hmc_draw": (_i, [_PA, _vp, _u32, _u32, _d, _u32, _u64, _u32, _u32, _vp, _vp, _vp, _vp]),
+    "mlmcpi_path_sweep_draw": (_i, [_PA, _vp, _vp, _u32, _u32, _u32, _u64, _u32, _u32, _vp]),
+    "mlmcpi_lattice_state_size": (_i, [_LA, C.POINTER(_u32)]),
+    "mlmcpi_lattice_evaluate": (_i, [_LA, _vp, _u32, _vp, _vp]),
+    "mlmcpi_lattice_force": (_i, [_LA, _vp, _vp, _u32, _vp]),
+    "mlmcpi_lattice_initialise": (_i, [_LA, _vp, _u32, _u64, _u32, _vp]),
+    "mlmcpi_lattice_sweep_draw": (_i, [_LA, _vp, _vp, _u32, _u32, _u32, _u64, _u32, _u32, _u32, _vp]),
+    "mlmcpi_qoi_phi_squared": (_i, [_vp, _u32, _u32, _vp, _vp]),
+    "mlmcpi_qoi_avg_plaquette": (_i, [_vp, _u32, _u32, _u32, _vp, _vp]),
+    "mlmcpi_qoi_2d_susceptibility": (_i, [_vp, _u32, _u32, _u32, _vp, _vp]),
+    "mlmcpi_lattice_hmc_workspace_bytes": (_i, [_LA, _u32, C.POINTER(_sz)]),
+    "mlmcpi_lattice_hmc_draw": (_i, [_LA, _vp, _u32, _u32, _d, _u32, _u64, _u32, _u32, _vp, _vp, _vp, _vp]),
+    "mlmcpi_stats_accumulate": (_i, [_vp, _vp, _u32, _vp]),
+    "mlmcpi_test_philox": (_i, [_vp, _vp, _vp]),
+    "mlmcpi_test_random": (_i, [_u64, _u32, _u32, _u32, _u32, _u32, _vp, _vp]),
+    "mlmcpi_test_expcos": (_i, [_u64, _u32, _u32, _d, _vp, _vp, _u32, _vp, _vp]),
+    "mlmcpi_test_expsin2": (_i, [_u64, _u32, _u32, _vp, _u32, _vp, _vp]),
+}
+
+# functions whose int return value is a status code
+_STATUS = {n for n, (r, _) in SIGNATURES.items() if r is _i and n != "mlmcpi_abi_version"}
+
+_lib = None
+
+
+def load():
+    """Load libmlmcpi_hip.so; raises if it has not been built (python __graft_entry__.py build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MlmcpiError(f"{LIB_PATH} not found: the HIP extension is not built "
+                              "(run `make -C mlmcpathintegral_amd/csrc`); there is no CPU fallback")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            f = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+            f.restype, f.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def call(name, *args):
+    """Call an ABI function; turn a negative status into an exception."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if name in _STATUS and rc != 0:
+        raise MlmcpiError(f"{name} failed with status {rc}: {lib.mlmcpi_last_error().decode()}")
+    return rc
+
+
+def path_action(kind, M, T_final, m0=1.0, mu2=1.0, lam=0.0, x0=0.0):
+    return PathAction(kind, M, T_final, m0, mu2, lam, x0)
+
+
+def lattice_action(kind, Mt, Mx, beta=0.0, mass=0.0):
+    return LatticeAction(kind, Mt, Mx, beta, mass)

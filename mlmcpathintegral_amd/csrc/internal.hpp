@@ -1,0 +1,47 @@
+// internal.hpp -- host-side plumbing shared by the translation units of libmlmcpi_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/mlmcpi_hip.h"
+#include "device_common.hpp"
+
+namespace mlmcpi {
+
+// error channel (thread local)
+int fail(int status, const char *fmt, ...);
+int fail_hip(hipError_t e, const char *what);
+
+#define MLMCPI_HIP_TRY(expr)                              \
+  do {                                                    \
+    hipError_t e__ = (expr);                              \
+    if (e__ != hipSuccess) return fail_hip(e__, #expr);   \
+  } while (0)
+
+// launch check: kernels report configuration errors through hipGetLastError
+#define MLMCPI_LAUNCH_CHECK(name)                         \
+  do {                                                    \
+    hipError_t e__ = hipGetLastError();                   \
+    if (e__ != hipSuccess) return fail_hip(e__, name);    \
+  } while (0)
+
+#define MLMCPI_REQUIRE(cond, ...)                         \
+  do {                                                    \
+    if (!(cond)) return fail(MLMCPI_ERR_INVALID, __VA_ARGS__); \
+  } while (0)
+
+inline hipStream_t as_stream(void *s) { return (hipStream_t)s; }
+
+// Library-owned scratch for reduction partials.  One buffer per device, grown on demand (the
+// first call of a given size allocates; steady state does not).  Calls that use it must not
+// overlap on different streams of the same device.
+int scratch(size_t bytes, void **d_ptr);
+
+inline RngKey make_key(uint64_t seed, uint32_t chain0, uint32_t step) {
+  return RngKey{(uint32_t)seed, (uint32_t)(seed >> 32), chain0, step};
+}
+
+constexpr uint32_t kMaxFuse = 16;  // max sweeps fused in one launch (kinds travel in a bitmask)
+
+}  // namespace mlmcpi

@@ -1,0 +1,680 @@
+// lattice2d.hip -- 2-D lattice kernels: Gaussian free field (vertex field, 5-point stencil) and
+// quenched Schwinger model (U(1) link angles, plaquette action), batched over B chains in the
+// reference's own SampleState layout (vertex l = Mt*j + i; link l = 2*Mt*j + 2*i + mu, i.e. one
+// double2 {theta_0, theta_1} per site, which is exactly a 16-byte-per-lane coalesced load).
+//
+// Sweeps are overlapped-tile kernels: a workgroup stages its tile plus a halo of 2 sites per fused
+// sweep in LDS, runs all colours of all fused sweeps there, and writes only the tile it owns to a
+// second buffer.  Halo updates are recomputed by every workgroup that needs them; the counter-based
+// RNG makes those recomputations bit-identical.  Per sweep HBM sees ~(1 + halo overhead) reads and
+// one write of every entry -- instead of the 4-5 passes of one-kernel-per-colour -- and k fused
+// sweeps divide that by k.
+#include "internal.hpp"
+
+namespace mlmcpi {
+
+constexpr int kSweepThreads = 256;
+
+// linear iteration of a workgroup over an nr x nc region without per-element division
+template <class F>
+__device__ __forceinline__ void for_region(uint32_t nr, uint32_t nc, F f) {
+  const uint32_t total = nr * nc;
+  uint32_t idx = threadIdx.x;
+  if (idx >= total) return;
+  uint32_t ri = idx / nc, ci = idx - ri * nc;
+  const uint32_t dr = kSweepThreads / nc, dc = kSweepThreads - dr * nc;
+  for (; idx < total; idx += kSweepThreads) {
+    f(ri, ci);
+    ri += dr;
+    ci += dc;
+    if (ci >= nc) {
+      ci -= nc;
+      ++ri;
+    }
+  }
+}
+
+struct TileGeom {
+  uint32_t TW, TH;      // owned tile extent (even)
+  uint32_t tiles_x;     // tiles per row of tiles
+};
+
+__device__ __forceinline__ uint32_t wrap_add(uint32_t base, uint32_t off, uint32_t n) {
+  uint32_t v = base + off;
+  while (v >= n) v -= n;
+  return v;
+}
+
+// ---- Schwinger sweeps ----------------------------------------------------------------------------
+// Colour order per sweep: (mu=0, j even), (mu=0, j odd), (mu=1, i even), (mu=1, i odd); links of one
+// colour do not appear in each other's staples (quenchedschwingeraction.cc:25-43).  Every link whose
+// six staple links lie inside the buffer is updated; the region of exact values shrinks by at most
+// two sites per side per sweep, so a halo of 2*nsweeps keeps the owned tile exact (tile origins are
+// even, which makes buffer parity equal lattice parity).
+__global__ void __launch_bounds__(kSweepThreads)
+    schwinger_sweep_kernel(uint32_t Mt, uint32_t Mx, double beta, const double2 *__restrict__ in,
+                           double2 *__restrict__ out, TileGeom tg, uint32_t nsweeps, uint32_t kinds, RngKey key0) {
+  extern __shared__ double lds[];
+  const uint32_t H = 2 * nsweeps;
+  const uint32_t tile = blockIdx.x, b = blockIdx.y;
+  const uint32_t ty = tile / tg.tiles_x, tx = tile - ty * tg.tiles_x;
+  const uint32_t i0 = tx * tg.TW, j0 = ty * tg.TH;
+  const uint32_t ow = min(tg.TW, Mt - i0), oh = min(tg.TH, Mx - j0);
+  const uint32_t bw = ow + 2 * H, bh = oh + 2 * H;
+  double *th0 = lds, *th1 = lds + (size_t)bw * bh;
+  const uint32_t sc = (uint32_t)(((uint64_t)i0 + Mt - (H % Mt)) % Mt);  // lattice column of buffer column 0
+  const uint32_t sr = (uint32_t)(((uint64_t)j0 + Mx - (H % Mx)) % Mx);
+  const double2 *src = in + (size_t)b * Mt * Mx;
+  RngKey key = key0;
+  key.chain += b;
+
+  for_region(bh, bw, [&](uint32_t r, uint32_t c) {
+    const uint32_t jj = wrap_add(sr, r, Mx), ii = wrap_add(sc, c, Mt);
+    const double2 v = src[(size_t)jj * Mt + ii];
+    th0[r * bw + c] = v.x;
+    th1[r * bw + c] = v.y;
+  });
+  __syncthreads();
+
+  for (uint32_t s = 0; s < nsweeps; ++s) {
+    const bool heat = (kinds >> s) & 1u;
+    RngKey skey = key;
+    skey.step += s;
+    // mu = 0: rows of one parity, r in [1, bh-2], c in [0, bw-2]
+    for (uint32_t par = 0; par < 2; ++par) {
+      const uint32_t r_first = par ? 1 : 2;
+      const uint32_t nr = (bh - 2 - r_first) / 2 + 1;
+      for_region(nr, bw - 1, [&](uint32_t ri, uint32_t c) {
+        const uint32_t r = r_first + 2 * ri, o = r * bw + c;
+        const double tp = mod_2pi(th0[o + bw] + th1[o] - th1[o + 1]);
+        const double tm = mod_2pi(th0[o - bw] + th1[o - bw + 1] - th1[o - bw]);
+        double v;
+        if (heat) {
+          const uint32_t jj = wrap_add(sr, r, Mx), ii = wrap_add(sc, c, Mt);
+          v = expcos_draw(skey, 2 * (jj * Mt + ii), beta, tp, tm);
+        } else {
+          v = mod_2pi((tp + tm) - th0[o]);
+        }
+        th0[o] = v;
+      });
+      __syncthreads();
+    }
+    // mu = 1: columns of one parity, c in [1, bw-2], r in [0, bh-2]
+    for (uint32_t par = 0; par < 2; ++par) {
+      const uint32_t c_first = par ? 1 : 2;
+      const uint32_t nc = (bw - 2 - c_first) / 2 + 1;
+      for_region(bh - 1, nc, [&](uint32_t r, uint32_t ci) {
+        const uint32_t c = c_first + 2 * ci, o = r * bw + c;
+        const double tp = mod_2pi(th0[o] + th1[o + 1] - th0[o + bw]);
+        const double tm = mod_2pi(th0[o + bw - 1] + th1[o - 1] - th0[o - 1]);
+        double v;
+        if (heat) {
+          const uint32_t jj = wrap_add(sr, r, Mx), ii = wrap_add(sc, c, Mt);
+          v = expcos_draw(skey, 2 * (jj * Mt + ii) + 1, beta, tp, tm);
+        } else {
+          v = mod_2pi((tp + tm) - th1[o]);
+        }
+        th1[o] = v;
+      });
+      __syncthreads();
+    }
+  }
+
+  double2 *dst = out + (size_t)b * Mt * Mx;
+  for_region(oh, ow, [&](uint32_t r, uint32_t c) {
+    const uint32_t o = (r + H) * bw + (c + H);
+    dst[(size_t)(j0 + r) * Mt + (i0 + c)] = make_double2(th0[o], th1[o]);
+  });
+}
+
+// ---- GFF sweeps --------------------------------------------------------------------------------------
+// Red/black order: (i+j) even, then odd.  gffaction.cc:33-42 (heat bath), :68-77 (overrelaxation);
+// Delta is summed in the order of the reference's neighbour table (+i, -i, +j, -j).
+__global__ void __launch_bounds__(kSweepThreads)
+    gff_sweep_kernel(uint32_t Mt, uint32_t Mx, double mu2, const double *__restrict__ in, double *__restrict__ out,
+                     TileGeom tg, uint32_t nsweeps, uint32_t kinds, RngKey key0) {
+  extern __shared__ double lds[];
+  const uint32_t H = 2 * nsweeps;
+  const uint32_t tile = blockIdx.x, b = blockIdx.y;
+  const uint32_t ty = tile / tg.tiles_x, tx = tile - ty * tg.tiles_x;
+  const uint32_t i0 = tx * tg.TW, j0 = ty * tg.TH;
+  const uint32_t ow = min(tg.TW, Mt - i0), oh = min(tg.TH, Mx - j0);
+  const uint32_t bw = ow + 2 * H, bh = oh + 2 * H;
+  double *phi = lds;
+  const uint32_t sc = (uint32_t)(((uint64_t)i0 + Mt - (H % Mt)) % Mt);
+  const uint32_t sr = (uint32_t)(((uint64_t)j0 + Mx - (H % Mx)) % Mx);
+  const double *src = in + (size_t)b * Mt * Mx;
+  RngKey key = key0;
+  key.chain += b;
+  const double kappa = 4. + mu2, sigma = 1. / sqrt(4. + mu2);
+
+  for_region(bh, bw, [&](uint32_t r, uint32_t c) {
+    phi[r * bw + c] = src[(size_t)wrap_add(sr, r, Mx) * Mt + wrap_add(sc, c, Mt)];
+  });
+  __syncthreads();
+
+  for (uint32_t s = 0; s < nsweeps; ++s) {
+    const bool heat = (kinds >> s) & 1u;
+    RngKey skey = key;
+    skey.step += s;
+    for (uint32_t colour = 0; colour < 2; ++colour) {
+      for_region(bh - 2, (bw - 2) / 2, [&](uint32_t ri, uint32_t ci) {
+        const uint32_t r = 1 + ri;
+        const uint32_t c = 1 + ((r + 1 + colour) & 1u) + 2 * ci;
+        const uint32_t o = r * bw + c;
+        double Delta = 0.0;
+        Delta += phi[o + 1];
+        Delta += phi[o - 1];
+        Delta += phi[o + bw];
+        Delta += phi[o - bw];
+        double v;
+        if (heat) {
+          const uint32_t ell = wrap_add(sr, r, Mx) * Mt + wrap_add(sc, c, Mt);
+          double n0, n1;
+          rng_normals(skey, ell >> 1, P_GFF_NORMAL, 0, n0, n1);
+          v = sigma * ((ell & 1u) ? n1 : n0) + Delta / kappa;
+        } else {
+          v = 2. * Delta / kappa - phi[o];
+        }
+        phi[o] = v;
+      });
+      __syncthreads();
+    }
+  }
+
+  double *dst = out + (size_t)b * Mt * Mx;
+  for_region(oh, ow, [&](uint32_t r, uint32_t c) { dst[(size_t)(j0 + r) * Mt + (i0 + c)] = phi[(r + H) * bw + (c + H)]; });
+}
+
+// ---- streaming kernels: evaluate, force, QoI ----------------------------------------------------------
+enum LatOp { L_GFF_ENERGY = 0, L_PHI2 = 1, L_SCHW_ENERGY = 2, L_PLAQ = 3, L_CHARGE = 4 };
+
+__device__ __forceinline__ double plaquette_angle(const double2 *t, uint32_t Mt, uint32_t Mx, uint32_t i, uint32_t j) {
+  const uint32_t ip = (i + 1 == Mt) ? 0 : i + 1, jp = (j + 1 == Mx) ? 0 : j + 1;
+  // theta(i,j,0) + theta(i+1,j,1) - theta(i,j+1,0) - theta(i,j,1)   (quenchedschwingeraction.cc:14-17)
+  const double2 here = t[(size_t)j * Mt + i];
+  return here.x + t[(size_t)j * Mt + ip].y - t[(size_t)jp * Mt + i].x - here.y;
+}
+
+// grid (nrows_blocks, B): each workgroup strides over lattice rows j
+template <int OP>
+__global__ void __launch_bounds__(256) lattice_reduce_kernel(uint32_t Mt, uint32_t Mx, double mu2,
+                                                             const double *__restrict__ state,
+                                                             double *__restrict__ partial) {
+  __shared__ double red[4];
+  const uint32_t b = blockIdx.y;
+  double acc[1] = {0.0};
+  if (OP == L_GFF_ENERGY || OP == L_PHI2) {
+    const double *phi = state + (size_t)b * Mt * Mx;
+    const double kappa = 4. + mu2;
+    for (uint32_t j = blockIdx.x; j < Mx; j += gridDim.x) {
+      const uint32_t jm = j == 0 ? Mx - 1 : j - 1, jp = j + 1 == Mx ? 0 : j + 1;
+      for (uint32_t i = threadIdx.x; i < Mt; i += blockDim.x) {
+        const double v = phi[(size_t)j * Mt + i];
+        if (OP == L_PHI2) {
+          acc[0] += v * v;
+        } else {  // gffaction.cc:15-23
+          const uint32_t im = i == 0 ? Mt - 1 : i - 1, ip = i + 1 == Mt ? 0 : i + 1;
+          double loc = kappa * v;
+          loc -= phi[(size_t)j * Mt + ip];
+          loc -= phi[(size_t)j * Mt + im];
+          loc -= phi[(size_t)jp * Mt + i];
+          loc -= phi[(size_t)jm * Mt + i];
+          acc[0] += v * loc;
+        }
+      }
+    }
+  } else {
+    const double2 *t = (const double2 *)state + (size_t)b * Mt * Mx;
+    for (uint32_t j = blockIdx.x; j < Mx; j += gridDim.x)
+      for (uint32_t i = threadIdx.x; i < Mt; i += blockDim.x) {
+        const double th = plaquette_angle(t, Mt, Mx, i, j);
+        if (OP == L_SCHW_ENERGY) acc[0] += 1. - cos(th);
+        if (OP == L_PLAQ) acc[0] += cos(th);
+        if (OP == L_CHARGE) acc[0] += mod_2pi(th);
+      }
+  }
+  block_sum<1>(acc, red);
+  if (threadIdx.x == 0) partial[(size_t)b * gridDim.x + blockIdx.x] = acc[0];
+}
+
+__global__ void lattice_finish_kernel(const double *__restrict__ partial, uint32_t nsplit, uint32_t B, int op,
+                                      double scale, double *__restrict__ out) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  double s = 0.0;
+  for (uint32_t k = 0; k < nsplit; ++k) s += partial[(size_t)b * nsplit + k];
+  out[b] = (op == L_CHARGE) ? (1. / (4. * kPi * kPi)) * s * s : scale * s;  // qoi2dsusceptibility.cc:26
+}
+
+// gffaction.cc:80-94
+__global__ void __launch_bounds__(256) gff_force_kernel(uint32_t Mt, uint32_t Mx, double mu2,
+                                                        const double *__restrict__ phi_all, double *__restrict__ f_all) {
+  const uint32_t b = blockIdx.y;
+  const double *phi = phi_all + (size_t)b * Mt * Mx;
+  double *f = f_all + (size_t)b * Mt * Mx;
+  const double kappa = 4. + mu2;
+  for (uint32_t j = blockIdx.x; j < Mx; j += gridDim.x) {
+    const uint32_t jm = j == 0 ? Mx - 1 : j - 1, jp = j + 1 == Mx ? 0 : j + 1;
+    for (uint32_t i = threadIdx.x; i < Mt; i += blockDim.x) {
+      const uint32_t im = i == 0 ? Mt - 1 : i - 1, ip = i + 1 == Mt ? 0 : i + 1;
+      double m = kappa * phi[(size_t)j * Mt + i];
+      m -= phi[(size_t)j * Mt + ip];
+      m -= phi[(size_t)j * Mt + im];
+      m -= phi[(size_t)jp * Mt + i];
+      m -= phi[(size_t)jm * Mt + i];
+      f[(size_t)j * Mt + i] = m;
+    }
+  }
+}
+
+// Gather form of quenchedschwingeraction.cc:68-89: the reference scatters +-beta sin(theta_P) of
+// plaquette (i,j) onto its four links; link (i,j,0) therefore receives F(i,j) - F(i,j-1) and link
+// (i,j,1) receives F(i-1,j) - F(i,j) (each a two-term sum, so the value is order independent).
+__global__ void __launch_bounds__(256) schwinger_force_kernel(uint32_t Mt, uint32_t Mx, double beta,
+                                                              const double2 *__restrict__ t_all,
+                                                              double2 *__restrict__ f_all) {
+  const uint32_t b = blockIdx.y;
+  const double2 *t = t_all + (size_t)b * Mt * Mx;
+  double2 *f = f_all + (size_t)b * Mt * Mx;
+  for (uint32_t j = blockIdx.x; j < Mx; j += gridDim.x) {
+    const uint32_t jm = j == 0 ? Mx - 1 : j - 1;
+    for (uint32_t i = threadIdx.x; i < Mt; i += blockDim.x) {
+      const uint32_t im = i == 0 ? Mt - 1 : i - 1;
+      const double F = beta * sin(plaquette_angle(t, Mt, Mx, i, j));
+      const double Fd = beta * sin(plaquette_angle(t, Mt, Mx, i, jm));
+      const double Fl = beta * sin(plaquette_angle(t, Mt, Mx, im, j));
+      f[(size_t)j * Mt + i] = make_double2(F - Fd, Fl - F);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) lattice_init_kernel(int kind, uint32_t n, RngKey key0, double *__restrict__ x) {
+  const uint32_t b = blockIdx.y;
+  RngKey key = key0;
+  key.chain += b;
+  double *xb = x + (size_t)b * n;
+  for (uint32_t l = blockIdx.x * blockDim.x + threadIdx.x; l < n; l += gridDim.x * blockDim.x) {
+    if (kind == MLMCPI_SCHWINGER) {
+      double u, v;
+      rng_uniforms(key, l, P_INIT, 0, u, v);
+      xb[l] = -kPi + 2.0 * kPi * u;
+    } else {
+      xb[l] = rng_normal0(key, l, P_INIT, 0);
+    }
+  }
+}
+
+// packed per-chain sums for the cross-rank reduction: [n, sum q, sum q^2, sum q^3, sum q^4]
+__global__ void stats_accumulate_kernel(double *__restrict__ acc, const double *__restrict__ q, uint32_t B) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const double v = q[b];
+  double *a = acc + 5 * (size_t)b;
+  a[0] += 1.0;
+  a[1] += v;
+  a[2] += v * v;
+  a[3] += v * v * v;
+  a[4] += v * v * v * v;
+}
+
+// ---- host dispatch ----------------------------------------------------------------------------------------
+static int check_lattice(const mlmcpi_lattice_action *act) {
+  if (!act) return fail(MLMCPI_ERR_INVALID, "action is NULL");
+  if (act->kind != MLMCPI_GFF && act->kind != MLMCPI_SCHWINGER)
+    return fail(MLMCPI_ERR_INVALID, "kind %d is not a 2-D lattice action", act->kind);
+  if (act->Mt < 2 || act->Mx < 2) return fail(MLMCPI_ERR_INVALID, "lattice %u x %u too small", act->Mt, act->Mx);
+  if ((uint64_t)act->Mt * act->Mx > (1ull << 30)) return fail(MLMCPI_ERR_INVALID, "lattice too large for 32-bit site indices");
+  // gffaction.hh:169-173: the GFF action requires a square lattice
+  if (act->kind == MLMCPI_GFF && act->Mt != act->Mx)
+    return fail(MLMCPI_ERR_INVALID, "Lattice has to be squared for GFF action");
+  return MLMCPI_OK;
+}
+
+static double gff_mu2(const mlmcpi_lattice_action &A) {  // gffaction.hh:174-181 (unrotated lattice)
+  const double a_lat = 1. / A.Mt;
+  return a_lat * a_lat * A.mass * A.mass;
+}
+
+static uint32_t row_blocks(uint32_t Mx, uint32_t B) {
+  uint32_t want = (2048 + B - 1) / B;
+  return want < Mx ? (want ? want : 1) : Mx;
+}
+
+template <int OP>
+static int launch_lattice_reduce(uint32_t Mt, uint32_t Mx, double mu2, const double *d_state, uint32_t B, double scale,
+                                 double *d_out, hipStream_t st) {
+  const uint32_t nsplit = row_blocks(Mx, B);
+  void *ws = nullptr;
+  if (int rc = scratch((size_t)B * nsplit * sizeof(double), &ws)) return rc;
+  hipLaunchKernelGGL((lattice_reduce_kernel<OP>), dim3(nsplit, B), dim3(256), 0, st, Mt, Mx, mu2, d_state, (double *)ws);
+  MLMCPI_LAUNCH_CHECK("lattice_reduce_kernel");
+  hipLaunchKernelGGL(lattice_finish_kernel, dim3((B + 255) / 256), dim3(256), 0, st, (const double *)ws, nsplit, B, OP,
+                     scale, d_out);
+  MLMCPI_LAUNCH_CHECK("lattice_finish_kernel");
+  return MLMCPI_OK;
+}
+
+static bool g_lds_attr_set = false;
+
+}  // namespace mlmcpi
+
+using namespace mlmcpi;
+
+extern "C" {
+
+int mlmcpi_lattice_state_size(const mlmcpi_lattice_action *act, uint32_t *n) {
+  if (int rc = check_lattice(act)) return rc;
+  MLMCPI_REQUIRE(n, "n is NULL");
+  *n = (act->kind == MLMCPI_SCHWINGER ? 2u : 1u) * act->Mt * act->Mx;
+  return MLMCPI_OK;
+}
+
+int mlmcpi_lattice_evaluate(const mlmcpi_lattice_action *act, const double *d_phi, uint32_t B, double *d_S,
+                            void *stream) {
+  if (int rc = check_lattice(act)) return rc;
+  MLMCPI_REQUIRE(d_phi && d_S && B > 0, "bad arguments");
+  if (act->kind == MLMCPI_GFF)
+    return launch_lattice_reduce<L_GFF_ENERGY>(act->Mt, act->Mx, gff_mu2(*act), d_phi, B, 0.5, d_S, as_stream(stream));
+  return launch_lattice_reduce<L_SCHW_ENERGY>(act->Mt, act->Mx, 0.0, d_phi, B, act->beta, d_S, as_stream(stream));
+}
+
+int mlmcpi_lattice_force(const mlmcpi_lattice_action *act, const double *d_phi, double *d_f, uint32_t B,
+                         void *stream) {
+  if (int rc = check_lattice(act)) return rc;
+  MLMCPI_REQUIRE(d_phi && d_f && d_phi != d_f && B > 0, "bad arguments");
+  dim3 grid(row_blocks(act->Mx, B), B), block(256);
+  if (act->kind == MLMCPI_GFF)
+    hipLaunchKernelGGL(gff_force_kernel, grid, block, 0, as_stream(stream), act->Mt, act->Mx, gff_mu2(*act), d_phi, d_f);
+  else
+    hipLaunchKernelGGL(schwinger_force_kernel, grid, block, 0, as_stream(stream), act->Mt, act->Mx, act->beta,
+                       (const double2 *)d_phi, (double2 *)d_f);
+  MLMCPI_LAUNCH_CHECK("lattice force kernel");
+  return MLMCPI_OK;
+}
+
+int mlmcpi_lattice_initialise(const mlmcpi_lattice_action *act, double *d_phi, uint32_t B, uint64_t seed,
+                              uint32_t chain0, void *stream) {
+  if (int rc = check_lattice(act)) return rc;
+  MLMCPI_REQUIRE(d_phi && B > 0, "bad arguments");
+  uint32_t n = 0;
+  mlmcpi_lattice_state_size(act, &n);
+  uint32_t nb = (n + 255) / 256;
+  if (nb > 1024) nb = 1024;
+  hipLaunchKernelGGL(lattice_init_kernel, dim3(nb, B), dim3(256), 0, as_stream(stream), act->kind, n,
+                     make_key(seed, chain0, 0), d_phi);
+  MLMCPI_LAUNCH_CHECK("lattice_init_kernel");
+  return MLMCPI_OK;
+}
+
+int mlmcpi_lattice_sweep_draw(const mlmcpi_lattice_action *act, double *d_phi, double *d_scratch, uint32_t B,
+                              uint32_t n_overrelax, uint32_t n_heatbath, uint64_t seed, uint32_t chain0,
+                              uint32_t sweep0, uint32_t fuse, void *stream) {
+  if (int rc = check_lattice(act)) return rc;
+  MLMCPI_REQUIRE(d_phi && d_scratch && d_phi != d_scratch && B > 0, "bad arguments");
+  MLMCPI_REQUIRE(act->Mt % 2 == 0 && act->Mx % 2 == 0, "multicolour sweeps need even Mt, Mx (got %u x %u)", act->Mt,
+                 act->Mx);
+  if (fuse == 0) fuse = 1;
+  if (fuse > kMaxFuse) fuse = kMaxFuse;
+  hipStream_t st = as_stream(stream);
+  const bool schw = act->kind == MLMCPI_SCHWINGER;
+  TileGeom tg;
+  tg.TW = act->Mt < 64 ? act->Mt : 64;
+  tg.TH = act->Mx < 32 ? act->Mx : 32;
+  tg.tiles_x = (act->Mt + tg.TW - 1) / tg.TW;
+  const uint32_t tiles_y = (act->Mx + tg.TH - 1) / tg.TH;
+  const uint32_t total = n_overrelax + n_heatbath;
+  const size_t state_bytes = (size_t)B * act->Mt * act->Mx * (schw ? 16 : 8);
+  if (!g_lds_attr_set) {
+    // allow tiles with deep halos to use the full 160 KiB of LDS
+    MLMCPI_HIP_TRY(hipFuncSetAttribute((const void *)schwinger_sweep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MLMCPI_HIP_TRY(hipFuncSetAttribute((const void *)gff_sweep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    g_lds_attr_set = true;
+  }
+  double *src = d_phi, *dst = d_scratch;
+  uint32_t s = 0;
+  while (s < total) {
+    uint32_t n = total - s < fuse ? total - s : fuse;
+    // shrink the fused count until the tile + halo fits in LDS
+    for (;;) {
+      const size_t cells = (size_t)(tg.TW + 4 * n) * (tg.TH + 4 * n);
+      if (cells * (schw ? 16 : 8) <= 160 * 1024 || n == 1) break;
+      --n;
+    }
+    uint32_t kinds = 0;
+    for (uint32_t q = 0; q < n; ++q)
+      if (s + q >= n_overrelax) kinds |= 1u << q;
+    const size_t lds = (size_t)(tg.TW + 4 * n) * (tg.TH + 4 * n) * (schw ? 16 : 8);
+    const RngKey key = make_key(seed, chain0, sweep0 + s);
+    dim3 grid(tg.tiles_x * tiles_y, B), block(kSweepThreads);
+    if (schw)
+      hipLaunchKernelGGL(schwinger_sweep_kernel, grid, block, lds, st, act->Mt, act->Mx, act->beta,
+                         (const double2 *)src, (double2 *)dst, tg, n, kinds, key);
+    else
+      hipLaunchKernelGGL(gff_sweep_kernel, grid, block, lds, st, act->Mt, act->Mx, gff_mu2(*act), (const double *)src,
+                         dst, tg, n, kinds, key);
+    MLMCPI_LAUNCH_CHECK("lattice sweep kernel");
+    double *tmp = src; src = dst; dst = tmp;
+    s += n;
+  }
+  if (src != d_phi) MLMCPI_HIP_TRY(hipMemcpyAsync(d_phi, src, state_bytes, hipMemcpyDeviceToDevice, st));
+  return MLMCPI_OK;
+}
+
+int mlmcpi_qoi_phi_squared(const double *d_phi, uint32_t n_vertices, uint32_t B, double *d_out, void *stream) {
+  MLMCPI_REQUIRE(d_phi && d_out && B > 0 && n_vertices > 0, "bad arguments");
+  // treat the field as a 1 x n strip: the reduction does not need the geometry
+  uint32_t Mt = n_vertices, Mx = 1;
+  if (n_vertices > 4096)
+    for (uint32_t w = 4096; w >= 64; w >>= 1)
+      if (n_vertices % w == 0) { Mt = w; Mx = n_vertices / w; break; }
+  return launch_lattice_reduce<L_PHI2>(Mt, Mx, 0.0, d_phi, B, 1.0 / n_vertices, d_out, as_stream(stream));
+}
+
+int mlmcpi_qoi_avg_plaquette(const double *d_theta, uint32_t Mt, uint32_t Mx, uint32_t B, double *d_out,
+                             void *stream) {
+  MLMCPI_REQUIRE(d_theta && d_out && B > 0 && Mt > 1 && Mx > 1, "bad arguments");
+  return launch_lattice_reduce<L_PLAQ>(Mt, Mx, 0.0, d_theta, B, 1.0 / ((double)Mx * Mt), d_out, as_stream(stream));
+}
+
+int mlmcpi_qoi_2d_susceptibility(const double *d_theta, uint32_t Mt, uint32_t Mx, uint32_t B, double *d_out,
+                                 void *stream) {
+  MLMCPI_REQUIRE(d_theta && d_out && B > 0 && Mt > 1 && Mx > 1, "bad arguments");
+  return launch_lattice_reduce<L_CHARGE>(Mt, Mx, 0.0, d_theta, B, 1.0, d_out, as_stream(stream));
+}
+
+int mlmcpi_stats_accumulate(double *d_acc, const double *d_q, uint32_t B, void *stream) {
+  MLMCPI_REQUIRE(d_acc && d_q && B > 0, "bad arguments");
+  hipLaunchKernelGGL(stats_accumulate_kernel, dim3((B + 255) / 256), dim3(256), 0, as_stream(stream), d_acc, d_q, B);
+  MLMCPI_LAUNCH_CHECK("stats_accumulate_kernel");
+  return MLMCPI_OK;
+}
+
+}  // extern "C"
+
+// =================================================================================================
+// Generic HMC for 2-D actions (sampler/hmcsampler.cc:8-69), streaming form: momenta and the trial
+// state live in HBM, one fused force + momentum + position kernel per leapfrog step (ping-pong on
+// the trial state because neighbours need the old positions).
+// =================================================================================================
+namespace mlmcpi {
+
+// p ~ N(0,1) per entry (Philox site = entry index), trial <- current
+__global__ void __launch_bounds__(256)
+    lat_hmc_init_kernel(uint32_t n, const double *__restrict__ x_cur, double *__restrict__ x_trial,
+                        double *__restrict__ p, const int32_t *__restrict__ done, RngKey key0) {
+  const uint32_t b = blockIdx.y;
+  if (done[b]) return;
+  RngKey key = key0;
+  key.chain += b;
+  const size_t off = (size_t)b * n;
+  for (uint32_t l = blockIdx.x * blockDim.x + threadIdx.x; l < n; l += gridDim.x * blockDim.x) {
+    p[off + l] = rng_normal0(key, l, P_MOMENTUM, 0);
+    x_trial[off + l] = x_cur[off + l];
+  }
+}
+
+// one leapfrog step: F(x_in); p -= dtp F; x_out = x_in + dtx p
+template <int KIND>
+__global__ void __launch_bounds__(256)
+    lat_hmc_step_kernel(uint32_t Mt, uint32_t Mx, double coupling, const double *__restrict__ x_in,
+                        double *__restrict__ x_out, double *__restrict__ p_all, const int32_t *__restrict__ done,
+                        double dtp, double dtx) {
+  const uint32_t b = blockIdx.y;
+  if (done[b]) return;
+  if (KIND == MLMCPI_GFF) {
+    const double *phi = x_in + (size_t)b * Mt * Mx;
+    double *out = x_out + (size_t)b * Mt * Mx, *p = p_all + (size_t)b * Mt * Mx;
+    const double kappa = 4. + coupling;
+    for (uint32_t j = blockIdx.x; j < Mx; j += gridDim.x) {
+      const uint32_t jm = j == 0 ? Mx - 1 : j - 1, jp = j + 1 == Mx ? 0 : j + 1;
+      for (uint32_t i = threadIdx.x; i < Mt; i += blockDim.x) {
+        const uint32_t im = i == 0 ? Mt - 1 : i - 1, ip = i + 1 == Mt ? 0 : i + 1;
+        const size_t o = (size_t)j * Mt + i;
+        double F = kappa * phi[o];
+        F -= phi[(size_t)j * Mt + ip];
+        F -= phi[(size_t)j * Mt + im];
+        F -= phi[(size_t)jp * Mt + i];
+        F -= phi[(size_t)jm * Mt + i];
+        const double pn = p[o] - dtp * F;
+        p[o] = pn;
+        out[o] = phi[o] + dtx * pn;
+      }
+    }
+  } else {
+    const double2 *t = (const double2 *)x_in + (size_t)b * Mt * Mx;
+    double2 *out = (double2 *)x_out + (size_t)b * Mt * Mx, *p = (double2 *)p_all + (size_t)b * Mt * Mx;
+    for (uint32_t j = blockIdx.x; j < Mx; j += gridDim.x) {
+      const uint32_t jm = j == 0 ? Mx - 1 : j - 1;
+      for (uint32_t i = threadIdx.x; i < Mt; i += blockDim.x) {
+        const uint32_t im = i == 0 ? Mt - 1 : i - 1;
+        const size_t o = (size_t)j * Mt + i;
+        const double F = coupling * sin(plaquette_angle(t, Mt, Mx, i, j));
+        const double Fd = coupling * sin(plaquette_angle(t, Mt, Mx, i, jm));
+        const double Fl = coupling * sin(plaquette_angle(t, Mt, Mx, im, j));
+        double2 pn = p[o];
+        pn.x -= dtp * (F - Fd);
+        pn.y -= dtp * (Fl - F);
+        p[o] = pn;
+        const double2 xo = t[o];
+        out[o] = make_double2(xo.x + dtx * pn.x, xo.y + dtx * pn.y);
+      }
+    }
+  }
+}
+
+// en4 = [4][B]: S0, T0, S1, T1 (already scaled).  hmcsampler.cc:50-67.
+__global__ void __launch_bounds__(256)
+    lat_hmc_accept_kernel(uint32_t n, double *__restrict__ x_cur, const double *__restrict__ x_trial,
+                          const double *__restrict__ en4, uint32_t B, const int32_t *__restrict__ done_in,
+                          int32_t *__restrict__ done_out, double *__restrict__ energies, RngKey key0) {
+  const uint32_t b = blockIdx.y;
+  if (done_in[b]) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) done_out[b] = 1;
+    return;
+  }
+  const double S0 = en4[b], T0 = en4[B + b], S1 = en4[2 * B + b], T1 = en4[3 * B + b];
+  const double dH = (S1 - S0) + (T1 - T0);
+  bool acc;
+  if (dH < 0.0) {
+    acc = true;
+  } else {
+    RngKey key = key0;
+    key.chain += b;
+    double u, v;
+    rng_uniforms(key, 0, P_ACCEPT, 0, u, v);
+    acc = u < exp(-dH);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    done_out[b] = acc ? 1 : 0;
+    if (energies) {
+      energies[4 * b + 0] = S0; energies[4 * b + 1] = T0; energies[4 * b + 2] = S1; energies[4 * b + 3] = T1;
+    }
+  }
+  if (!acc) return;
+  const size_t off = (size_t)b * n;
+  for (uint32_t l = blockIdx.x * blockDim.x + threadIdx.x; l < n; l += gridDim.x * blockDim.x)
+    x_cur[off + l] = x_trial[off + l];
+}
+
+static size_t align256_(size_t n) { return (n + 255) & ~(size_t)255; }
+
+static int lattice_energy(const mlmcpi_lattice_action *act, const double *d_phi, uint32_t B, double *d_S, hipStream_t st) {
+  if (act->kind == MLMCPI_GFF)
+    return launch_lattice_reduce<L_GFF_ENERGY>(act->Mt, act->Mx, gff_mu2(*act), d_phi, B, 0.5, d_S, st);
+  return launch_lattice_reduce<L_SCHW_ENERGY>(act->Mt, act->Mx, 0.0, d_phi, B, act->beta, d_S, st);
+}
+
+static int kinetic_energy(const double *d_p, uint32_t n, uint32_t B, double *d_T, hipStream_t st) {
+  uint32_t w = n, h = 1;
+  if (n > 4096)
+    for (uint32_t c = 4096; c >= 64; c >>= 1)
+      if (n % c == 0) { w = c; h = n / c; break; }
+  return launch_lattice_reduce<L_PHI2>(w, h, 0.0, d_p, B, 0.5, d_T, st);
+}
+
+}  // namespace mlmcpi
+
+extern "C" {
+
+// workspace: p | trial A | trial B | energies [4][B] | flags [2][B]
+int mlmcpi_lattice_hmc_workspace_bytes(const mlmcpi_lattice_action *act, uint32_t B, size_t *bytes) {
+  if (int rc = check_lattice(act)) return rc;
+  MLMCPI_REQUIRE(bytes && B > 0, "bad arguments");
+  uint32_t n = 0;
+  mlmcpi_lattice_state_size(act, &n);
+  *bytes = 3 * align256_((size_t)B * n * 8) + align256_((size_t)4 * B * 8) + align256_((size_t)2 * B * 4);
+  return MLMCPI_OK;
+}
+
+int mlmcpi_lattice_hmc_draw(const mlmcpi_lattice_action *act, double *d_phi, uint32_t B, uint32_t nt, double dt,
+                            uint32_t n_rep, uint64_t seed, uint32_t chain0, uint32_t traj0, void *d_work,
+                            int32_t *d_accept, double *d_energies, void *stream) {
+  if (int rc = check_lattice(act)) return rc;
+  MLMCPI_REQUIRE(d_phi && d_work && B > 0 && n_rep > 0, "bad arguments");
+  uint32_t n = 0;
+  mlmcpi_lattice_state_size(act, &n);
+  hipStream_t st = as_stream(stream);
+  char *w = (char *)d_work;
+  const size_t sb = align256_((size_t)B * n * 8);
+  double *p = (double *)w, *xa = (double *)(w + sb), *xb = (double *)(w + 2 * sb);
+  double *en4 = (double *)(w + 3 * sb);
+  int32_t *flags = (int32_t *)(w + 3 * sb + align256_((size_t)4 * B * 8));
+  MLMCPI_HIP_TRY(hipMemsetAsync(flags, 0, (size_t)2 * B * 4, st));
+  uint32_t nb = (n + 255) / 256;
+  if (nb > 1024) nb = 1024;
+  const dim3 lin_grid(nb, B), row_grid(row_blocks(act->Mx, B), B), block(256);
+  const double coupling = act->kind == MLMCPI_GFF ? gff_mu2(*act) : act->beta;
+  for (uint32_t r = 0; r < n_rep; ++r) {
+    const int32_t *done_in = flags + (size_t)(r & 1) * B;
+    int32_t *done_out = flags + (size_t)((r + 1) & 1) * B;
+    const RngKey key = make_key(seed, chain0, traj0 + r);
+    hipLaunchKernelGGL(lat_hmc_init_kernel, lin_grid, block, 0, st, n, (const double *)d_phi, xa, p, done_in, key);
+    MLMCPI_LAUNCH_CHECK("lat_hmc_init_kernel");
+    if (int rc = lattice_energy(act, d_phi, B, en4, st)) return rc;
+    if (int rc = kinetic_energy(p, n, B, en4 + B, st)) return rc;
+    double *src = xa, *dst = xb;
+    for (uint32_t k = 0; k <= nt; ++k) {
+      const double dtp = (k == 0 || k == nt) ? 0.5 * dt : dt;
+      const double dtx = (k == nt) ? 0.0 : dt;
+      if (act->kind == MLMCPI_GFF)
+        hipLaunchKernelGGL(lat_hmc_step_kernel<MLMCPI_GFF>, row_grid, block, 0, st, act->Mt, act->Mx, coupling,
+                           (const double *)src, dst, p, done_in, dtp, dtx);
+      else
+        hipLaunchKernelGGL(lat_hmc_step_kernel<MLMCPI_SCHWINGER>, row_grid, block, 0, st, act->Mt, act->Mx, coupling,
+                           (const double *)src, dst, p, done_in, dtp, dtx);
+      MLMCPI_LAUNCH_CHECK("lat_hmc_step_kernel");
+      double *tmp = src; src = dst; dst = tmp;
+    }
+    if (int rc = lattice_energy(act, src, B, en4 + 2 * (size_t)B, st)) return rc;
+    if (int rc = kinetic_energy(p, n, B, en4 + 3 * (size_t)B, st)) return rc;
+    hipLaunchKernelGGL(lat_hmc_accept_kernel, lin_grid, block, 0, st, n, d_phi, (const double *)src,
+                       (const double *)en4, B, done_in, done_out, d_energies, key);
+    MLMCPI_LAUNCH_CHECK("lat_hmc_accept_kernel");
+  }
+  if (d_accept)
+    MLMCPI_HIP_TRY(hipMemcpyAsync(d_accept, flags + (size_t)(n_rep & 1) * B, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
+  return MLMCPI_OK;
+}
+
+}  // extern "C"

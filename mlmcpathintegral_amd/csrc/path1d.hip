@@ -1,0 +1,600 @@
+// path1d.hip -- 1-D path kernels (harmonic / quartic oscillator, topological rotor), batched over
+// B chains laid out chain-major x[b*M + j]:
+//   * Action::evaluate / Action::force                      (standalone, drop-in methods)
+//   * QoIXsquared / QoISusceptibility
+//   * fused HMC trajectory: state AND momenta stay in registers for the whole trajectory, one
+//     workgroup per chain segment, halo of nt+1 sites recomputed redundantly, so HBM sees one read
+//     and one write of the path per trajectory instead of 4 x 8 B per site per leapfrog step
+//   * rotor overrelaxation / heat-bath sweeps (even / odd colouring) on LDS-resident segments
+#include "internal.hpp"
+
+namespace mlmcpi {
+
+struct PathP {
+  int kind;
+  uint32_t M;
+  double a, m0, mu2, lambda, x0;
+  double c1;      // m0 / a
+  double c2;      // 2 + a^2 mu2
+  double c3;      // a lambda
+  double inv_a2;  // 1 / a^2
+  double T_final;
+};
+
+static PathP make_params(const mlmcpi_path_action &A) {
+  PathP P;
+  P.kind = A.kind;
+  P.M = A.M;
+  P.T_final = A.T_final;
+  P.a = A.T_final / A.M;  // lattice/lattice1d.cc:9
+  P.m0 = A.m0;
+  P.mu2 = A.mu2;
+  P.lambda = A.lambda;
+  P.x0 = A.x0;
+  P.c1 = A.m0 / P.a;
+  P.c2 = 2. + P.a * P.a * A.mu2;
+  P.c3 = P.a * A.lambda;
+  P.inv_a2 = 1. / (P.a * P.a);
+  return P;
+}
+
+// Site term of the action involving x_j and its left neighbour; S = energy_scale * sum_j term_j.
+//   HO       harmonicoscillatoraction.cc:8-18     S = (a m0/2) sum [ (dx)^2/a^2 + mu2 x^2 ]
+//   quartic  quarticoscillatoraction.cc:7-27      S = (a/2) sum [ m0((dx)^2/a^2 + mu2 x^2) + (lambda/2)(x-x0)^4 ]
+//   rotor    rotoraction.cc:9-18                  S = (m0/a) sum [ 1 - cos(dx) ]
+template <int KIND>
+__device__ __forceinline__ double site_energy(const PathP &P, double x, double xl) {
+  const double d = x - xl;
+  if (KIND == MLMCPI_HARMONIC) return P.inv_a2 * d * d + P.mu2 * x * x;
+  if (KIND == MLMCPI_QUARTIC) {
+    const double sh = x - P.x0, sh2 = sh * sh;
+    return P.m0 * (P.inv_a2 * d * d + P.mu2 * (x * x)) + 0.5 * P.lambda * sh2 * sh2;
+  }
+  return 1. - cos(d);
+}
+
+__host__ __device__ inline double energy_scale(const PathP &P) {
+  if (P.kind == MLMCPI_HARMONIC) return 0.5 * P.a * P.m0;
+  if (P.kind == MLMCPI_QUARTIC) return 0.5 * P.a;
+  return P.m0 / P.a;
+}
+
+// Force on site j.  HO harmonicoscillatoraction.cc:21-35, quartic quarticoscillatoraction.cc:30-53,
+// rotor rotoraction.cc:59-79.
+template <int KIND>
+__device__ __forceinline__ double site_force(const PathP &P, double xl, double x, double xr) {
+  if (KIND == MLMCPI_ROTOR) return P.c1 * (sin(x - xl) + sin(x - xr));
+  double f = P.c1 * (P.c2 * x - xl - xr);
+  if (KIND == MLMCPI_QUARTIC) {
+    const double sh = x - P.x0;
+    f += P.c3 * sh * sh * sh;
+  }
+  return f;
+}
+
+// ---- standalone evaluate / force / QoI ------------------------------------------------------------
+enum ReduceOp { R_ENERGY = 0, R_XSQUARED = 1, R_WINDING = 2 };
+
+// grid (nsplit, B); partial[b*nsplit + s] = sum over the split's sites of the site term
+template <int KIND, int OP>
+__global__ void __launch_bounds__(256) path_reduce_kernel(PathP P, const double *__restrict__ x,
+                                                          double *__restrict__ partial) {
+  __shared__ double red[4];
+  const uint32_t b = blockIdx.y, M = P.M;
+  const double *xb = x + (size_t)b * M;
+  const uint32_t per = (M + gridDim.x - 1) / gridDim.x;
+  const uint32_t lo = blockIdx.x * per, hi = min(M, lo + per);
+  double acc[1] = {0.0};
+  for (uint32_t j = lo + threadIdx.x; j < hi; j += blockDim.x) {
+    const double xj = xb[j], xl = xb[j == 0 ? M - 1 : j - 1];
+    if (OP == R_ENERGY) acc[0] += site_energy<KIND>(P, xj, xl);
+    if (OP == R_XSQUARED) acc[0] += xj * xj;
+    if (OP == R_WINDING) acc[0] += mod_2pi(xj - xl);
+  }
+  block_sum<1>(acc, red);
+  if (threadIdx.x == 0) partial[(size_t)b * gridDim.x + blockIdx.x] = acc[0];
+}
+
+// out[b] = finish(sum_s partial[b][s]); one thread per chain, fixed summation order
+__global__ void path_finish_kernel(const double *__restrict__ partial, uint32_t nsplit, uint32_t B, int op,
+                                   double scale, double *__restrict__ out) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  double s = 0.0;
+  for (uint32_t k = 0; k < nsplit; ++k) s += partial[(size_t)b * nsplit + k];
+  // R_WINDING: chi = Q^2 / (4 pi^2 T)  (qoisusceptibility.cc:20-22); others: scale * sum
+  out[b] = (op == R_WINDING) ? (1. / (4. * kPi * kPi)) * (s * s) * scale : scale * s;
+}
+
+template <int KIND>
+__global__ void __launch_bounds__(256) path_force_kernel(PathP P, const double *__restrict__ x,
+                                                         double *__restrict__ f) {
+  const uint32_t b = blockIdx.y, M = P.M;
+  const double *xb = x + (size_t)b * M;
+  double *fb = f + (size_t)b * M;
+  for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < M; j += gridDim.x * blockDim.x) {
+    const double xl = xb[j == 0 ? M - 1 : j - 1], xr = xb[j + 1 == M ? 0 : j + 1];
+    fb[j] = site_force<KIND>(P, xl, xb[j], xr);
+  }
+}
+
+__global__ void __launch_bounds__(256) path_init_kernel(int kind, uint32_t M, RngKey key0, double *__restrict__ x) {
+  const uint32_t b = blockIdx.y;
+  RngKey key = key0;
+  key.chain += b;
+  double *xb = x + (size_t)b * M;
+  for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < M; j += gridDim.x * blockDim.x) {
+    if (kind == MLMCPI_ROTOR) {
+      double u, v;
+      rng_uniforms(key, j, P_INIT, 0, u, v);
+      xb[j] = -kPi + 2.0 * kPi * u;
+    } else {
+      xb[j] = 0.0;
+    }
+  }
+}
+
+// ---- fused HMC trajectory ---------------------------------------------------------------------------
+// Grid (nseg, B), NT threads, R consecutive sites per thread: buffer site k = t*R + r maps to global
+// site (g0 + k) mod M.  halo == 0 means the buffer IS the periodic path (NT*R == M).  Otherwise the
+// first / last `halo` = nt+1 buffer sites are recomputed copies of the neighbouring segments; the
+// error front entering from the clamped buffer ends advances one site per leapfrog step and never
+// reaches an owned site.  Only boundary values move through LDS (2 doubles per thread per step,
+// double buffered -> one barrier per step).
+//
+// sampler/hmcsampler.cc:22-57: p ~ N(0,1); T0; nt+1 force evaluations with half steps for p at
+// both ends and no position update after the last; T1; S(x_trial), S(x_cur).
+template <int KIND, int R>
+__global__ void __launch_bounds__(R >= 8 ? 512 : 1024)
+    hmc_trajectory_kernel(PathP P, const double *__restrict__ x_cur, double *__restrict__ x_trial,
+                          double *__restrict__ partials, const int32_t *__restrict__ done, uint32_t owned_len,
+                          uint32_t halo, uint32_t nt, double dt, RngKey key0) {
+  extern __shared__ double lds[];  // [2][2][NT] boundary exchange | 4*NT/64 reduction scratch | [R][NT] staging
+  const uint32_t b = blockIdx.y, seg = blockIdx.x, t = threadIdx.x, NT = blockDim.x, M = P.M;
+  if (done[b]) return;  // reference: repetitions after an acceptance are not run (hmcsampler.cc:10-12)
+  const bool periodic = (halo == 0);
+  const uint32_t o0 = seg * owned_len;
+  const uint32_t olen = min(owned_len, M - o0);
+  const uint32_t g0 = (uint32_t)(((uint64_t)o0 + M - (halo % M)) % M);
+  const uint32_t kbase = t * R;
+  const double *xb = x_cur + (size_t)b * M;
+  RngKey key = key0;
+  key.chain += b;
+
+  // Momenta are generated in a rolled loop through LDS: unrolled, the R Box-Muller chains get
+  // interleaved and their temporaries push the 2R doubles of state out of the register file.
+  double *ex_first = lds, *ex_last = lds + 2 * NT;  // [2][NT] each
+  double *stage = lds + 4 * NT + 4 * (NT / kWave);  // [R][NT]
+  {
+    uint32_t g = (uint32_t)(((uint64_t)g0 + kbase) % M);
+#pragma unroll 1
+    for (int r = 0; r < R; ++r) {
+      stage[r * NT + t] = rng_normal0(key, g, P_MOMENTUM, 0);
+      g = (g + 1 == M) ? 0 : g + 1;
+    }
+  }
+  double x[R], p[R];
+  uint32_t g = (uint32_t)(((uint64_t)g0 + kbase) % M);
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    x[r] = xb[g];
+    p[r] = stage[r * NT + t];  // written by this thread: no barrier needed
+    g = (g + 1 == M) ? 0 : g + 1;
+  }
+
+  int buf = 0;
+  double xl, xr;
+  auto exchange = [&]() {
+    ex_first[buf * NT + t] = x[0];
+    ex_last[buf * NT + t] = x[R - 1];
+    __syncthreads();
+    if (t == 0)
+      xl = periodic ? ex_last[buf * NT + NT - 1] : x[0];
+    else
+      xl = ex_last[buf * NT + t - 1];
+    if (t == NT - 1)
+      xr = periodic ? ex_first[buf * NT] : x[R - 1];
+    else
+      xr = ex_first[buf * NT + t + 1];
+    buf ^= 1;
+  };
+
+  // owned mask of buffer site k: halo <= k < halo + olen
+  auto owned = [&](int r) { return (kbase + r - halo) < olen; };
+
+  double sums[4] = {0.0, 0.0, 0.0, 0.0};  // S_cur, T0, S_trial, T1 (raw site sums)
+  exchange();
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    if (owned(r)) {
+      sums[0] += site_energy<KIND>(P, x[r], r == 0 ? xl : x[r - 1]);
+      sums[1] += p[r] * p[r];
+    }
+    if (KIND == MLMCPI_ROTOR) __builtin_amdgcn_sched_barrier(0);
+  }
+
+  for (uint32_t k = 0; k <= nt; ++k) {
+    const double dtp = (k == 0 || k == nt) ? 0.5 * dt : dt;
+    const double dtx = (k == nt) ? 0.0 : dt;
+    if (KIND == MLMCPI_ROTOR) {
+      // one sine per link: d_r = sin(x_r - x_{r-1}); F_r = c1 (d_r - d_{r+1}), identical to
+      // c1 (sin(x-x_m) + sin(x-x_p)) because sin is odd
+      double dprev = sin(x[0] - xl);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const double dnext = sin((r == R - 1 ? xr : x[r + 1]) - x[r]);
+        p[r] -= dtp * (P.c1 * (dprev - dnext));
+        dprev = dnext;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+      double left = xl;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const double right = (r == R - 1) ? xr : x[r + 1];
+        const double f = site_force<KIND>(P, left, x[r], right);
+        left = x[r];
+        p[r] -= dtp * f;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) x[r] += dtx * p[r];
+    if (k < nt) exchange();  // positions do not change in the last step: xl stays valid
+  }
+
+  double *xt = x_trial + (size_t)b * M;
+  g = (uint32_t)(((uint64_t)g0 + kbase) % M);
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    if (owned(r)) {
+      sums[2] += site_energy<KIND>(P, x[r], r == 0 ? xl : x[r - 1]);
+      sums[3] += p[r] * p[r];
+      xt[g] = x[r];
+    }
+    g = (g + 1 == M) ? 0 : g + 1;
+    if (KIND == MLMCPI_ROTOR) __builtin_amdgcn_sched_barrier(0);
+  }
+  block_sum<4>(sums, lds + 4 * NT);
+  if (t == 0) {
+    double *out = partials + ((size_t)b * gridDim.x + seg) * 4;
+    out[0] = sums[0]; out[1] = sums[1]; out[2] = sums[2]; out[3] = sums[3];
+  }
+}
+
+// Global Metropolis test + copy of accepted trial states.  Grid (nblk, B).  Every workgroup of a
+// chain recomputes the (cheap) decision from the segment partials in the same order, so no
+// inter-workgroup hand-off is needed.  sampler/hmcsampler.cc:50-67.
+__global__ void __launch_bounds__(256)
+    hmc_accept_kernel(uint32_t M, double escale, double *__restrict__ x_cur, const double *__restrict__ x_trial,
+                      const double *__restrict__ partials, uint32_t nseg, const int32_t *__restrict__ done_in,
+                      int32_t *__restrict__ done_out, double *__restrict__ energies, RngKey key0) {
+  const uint32_t b = blockIdx.y;
+  if (done_in[b]) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) done_out[b] = 1;
+    return;
+  }
+  double s[4] = {0.0, 0.0, 0.0, 0.0};
+  for (uint32_t k = 0; k < nseg; ++k) {
+    const double *q = partials + ((size_t)b * nseg + k) * 4;
+    s[0] += q[0]; s[1] += q[1]; s[2] += q[2]; s[3] += q[3];
+  }
+  const double S0 = escale * s[0], T0 = 0.5 * s[1], S1 = escale * s[2], T1 = 0.5 * s[3];
+  const double dH = (S1 - S0) + (T1 - T0);
+  bool acc;
+  if (dH < 0.0) {
+    acc = true;
+  } else {
+    RngKey key = key0;
+    key.chain += b;
+    double u, v;
+    rng_uniforms(key, 0, P_ACCEPT, 0, u, v);
+    acc = u < exp(-dH);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    done_out[b] = acc ? 1 : 0;
+    if (energies) {
+      energies[4 * b + 0] = S0; energies[4 * b + 1] = T0; energies[4 * b + 2] = S1; energies[4 * b + 3] = T1;
+    }
+  }
+  if (!acc) return;
+  double *dst = x_cur + (size_t)b * M;
+  const double *src = x_trial + (size_t)b * M;
+  for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < M; j += gridDim.x * blockDim.x) dst[j] = src[j];
+}
+
+// ---- rotor sweeps -----------------------------------------------------------------------------------
+// Grid (nseg, B), 256 threads.  The segment plus a halo of 2 sites per fused sweep lives in LDS;
+// every site whose two neighbours are inside the buffer is updated, so stale values creep inwards
+// by at most two sites per sweep and never reach the owned range.  in != out (halo reads race with
+// the neighbours' writes otherwise).  kinds bit s = 1 -> sweep s is a heat-bath sweep.
+// rotoraction.cc:20-56, rotoraction.hh:195-213.
+__global__ void __launch_bounds__(256)
+    rotor_sweep_kernel(PathP P, const double *__restrict__ in, double *__restrict__ out, uint32_t owned_len,
+                       uint32_t nsweeps, uint32_t kinds, RngKey key0) {
+  extern __shared__ double buf[];
+  const uint32_t b = blockIdx.y, seg = blockIdx.x, M = P.M, halo = 2 * nsweeps;
+  const uint32_t o0 = seg * owned_len, olen = min(owned_len, M - o0);
+  const uint32_t L = olen + 2 * halo;
+  const uint32_t g0 = (uint32_t)(((uint64_t)o0 + M - (halo % M)) % M);
+  const double *xin = in + (size_t)b * M;
+  RngKey key = key0;
+  key.chain += b;
+  for (uint32_t k = threadIdx.x; k < L; k += blockDim.x) buf[k] = xin[(uint32_t)(((uint64_t)g0 + k) % M)];
+  __syncthreads();
+  const double sig_scale = 2.0 * P.m0 / P.a;  // W'' = (2 m0 / a) |cos((x+ - x-)/2)|
+  for (uint32_t s = 0; s < nsweeps; ++s) {
+    const bool heat = (kinds >> s) & 1u;
+    RngKey skey = key;
+    skey.step += s;
+    for (uint32_t colour = 0; colour < 2; ++colour) {
+      // buffer parity == global parity (g0 is even because o0, halo and M are)
+      for (uint32_t k = 2 - colour + 2 * threadIdx.x; k + 1 < L; k += 2 * blockDim.x) {
+        // k runs over {2,4,..} for colour 0 and {1,3,..} for colour 1
+        const double xm = buf[k - 1], xp = buf[k + 1];
+        double sm, cm, sp, cp;
+        sincos(xm, &sm, &cm);
+        sincos(xp, &sp, &cp);
+        const double x_min = atan2(sp + sm, cp + cm);
+        double xn;
+        if (heat) {
+          const double sigma = 2. * (sig_scale * fabs(cos(0.5 * (xp - xm))));
+          const uint32_t gsite = (uint32_t)(((uint64_t)g0 + k) % M);
+          xn = mod_2pi(x_min + expsin2_draw(skey, gsite, sigma));
+        } else {
+          xn = mod_2pi(2.0 * x_min - buf[k]);
+        }
+        buf[k] = xn;
+      }
+      __syncthreads();
+    }
+  }
+  double *xout = out + (size_t)b * M;
+  for (uint32_t k = threadIdx.x; k < olen; k += blockDim.x) xout[o0 + k] = buf[halo + k];
+}
+
+// ---- host dispatch ---------------------------------------------------------------------------------------
+static int check_action(const mlmcpi_path_action *act) {
+  if (!act) return fail(MLMCPI_ERR_INVALID, "action is NULL");
+  if (act->kind < MLMCPI_HARMONIC || act->kind > MLMCPI_ROTOR)
+    return fail(MLMCPI_ERR_INVALID, "kind %d is not a 1-D path action", act->kind);
+  if (act->M < 2) return fail(MLMCPI_ERR_INVALID, "M_lat = %u too small", act->M);
+  if (!(act->T_final > 0.0)) return fail(MLMCPI_ERR_INVALID, "T_final must be positive");
+  return MLMCPI_OK;
+}
+
+static uint32_t choose_split(uint32_t sites, uint32_t B) {
+  // enough workgroups to fill 256 CUs, at least ~1024 sites each
+  uint32_t want = (2048 + B - 1) / B, cap = (sites + 1023) / 1024;
+  uint32_t n = want < cap ? want : cap;
+  return n ? n : 1;
+}
+
+template <int OP>
+static int launch_reduce(const PathP &P, const double *d_x, uint32_t B, double scale, double *d_out, hipStream_t st) {
+  const uint32_t nsplit = choose_split(P.M, B);
+  void *ws = nullptr;
+  int rc = scratch((size_t)B * nsplit * sizeof(double), &ws);
+  if (rc) return rc;
+  dim3 grid(nsplit, B), block(256);
+  switch (P.kind) {
+    case MLMCPI_HARMONIC:
+      hipLaunchKernelGGL((path_reduce_kernel<MLMCPI_HARMONIC, OP>), grid, block, 0, st, P, d_x, (double *)ws);
+      break;
+    case MLMCPI_QUARTIC:
+      hipLaunchKernelGGL((path_reduce_kernel<MLMCPI_QUARTIC, OP>), grid, block, 0, st, P, d_x, (double *)ws);
+      break;
+    default:
+      hipLaunchKernelGGL((path_reduce_kernel<MLMCPI_ROTOR, OP>), grid, block, 0, st, P, d_x, (double *)ws);
+  }
+  MLMCPI_LAUNCH_CHECK("path_reduce_kernel");
+  hipLaunchKernelGGL(path_finish_kernel, dim3((B + 255) / 256), dim3(256), 0, st, (const double *)ws, nsplit, B, OP,
+                     scale, d_out);
+  MLMCPI_LAUNCH_CHECK("path_finish_kernel");
+  return MLMCPI_OK;
+}
+
+struct HmcPlan {
+  uint32_t R, NT, nseg, owned_len, halo;
+};
+
+// Register-resident geometry: the whole periodic path in one workgroup when M = NT*R fits
+// (NT a multiple of 64, R in {1,2,4,8,16}, NT <= 512 for R >= 8 so that 2R doubles of state plus
+// the sine's temporaries stay in VGPRs, else <= 1024), i.e. M <= 8192; longer paths are cut into
+// segments of NT*R buffer sites with a halo of nt+1.
+static int plan_hmc(int kind, uint32_t M, uint32_t B, uint32_t nt, HmcPlan *plan) {
+  const uint32_t maxR = (kind == MLMCPI_ROTOR) ? 8 : 16;  // the rotor's sines need the registers
+  static const uint32_t Rs[5] = {16, 8, 4, 2, 1};
+  uint32_t best = 0, fallback = 0, best_nt = 0, fallback_nt = 0;
+  for (uint32_t R : Rs) {
+    if (R > maxR || M % R) continue;
+    uint32_t NT = M / R;
+    if (NT % 64 || NT < 64 || NT > (R >= 8 ? 512u : 1024u)) continue;  // register budget: see launch bounds
+    if (!fallback || NT > fallback_nt) { fallback = R; fallback_nt = NT; }  // most parallel
+    if (!best && (uint64_t)B * (NT / 64) >= 2048) { best = R; best_nt = NT; }  // largest R that still fills the chip
+  }
+  if (best || fallback) {
+    plan->R = best ? best : fallback;
+    plan->NT = best ? best_nt : fallback_nt;
+    plan->nseg = 1;
+    plan->owned_len = M;
+    plan->halo = 0;
+    return MLMCPI_OK;
+  }
+  const uint32_t halo = nt + 1;
+  uint32_t R = maxR, NT = 4096 / maxR;
+  if (M + 2 * halo <= 1024) { R = 4; NT = 256; }  // short odd-sized paths
+  const uint32_t L = NT * R;
+  if (2 * halo + 64 > L) return fail(MLMCPI_ERR_INVALID, "nt = %u too long for the fused trajectory (max %u)", nt, (L - 64) / 2 - 1);
+  const uint32_t owned_max = L - 2 * halo;
+  const uint32_t nseg = (M + owned_max - 1) / owned_max;
+  plan->R = R;
+  plan->NT = NT;
+  plan->nseg = nseg;
+  plan->owned_len = (M + nseg - 1) / nseg;
+  plan->halo = halo;
+  return MLMCPI_OK;
+}
+
+template <int KIND>
+static int launch_traj(const HmcPlan &pl, const PathP &P, const double *x_cur, double *x_trial, double *partials,
+                       const int32_t *done, uint32_t B, uint32_t nt, double dt, RngKey key, hipStream_t st) {
+  dim3 grid(pl.nseg, B), block(pl.NT);
+  const size_t lds = (4 * pl.NT + 4 * (pl.NT / 64) + (size_t)pl.R * pl.NT) * sizeof(double);
+#define MLMCPI_TRAJ(RR)                                                                                          \
+  hipLaunchKernelGGL((hmc_trajectory_kernel<KIND, RR>), grid, block, lds, st, P, x_cur, x_trial, partials, done, \
+                     pl.owned_len, pl.halo, nt, dt, key)
+  switch (pl.R) {
+    case 16: MLMCPI_TRAJ(16); break;
+    case 8: MLMCPI_TRAJ(8); break;
+    case 4: MLMCPI_TRAJ(4); break;
+    case 2: MLMCPI_TRAJ(2); break;
+    default: MLMCPI_TRAJ(1);
+  }
+#undef MLMCPI_TRAJ
+  MLMCPI_LAUNCH_CHECK("hmc_trajectory_kernel");
+  return MLMCPI_OK;
+}
+
+static size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
+
+}  // namespace mlmcpi
+
+using namespace mlmcpi;
+
+extern "C" {
+
+int mlmcpi_path_evaluate(const mlmcpi_path_action *act, const double *d_x, uint32_t B, double *d_S, void *stream) {
+  if (int rc = check_action(act)) return rc;
+  MLMCPI_REQUIRE(d_x && d_S && B > 0, "bad arguments");
+  PathP P = make_params(*act);
+  return launch_reduce<R_ENERGY>(P, d_x, B, energy_scale(P), d_S, as_stream(stream));
+}
+
+int mlmcpi_path_force(const mlmcpi_path_action *act, const double *d_x, double *d_f, uint32_t B, void *stream) {
+  if (int rc = check_action(act)) return rc;
+  MLMCPI_REQUIRE(d_x && d_f && B > 0 && d_x != d_f, "bad arguments");
+  PathP P = make_params(*act);
+  dim3 grid(choose_split(P.M, B) , B), block(256);
+  hipStream_t st = as_stream(stream);
+  switch (P.kind) {
+    case MLMCPI_HARMONIC: hipLaunchKernelGGL(path_force_kernel<MLMCPI_HARMONIC>, grid, block, 0, st, P, d_x, d_f); break;
+    case MLMCPI_QUARTIC: hipLaunchKernelGGL(path_force_kernel<MLMCPI_QUARTIC>, grid, block, 0, st, P, d_x, d_f); break;
+    default: hipLaunchKernelGGL(path_force_kernel<MLMCPI_ROTOR>, grid, block, 0, st, P, d_x, d_f);
+  }
+  MLMCPI_LAUNCH_CHECK("path_force_kernel");
+  return MLMCPI_OK;
+}
+
+int mlmcpi_path_initialise(const mlmcpi_path_action *act, double *d_x, uint32_t B, uint64_t seed, uint32_t chain0,
+                           void *stream) {
+  if (int rc = check_action(act)) return rc;
+  MLMCPI_REQUIRE(d_x && B > 0, "bad arguments");
+  dim3 grid(choose_split(act->M, B), B), block(256);
+  hipLaunchKernelGGL(path_init_kernel, grid, block, 0, as_stream(stream), act->kind, act->M, make_key(seed, chain0, 0),
+                     d_x);
+  MLMCPI_LAUNCH_CHECK("path_init_kernel");
+  return MLMCPI_OK;
+}
+
+int mlmcpi_qoi_xsquared(const double *d_x, uint32_t M, uint32_t B, double *d_out, void *stream) {
+  MLMCPI_REQUIRE(d_x && d_out && B > 0 && M > 1, "bad arguments");
+  PathP P = {};
+  P.kind = MLMCPI_HARMONIC;
+  P.M = M;
+  return launch_reduce<R_XSQUARED>(P, d_x, B, 1.0 / M, d_out, as_stream(stream));
+}
+
+int mlmcpi_qoi_susceptibility(const double *d_x, uint32_t M, double T_final, uint32_t B, double *d_out,
+                              void *stream) {
+  MLMCPI_REQUIRE(d_x && d_out && B > 0 && M > 1 && T_final > 0, "bad arguments");
+  PathP P = {};
+  P.kind = MLMCPI_ROTOR;
+  P.M = M;
+  return launch_reduce<R_WINDING>(P, d_x, B, 1.0 / T_final, d_out, as_stream(stream));
+}
+
+// workspace layout: x_trial [B*M] | partials [B*nseg*4] | flags [2][B] int32
+int mlmcpi_path_hmc_workspace_bytes(const mlmcpi_path_action *act, uint32_t B, uint32_t nt, size_t *bytes) {
+  if (int rc = check_action(act)) return rc;
+  MLMCPI_REQUIRE(bytes && B > 0, "bad arguments");
+  HmcPlan pl;
+  if (int rc = plan_hmc(act->kind, act->M, B, nt, &pl)) return rc;
+  *bytes = align256((size_t)B * act->M * 8) + align256((size_t)B * pl.nseg * 4 * 8) + align256((size_t)2 * B * 4);
+  return MLMCPI_OK;
+}
+
+int mlmcpi_path_hmc_draw(const mlmcpi_path_action *act, double *d_x, uint32_t B, uint32_t nt, double dt,
+                         uint32_t n_rep, uint64_t seed, uint32_t chain0, uint32_t traj0, void *d_work,
+                         int32_t *d_accept, double *d_energies, void *stream) {
+  if (int rc = check_action(act)) return rc;
+  MLMCPI_REQUIRE(d_x && d_work && B > 0 && n_rep > 0, "bad arguments");
+  HmcPlan pl;
+  if (int rc = plan_hmc(act->kind, act->M, B, nt, &pl)) return rc;
+  PathP P = make_params(*act);
+  hipStream_t st = as_stream(stream);
+  char *w = (char *)d_work;
+  double *x_trial = (double *)w;
+  w += align256((size_t)B * P.M * 8);
+  double *partials = (double *)w;
+  w += align256((size_t)B * pl.nseg * 4 * 8);
+  int32_t *flags = (int32_t *)w;  // [2][B]
+  MLMCPI_HIP_TRY(hipMemsetAsync(flags, 0, (size_t)2 * B * 4, st));
+  const uint32_t copy_blocks = choose_split(P.M, B);
+  for (uint32_t r = 0; r < n_rep; ++r) {
+    const int32_t *done_in = flags + (size_t)(r & 1) * B;
+    int32_t *done_out = flags + (size_t)((r + 1) & 1) * B;
+    RngKey key = make_key(seed, chain0, traj0 + r);
+    int rc;
+    switch (P.kind) {
+      case MLMCPI_HARMONIC: rc = launch_traj<MLMCPI_HARMONIC>(pl, P, d_x, x_trial, partials, done_in, B, nt, dt, key, st); break;
+      case MLMCPI_QUARTIC: rc = launch_traj<MLMCPI_QUARTIC>(pl, P, d_x, x_trial, partials, done_in, B, nt, dt, key, st); break;
+      default: rc = launch_traj<MLMCPI_ROTOR>(pl, P, d_x, x_trial, partials, done_in, B, nt, dt, key, st);
+    }
+    if (rc) return rc;
+    hipLaunchKernelGGL(hmc_accept_kernel, dim3(copy_blocks, B), dim3(256), 0, st, P.M, energy_scale(P), d_x,
+                       (const double *)x_trial, (const double *)partials, pl.nseg, done_in, done_out, d_energies, key);
+    MLMCPI_LAUNCH_CHECK("hmc_accept_kernel");
+  }
+  if (d_accept)
+    MLMCPI_HIP_TRY(hipMemcpyAsync(d_accept, flags + (size_t)(n_rep & 1) * B, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
+  return MLMCPI_OK;
+}
+
+int mlmcpi_path_sweep_draw(const mlmcpi_path_action *act, double *d_x, double *d_scratch, uint32_t B,
+                           uint32_t n_overrelax, uint32_t n_heatbath, uint64_t seed, uint32_t chain0,
+                           uint32_t sweep0, void *stream) {
+  if (int rc = check_action(act)) return rc;
+  // action/action.hh:73-96: only the rotor implements local updates among the 1-D actions
+  if (act->kind != MLMCPI_ROTOR)
+    return fail(MLMCPI_ERR_UNSUPPORTED, "heat bath / overrelaxation update not implemented for this action");
+  MLMCPI_REQUIRE(d_x && d_scratch && d_x != d_scratch && B > 0, "bad arguments");
+  MLMCPI_REQUIRE(act->M % 2 == 0, "even/odd sweeps need an even number of sites (M_lat = %u)", act->M);
+  PathP P = make_params(*act);
+  hipStream_t st = as_stream(stream);
+  const uint32_t total = n_overrelax + n_heatbath;
+  double *src = d_x, *dst = d_scratch;
+  uint32_t s = 0;
+  while (s < total) {
+    // fuse up to 4 sweeps per launch; overrelaxation sweeps come first (sampler order)
+    uint32_t n = total - s < 4 ? total - s : 4, kinds = 0;
+    for (uint32_t q = 0; q < n; ++q)
+      if (s + q >= n_overrelax) kinds |= 1u << q;
+    const uint32_t halo = 2 * n;
+    uint32_t owned = 2048 - 2 * halo;  // even
+    if (owned > P.M) owned = P.M;
+    const uint32_t nseg = (P.M + owned - 1) / owned;
+    owned = (P.M + nseg - 1) / nseg;
+    owned += owned & 1;  // keep segment starts even
+    const uint32_t nseg2 = (P.M + owned - 1) / owned;
+    const size_t lds = (size_t)(owned + 2 * halo) * sizeof(double);
+    hipLaunchKernelGGL(rotor_sweep_kernel, dim3(nseg2, B), dim3(256), lds, st, P, (const double *)src, dst, owned, n,
+                       kinds, make_key(seed, chain0, sweep0 + s));
+    MLMCPI_LAUNCH_CHECK("rotor_sweep_kernel");
+    double *tmp = src; src = dst; dst = tmp;
+    s += n;
+  }
+  if (src != d_x) MLMCPI_HIP_TRY(hipMemcpyAsync(d_x, src, (size_t)B * P.M * 8, hipMemcpyDeviceToDevice, st));
+  return MLMCPI_OK;
+}
+
+}  // extern "C"

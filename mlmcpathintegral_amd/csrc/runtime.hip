@@ -1,0 +1,255 @@
+// runtime.hip -- plumbing entry points of the C ABI: errors, device selection, memory, host-side
+// index maps (lattice/lattice2d.hh:230-268,348-375; lattice/lattice1d.cc:11-18;
+// lattice/lattice2d.cc:137-155), RNG test hooks.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <mutex>
+
+#include "internal.hpp"
+
+namespace mlmcpi {
+
+static thread_local char g_err[512] = "";
+
+int fail(int status, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return status;
+}
+
+int fail_hip(hipError_t e, const char *what) {
+  snprintf(g_err, sizeof(g_err), "HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
+  return MLMCPI_ERR_HIP;
+}
+
+static std::mutex g_scratch_mutex;
+static void *g_scratch[64] = {nullptr};
+static size_t g_scratch_bytes[64] = {0};
+
+int scratch(size_t bytes, void **d_ptr) {
+  int dev = 0;
+  MLMCPI_HIP_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64) return fail(MLMCPI_ERR_INVALID, "device index %d out of range", dev);
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (g_scratch_bytes[dev] < bytes) {
+    if (g_scratch[dev]) {
+      MLMCPI_HIP_TRY(hipDeviceSynchronize());
+      MLMCPI_HIP_TRY(hipFree(g_scratch[dev]));
+      g_scratch[dev] = nullptr;
+      g_scratch_bytes[dev] = 0;
+    }
+    size_t want = bytes < (1u << 20) ? (1u << 20) : bytes;
+    MLMCPI_HIP_TRY(hipMalloc(&g_scratch[dev], want));
+    g_scratch_bytes[dev] = want;
+  }
+  *d_ptr = g_scratch[dev];
+  return MLMCPI_OK;
+}
+
+// ---- test kernels ------------------------------------------------------------------------------
+__global__ void test_random_kernel(RngKey key, uint32_t purpose, uint32_t sub, uint32_t n, double *out) {
+  uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  double u0, u1, n0, n1;
+  rng_uniforms(key, k, purpose, sub, u0, u1);
+  rng_normals(key, k, purpose, sub, n0, n1);
+  out[4 * k + 0] = u0;
+  out[4 * k + 1] = u1;
+  out[4 * k + 2] = n0;
+  out[4 * k + 3] = n1;
+}
+
+__global__ void test_philox_kernel(U4 ctr, uint32_t k0, uint32_t k1, uint32_t *out) {
+  U4 r = philox4x32_10(ctr.x, ctr.y, ctr.z, ctr.w, k0, k1);
+  out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
+}
+
+__global__ void test_expcos_kernel(RngKey key, double beta, const double *xp, const double *xm, uint32_t n,
+                                   double *out) {
+  uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) out[k] = expcos_draw(key, k, beta, xp[k], xm[k]);
+}
+
+__global__ void test_expsin2_kernel(RngKey key, const double *sigma, uint32_t n, double *out) {
+  uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) out[k] = expsin2_draw(key, k, sigma[k]);
+}
+
+}  // namespace mlmcpi
+
+using namespace mlmcpi;
+
+extern "C" {
+
+int mlmcpi_abi_version(void) { return MLMCPI_ABI_VERSION; }
+const char *mlmcpi_last_error(void) { return g_err; }
+
+int mlmcpi_device_count(int *count) {
+  MLMCPI_REQUIRE(count, "count is NULL");
+  hipError_t e = hipGetDeviceCount(count);
+  if (e != hipSuccess) {
+    *count = 0;
+    fail_hip(e, "hipGetDeviceCount");
+    return MLMCPI_ERR_NO_DEVICE;
+  }
+  return MLMCPI_OK;
+}
+
+int mlmcpi_set_device(int device) {
+  MLMCPI_HIP_TRY(hipSetDevice(device));
+  return MLMCPI_OK;
+}
+
+int mlmcpi_device_name(char *buf, size_t len) {
+  MLMCPI_REQUIRE(buf && len > 0, "buf is NULL");
+  int dev = 0;
+  MLMCPI_HIP_TRY(hipGetDevice(&dev));
+  hipDeviceProp_t prop;
+  MLMCPI_HIP_TRY(hipGetDeviceProperties(&prop, dev));
+  snprintf(buf, len, "%s (%s)", prop.name, prop.gcnArchName);
+  return MLMCPI_OK;
+}
+
+int mlmcpi_malloc(void **d_ptr, size_t bytes) {
+  MLMCPI_REQUIRE(d_ptr, "d_ptr is NULL");
+  MLMCPI_HIP_TRY(hipMalloc(d_ptr, bytes ? bytes : 8));
+  return MLMCPI_OK;
+}
+int mlmcpi_free(void *d_ptr) {
+  if (d_ptr) MLMCPI_HIP_TRY(hipFree(d_ptr));
+  return MLMCPI_OK;
+}
+int mlmcpi_memset(void *d_ptr, int value, size_t bytes, void *stream) {
+  MLMCPI_HIP_TRY(hipMemsetAsync(d_ptr, value, bytes, as_stream(stream)));
+  return MLMCPI_OK;
+}
+int mlmcpi_copy_h2d(void *d_dst, const void *src, size_t bytes, void *stream) {
+  MLMCPI_HIP_TRY(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, as_stream(stream)));
+  MLMCPI_HIP_TRY(hipStreamSynchronize(as_stream(stream)));
+  return MLMCPI_OK;
+}
+int mlmcpi_copy_d2h(void *dst, const void *d_src, size_t bytes, void *stream) {
+  MLMCPI_HIP_TRY(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, as_stream(stream)));
+  MLMCPI_HIP_TRY(hipStreamSynchronize(as_stream(stream)));
+  return MLMCPI_OK;
+}
+int mlmcpi_copy_d2d(void *d_dst, const void *d_src, size_t bytes, void *stream) {
+  MLMCPI_HIP_TRY(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, as_stream(stream)));
+  return MLMCPI_OK;
+}
+int mlmcpi_stream_synchronize(void *stream) {
+  MLMCPI_HIP_TRY(hipStreamSynchronize(as_stream(stream)));
+  return MLMCPI_OK;
+}
+
+// ---- index maps ----------------------------------------------------------------------------------
+uint32_t mlmcpi_vertex_cart2lin(uint32_t Mt, uint32_t Mx, int rotated, int i, int j) {
+  const int mt = (int)Mt, mx = (int)Mx;
+  if (rotated) {
+    const int half_t = mt / 2, half_x = mx / 2;
+    const int ii = ((i + mt) - (i & 1)) / 2, jj = ((j + mx) - (j & 1)) / 2;
+    return (uint32_t)(half_t * (jj % half_x) + ii % half_t + (mt * mx / 4) * (i & 1));
+  }
+  return (uint32_t)(mt * ((j + mx) % mx) + (i + mt) % mt);
+}
+
+void mlmcpi_vertex_lin2cart(uint32_t Mt, uint32_t Mx, int rotated, uint32_t ell, int *i, int *j) {
+  const int mt = (int)Mt, mx = (int)Mx;
+  if (rotated) {
+    const int quarter = mt * mx / 4, half_t = mt / 2;
+    const int parity = (int)ell / quarter;
+    const int rest = (int)ell - quarter * parity;
+    const int jh = rest / half_t;
+    *j = 2 * jh + parity;
+    *i = 2 * (rest - half_t * jh) + parity;
+  } else {
+    *j = (int)(ell / Mt);
+    *i = (int)(ell - Mt * (uint32_t)*j);
+  }
+}
+
+uint32_t mlmcpi_link_cart2lin(uint32_t Mt, uint32_t Mx, int i, int j, int mu) {
+  const int mt = (int)Mt, mx = (int)Mx;
+  return (uint32_t)(2 * mt * ((j + mx) % mx) + 2 * ((i + mt) % mt) + mu);
+}
+
+void mlmcpi_link_lin2cart(uint32_t Mt, uint32_t Mx, uint32_t ell, int *i, int *j, int *mu) {
+  (void)Mx;
+  const uint32_t row = ell / (2 * Mt), rest = ell - 2 * Mt * row;
+  *j = (int)row;
+  *i = (int)(rest >> 1);
+  *mu = (int)(rest & 1u);
+}
+
+int mlmcpi_neighbours_1d(uint32_t M, uint32_t *out) {
+  MLMCPI_REQUIRE(out && M > 0, "bad arguments");
+  for (uint32_t ell = 0; ell < M; ++ell) {
+    out[2 * ell] = (ell + M - 1) % M;
+    out[2 * ell + 1] = (ell + 1) % M;
+  }
+  return MLMCPI_OK;
+}
+
+int mlmcpi_neighbours_2d(uint32_t Mt, uint32_t Mx, int rotated, uint32_t *out) {
+  MLMCPI_REQUIRE(out && Mt > 0 && Mx > 0, "bad arguments");
+  MLMCPI_REQUIRE(!rotated || (Mt % 2 == 0 && Mx % 2 == 0), "rotated lattices need even Mt, Mx");
+  // nearest neighbours first, then diagonals (next-nearest on the rotated lattice)
+  static const int step_plain[8][2] = {{1, 0}, {-1, 0}, {0, 1}, {0, -1}, {1, 1}, {1, -1}, {-1, 1}, {-1, -1}};
+  static const int step_rot[8][2] = {{1, 1}, {1, -1}, {-1, 1}, {-1, -1}, {2, 0}, {-2, 0}, {0, 2}, {0, -2}};
+  const uint32_t nv = rotated ? Mt * Mx / 2 : Mt * Mx;
+  for (uint32_t ell = 0; ell < nv; ++ell) {
+    int i, j;
+    mlmcpi_vertex_lin2cart(Mt, Mx, rotated, ell, &i, &j);
+    for (int k = 0; k < 8; ++k) {
+      const int *s = rotated ? step_rot[k] : step_plain[k];
+      out[8 * ell + k] = mlmcpi_vertex_cart2lin(Mt, Mx, rotated, i + s[0], j + s[1]);
+    }
+  }
+  return MLMCPI_OK;
+}
+
+// ---- test hooks ------------------------------------------------------------------------------------
+int mlmcpi_test_philox(const uint32_t *ctr4, const uint32_t *key2, uint32_t *out4) {
+  MLMCPI_REQUIRE(ctr4 && key2 && out4, "NULL argument");
+  uint32_t *d = nullptr;
+  MLMCPI_HIP_TRY(hipMalloc(&d, 16));
+  hipLaunchKernelGGL(test_philox_kernel, dim3(1), dim3(1), 0, 0, U4{ctr4[0], ctr4[1], ctr4[2], ctr4[3]}, key2[0],
+                     key2[1], d);
+  MLMCPI_LAUNCH_CHECK("test_philox_kernel");
+  MLMCPI_HIP_TRY(hipMemcpy(out4, d, 16, hipMemcpyDeviceToHost));
+  MLMCPI_HIP_TRY(hipFree(d));
+  return MLMCPI_OK;
+}
+
+int mlmcpi_test_random(uint64_t seed, uint32_t chain, uint32_t step, uint32_t purpose, uint32_t sub, uint32_t n,
+                       double *d_out, void *stream) {
+  MLMCPI_REQUIRE(d_out && n > 0, "bad arguments");
+  hipLaunchKernelGGL(test_random_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream),
+                     make_key(seed, chain, step), purpose, sub, n, d_out);
+  MLMCPI_LAUNCH_CHECK("test_random_kernel");
+  return MLMCPI_OK;
+}
+
+int mlmcpi_test_expcos(uint64_t seed, uint32_t chain, uint32_t step, double beta, const double *d_xp,
+                       const double *d_xm, uint32_t n, double *d_out, void *stream) {
+  MLMCPI_REQUIRE(d_xp && d_xm && d_out && n > 0, "bad arguments");
+  hipLaunchKernelGGL(test_expcos_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream),
+                     make_key(seed, chain, step), beta, d_xp, d_xm, n, d_out);
+  MLMCPI_LAUNCH_CHECK("test_expcos_kernel");
+  return MLMCPI_OK;
+}
+
+int mlmcpi_test_expsin2(uint64_t seed, uint32_t chain, uint32_t step, const double *d_sigma, uint32_t n,
+                        double *d_out, void *stream) {
+  MLMCPI_REQUIRE(d_sigma && d_out && n > 0, "bad arguments");
+  hipLaunchKernelGGL(test_expsin2_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream),
+                     make_key(seed, chain, step), d_sigma, n, d_out);
+  MLMCPI_LAUNCH_CHECK("test_expsin2_kernel");
+  return MLMCPI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,186 @@
+"""Thin torch-tensor front end of the C ABI, used by tests and bench.py.
+
+PyTorch is plumbing only: it owns device memory and the stream; every computation goes through
+libmlmcpi_hip.so.  All state tensors are float64 CUDA tensors of shape [B, n] in the reference's
+SampleState layout (see include/mlmcpi_hip.h).
+"""
+import ctypes as C
+
+import torch
+
+from . import abi
+from .abi import GFF, HARMONIC, QUARTIC, ROTOR, SCHWINGER  # noqa: F401
+
+
+def _p(t):
+    if t is None:
+        return C.c_void_p(0)
+    assert t.is_cuda and t.is_contiguous(), "device, contiguous tensors only"
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f64(B, n, like):
+    return torch.empty((B, n), dtype=torch.float64, device=like.device)
+
+
+def _check_state(x, n):
+    assert x.dtype == torch.float64 and x.dim() == 2 and x.shape[1] == n, (x.shape, n)
+
+
+# ---- 1-D paths -----------------------------------------------------------------------------------
+def path_evaluate(act, x):
+    _check_state(x, act.M)
+    out = torch.empty(x.shape[0], dtype=torch.float64, device=x.device)
+    abi.call("mlmcpi_path_evaluate", C.byref(act), _p(x), x.shape[0], _p(out), _stream())
+    return out
+
+
+def path_force(act, x):
+    _check_state(x, act.M)
+    f = torch.empty_like(x)
+    abi.call("mlmcpi_path_force", C.byref(act), _p(x), _p(f), x.shape[0], _stream())
+    return f
+
+
+def path_initialise(act, B, seed, chain0=0, device="cuda"):
+    x = torch.empty((B, act.M), dtype=torch.float64, device=device)
+    abi.call("mlmcpi_path_initialise", C.byref(act), _p(x), B, seed, chain0, _stream())
+    return x
+
+
+def qoi_xsquared(x):
+    out = torch.empty(x.shape[0], dtype=torch.float64, device=x.device)
+    abi.call("mlmcpi_qoi_xsquared", _p(x), x.shape[1], x.shape[0], _p(out), _stream())
+    return out
+
+
+def qoi_susceptibility(x, T_final):
+    out = torch.empty(x.shape[0], dtype=torch.float64, device=x.device)
+    abi.call("mlmcpi_qoi_susceptibility", _p(x), x.shape[1], float(T_final), x.shape[0], _p(out), _stream())
+    return out
+
+
+class PathHMC:
+    """HMCSampler::draw on B device-resident chains (sampler/hmcsampler.cc:8-69)."""
+
+    def __init__(self, act, B, nt, dt, n_rep=1, seed=1, chain0=0, device="cuda"):
+        self.act, self.B, self.nt, self.dt, self.n_rep, self.seed, self.chain0 = act, B, nt, dt, n_rep, seed, chain0
+        nbytes = C.c_size_t(0)
+        abi.call("mlmcpi_path_hmc_workspace_bytes", C.byref(act), B, nt, C.byref(nbytes))
+        self.work = torch.empty(nbytes.value, dtype=torch.uint8, device=device)
+        self.accept = torch.zeros(B, dtype=torch.int32, device=device)
+        self.energies = torch.zeros((B, 4), dtype=torch.float64, device=device)
+        self.traj = 0
+        self.n_total = 0
+        self.n_accepted = torch.zeros(B, dtype=torch.int64, device=device)
+
+    def draw(self, x, count_stats=True):
+        _check_state(x, self.act.M)
+        abi.call("mlmcpi_path_hmc_draw", C.byref(self.act), _p(x), self.B, self.nt, float(self.dt), self.n_rep,
+                 self.seed, self.chain0, self.traj, _p(self.work), _p(self.accept), _p(self.energies), _stream())
+        self.traj += self.n_rep
+        if count_stats:
+            self.n_total += 1
+            self.n_accepted += self.accept
+        return self.accept
+
+
+def path_sweep_draw(act, x, scratch, n_overrelax, n_heatbath, seed, chain0, sweep0):
+    _check_state(x, act.M)
+    abi.call("mlmcpi_path_sweep_draw", C.byref(act), _p(x), _p(scratch), x.shape[0], n_overrelax, n_heatbath, seed,
+             chain0, sweep0, _stream())
+
+
+# ---- 2-D lattices ---------------------------------------------------------------------------------
+def lattice_size(act):
+    n = C.c_uint32(0)
+    abi.call("mlmcpi_lattice_state_size", C.byref(act), C.byref(n))
+    return n.value
+
+
+def lattice_evaluate(act, phi):
+    out = torch.empty(phi.shape[0], dtype=torch.float64, device=phi.device)
+    abi.call("mlmcpi_lattice_evaluate", C.byref(act), _p(phi), phi.shape[0], _p(out), _stream())
+    return out
+
+
+def lattice_force(act, phi):
+    f = torch.empty_like(phi)
+    abi.call("mlmcpi_lattice_force", C.byref(act), _p(phi), _p(f), phi.shape[0], _stream())
+    return f
+
+
+def lattice_initialise(act, B, seed, chain0=0, device="cuda"):
+    phi = torch.empty((B, lattice_size(act)), dtype=torch.float64, device=device)
+    abi.call("mlmcpi_lattice_initialise", C.byref(act), _p(phi), B, seed, chain0, _stream())
+    return phi
+
+
+def lattice_sweep_draw(act, phi, scratch, n_overrelax, n_heatbath, seed, chain0, sweep0, fuse=0):
+    _check_state(phi, lattice_size(act))
+    abi.call("mlmcpi_lattice_sweep_draw", C.byref(act), _p(phi), _p(scratch), phi.shape[0], n_overrelax, n_heatbath,
+             seed, chain0, sweep0, fuse, _stream())
+
+
+def qoi_phi_squared(phi):
+    out = torch.empty(phi.shape[0], dtype=torch.float64, device=phi.device)
+    abi.call("mlmcpi_qoi_phi_squared", _p(phi), phi.shape[1], phi.shape[0], _p(out), _stream())
+    return out
+
+
+def qoi_avg_plaquette(theta, Mt, Mx):
+    out = torch.empty(theta.shape[0], dtype=torch.float64, device=theta.device)
+    abi.call("mlmcpi_qoi_avg_plaquette", _p(theta), Mt, Mx, theta.shape[0], _p(out), _stream())
+    return out
+
+
+def qoi_2d_susceptibility(theta, Mt, Mx):
+    out = torch.empty(theta.shape[0], dtype=torch.float64, device=theta.device)
+    abi.call("mlmcpi_qoi_2d_susceptibility", _p(theta), Mt, Mx, theta.shape[0], _p(out), _stream())
+    return out
+
+
+class LatticeHMC:
+    """HMCSampler::draw for a 2-D action (streaming leapfrog)."""
+
+    def __init__(self, act, B, nt, dt, n_rep=1, seed=1, chain0=0, device="cuda"):
+        self.act, self.B, self.nt, self.dt, self.n_rep, self.seed, self.chain0 = act, B, nt, dt, n_rep, seed, chain0
+        nbytes = C.c_size_t(0)
+        abi.call("mlmcpi_lattice_hmc_workspace_bytes", C.byref(act), B, C.byref(nbytes))
+        self.work = torch.empty(nbytes.value, dtype=torch.uint8, device=device)
+        self.accept = torch.zeros(B, dtype=torch.int32, device=device)
+        self.energies = torch.zeros((B, 4), dtype=torch.float64, device=device)
+        self.traj = 0
+
+    def draw(self, phi):
+        abi.call("mlmcpi_lattice_hmc_draw", C.byref(self.act), _p(phi), self.B, self.nt, float(self.dt), self.n_rep,
+                 self.seed, self.chain0, self.traj, _p(self.work), _p(self.accept), _p(self.energies), _stream())
+        self.traj += self.n_rep
+        return self.accept
+
+
+def stats_accumulate(acc, q):
+    abi.call("mlmcpi_stats_accumulate", _p(acc), _p(q), q.shape[0], _stream())
+
+
+# ---- test hooks -------------------------------------------------------------------------------------
+def test_random(seed, chain, step, purpose, sub, n, device="cuda"):
+    out = torch.empty((n, 4), dtype=torch.float64, device=device)
+    abi.call("mlmcpi_test_random", seed, chain, step, purpose, sub, n, _p(out), _stream())
+    return out
+
+
+def test_expcos(seed, chain, step, beta, xp, xm):
+    out = torch.empty_like(xp)
+    abi.call("mlmcpi_test_expcos", seed, chain, step, float(beta), _p(xp), _p(xm), xp.numel(), _p(out), _stream())
+    return out
+
+
+def test_expsin2(seed, chain, step, sigma):
+    out = torch.empty_like(sigma)
+    abi.call("mlmcpi_test_expsin2", seed, chain, step, _p(sigma), sigma.numel(), _p(out), _stream())
+    return out

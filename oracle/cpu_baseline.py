@@ -1,0 +1,75 @@
+"""CPU baseline leg of bench.py: the oracle's reference-order samplers timed on the host cores.
+
+TEST/BENCH INFRASTRUCTURE ONLY.  One independent chain per process (the reference's own parallel
+model: one chain per MPI rank), steady-state draws only (constructor work -- state initialisation,
+burn-in, HMC auto-tuning -- is excluded).  Prints one JSON object.
+"""
+import argparse
+import json
+import multiprocessing as mp
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def _worker(args):
+    import numpy as np
+    import oracle as O
+    workload, size, draws, n_or, n_hb, nt, dt = args
+    L = O.lib()
+    if workload == "schwinger":
+        A = O.Action(O.SCHWINGER, Mt=size, Mx=size, beta=1.0)
+        units = 2 * size * size * (n_or + n_hb)
+        s = L.orc_heatbath_new(A.h, n_hb, n_or, 0, 0)
+        draw = lambda x: L.orc_heatbath_draw(s, x)
+    elif workload == "gff":
+        A = O.Action(O.GFF, Mt=size, Mx=size, mass=10.0)
+        units = size * size * (n_or + n_hb)
+        s = L.orc_heatbath_new(A.h, n_hb, n_or, 0, 0)
+        draw = lambda x: L.orc_heatbath_draw(s, x)
+    else:  # rotor HMC, fixed dt (no auto-tune)
+        A = O.Action(O.ROTOR, M=size, T_final=size / 8.0, m0=0.25)
+        units = size * (nt + 1)
+        s = L.orc_hmc_new(A.h, nt, dt, 1, 0, 0, 0, 0)
+        draw = lambda x: L.orc_hmc_draw(s, x)
+    x = np.zeros(A.size)
+    draw(x)  # warm-up (page in, first touch)
+    t0 = time.perf_counter()
+    for _ in range(draws):
+        draw(x)
+    el = time.perf_counter() - t0
+    return units * draws, el
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="schwinger")
+    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--draws", type=int, default=4)
+    ap.add_argument("--cores", type=int, default=0)
+    ap.add_argument("--n-overrelax", type=int, default=10)
+    ap.add_argument("--n-heatbath", type=int, default=1)
+    ap.add_argument("--nt", type=int, default=100)
+    ap.add_argument("--dt", type=float, default=0.1)
+    a = ap.parse_args()
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = a.cores or min(avail, 16)
+    import oracle as O
+    O.build()  # compile once, before forking
+    job = (a.workload, a.size, a.draws, a.n_overrelax, a.n_heatbath, a.nt, a.dt)
+    t0 = time.perf_counter()
+    with mp.get_context("fork").Pool(cores) as pool:
+        res = pool.map(_worker, [job] * cores)
+    wall = time.perf_counter() - t0
+    rate = sum(u / el for u, el in res)  # all processes run concurrently: aggregate rate
+    print(json.dumps({"value": rate, "per_core": rate / cores, "cores": cores, "wall_s": wall,
+                      "sample": f"{a.draws} draws per core of {a.workload} {a.size}, one chain per core"}))
+
+
+if __name__ == "__main__":
+    main()

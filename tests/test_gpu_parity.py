@@ -1,0 +1,437 @@
+"""GPU: the HIP path (through the C ABI) against the CPU oracle on identical seeded inputs.
+
+Tolerances (north_star: bit-exact for integer/index work, stated fp tolerance otherwise):
+  * Philox words and uniforms: bit-exact;
+  * deterministic fp64 functions (evaluate, force, QoI, single updates, whole sweeps and HMC
+    trajectories with the same counter-based random numbers): |diff| <= 1e-12 * scale, the slack
+    covering libm-vs-ocml transcendentals, FMA contraction and summation order;
+  * expectation values: within 4 combined standard errors of the reference chain / closed form
+    (tests/test_gpu_statistics.py).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SEED = 0x1234567812345678
+TOL = 1e-12
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64).cuda()
+
+
+def seq(n):
+    return np.sin(np.arange(n) + 1.0)
+
+
+def assert_close(got, want, tol=TOL, scale=None, what=""):
+    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    s = scale if scale is not None else max(1.0, float(np.max(np.abs(want))) if want.size else 1.0)
+    err = float(np.max(np.abs(got - want))) if want.size else 0.0
+    assert err <= tol * s, f"{what}: max |diff| = {err:.3e} > {tol:.1e} * {s:.3e}"
+
+
+def assert_angles_close(got, want, tol=TOL, what=""):
+    """angles in [-pi, pi): compare modulo 2 pi (a value within rounding of -pi may wrap)"""
+    d = np.asarray(got) - np.asarray(want)
+    d = d - 2 * np.pi * np.round(d / (2 * np.pi))
+    err = float(np.max(np.abs(d)))
+    assert err <= tol * 4, f"{what}: max angular diff = {err:.3e}"
+
+
+# ---- RNG ---------------------------------------------------------------------------------------------
+def test_philox_known_answers_on_device(gpu_ops):
+    import ctypes as C
+    from mlmcpathintegral_amd import abi
+    kat = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "philox_kat.json")))
+    for v in kat["vectors"]:
+        ctr = np.array([int(x, 16) for x in v["ctr"]], dtype=np.uint32)
+        key = np.array([int(x, 16) for x in v["key"]], dtype=np.uint32)
+        out = np.zeros(4, dtype=np.uint32)
+        abi.call("mlmcpi_test_philox", ctr.ctypes.data_as(C.c_void_p), key.ctypes.data_as(C.c_void_p),
+                 out.ctypes.data_as(C.c_void_p))
+        assert [f"{x:08x}" for x in out] == v["out"]
+
+
+@pytest.mark.parametrize("purpose,sub", [(1, 0), (3, 0), (4, 7), (5, 123456)])
+def test_random_streams_match_oracle(gpu_ops, orc, purpose, sub):
+    n, chain, step = 1000, 17, 9001
+    got = gpu_ops.test_random(SEED, chain, step, purpose, sub, n).cpu().numpy()
+    want = np.zeros((n, 4))
+    for k in range(n):
+        orc.lib().orc_dev_random(SEED, chain, step, k, purpose, sub, want[k])
+    assert (got[:, :2] == want[:, :2]).all(), "uniforms must be bit-exact"
+    assert ((got[:, :2] >= 0) & (got[:, :2] < 1)).all()
+    assert_close(got[:, 2:], want[:, 2:], tol=1e-13, what="Box-Muller normals")
+
+
+def test_expcos_draws_match_oracle(gpu_ops, orc):
+    rng = np.random.default_rng(1)
+    n = 4096
+    xp, xm = rng.uniform(-np.pi, np.pi, n), rng.uniform(-np.pi, np.pi, n)
+    for beta in (0.3, 1.0, 4.0):
+        got = gpu_ops.test_expcos(SEED, 3, 5, beta, dev(xp), dev(xm)).cpu().numpy()
+        want = np.array([orc.lib().orc_dev_expcos_draw(SEED, 3, 5, k, beta, xp[k], xm[k]) for k in range(n)])
+        assert_angles_close(got, want, what=f"ExpCos beta={beta}")
+        assert ((got >= -np.pi) & (got < np.pi + 1e-15)).all()
+
+
+def test_expsin2_draws_match_oracle(gpu_ops, orc):
+    rng = np.random.default_rng(2)
+    n = 4096
+    sigma = rng.uniform(0.05, 40.0, n)
+    got = gpu_ops.test_expsin2(SEED, 1, 2, dev(sigma)).cpu().numpy()
+    want = np.array([orc.lib().orc_dev_expsin2_draw(SEED, 1, 2, k, sigma[k]) for k in range(n)])
+    assert_close(got, want, what="ExpSin2")
+    assert (np.abs(got) < np.pi).all()
+
+
+# ---- 1-D actions ---------------------------------------------------------------------------------------
+PATH_CASES = [
+    ("harmonic", dict(M=128, T_final=4.0, m0=1.0, mu2=1.0)),
+    ("quartic", dict(M=16, T_final=4.0, m0=1.0, mu2=1.0, lam=1.0, x0=1.0)),
+    ("quartic", dict(M=1000, T_final=125.0, m0=1.0, mu2=1.0, lam=1.0, x0=1.0)),
+    ("rotor", dict(M=16, T_final=4.0, m0=0.25)),
+    ("rotor", dict(M=4096, T_final=512.0, m0=0.25)),
+    ("rotor", dict(M=65536, T_final=8192.0, m0=0.25)),
+]
+KINDS = {"harmonic": 0, "quartic": 1, "rotor": 2}
+
+
+def make_path(orc, name, p):
+    from mlmcpathintegral_amd import abi
+    k = KINDS[name]
+    act = abi.path_action(k, p["M"], p["T_final"], p.get("m0", 1.0), p.get("mu2", 1.0), p.get("lam", 0.0), p.get("x0", 0.0))
+    return act, orc.Action(k, **p)
+
+
+@pytest.mark.parametrize("name,p", PATH_CASES)
+def test_path_evaluate_force_qoi(gpu_ops, orc, name, p):
+    act, A = make_path(orc, name, p)
+    M, B = p["M"], 3
+    rng = np.random.default_rng(M)
+    x = np.vstack([seq(M)] + [rng.uniform(-3, 3, M) for _ in range(B - 1)])
+    xd = dev(x)
+    S = gpu_ops.path_evaluate(act, xd).cpu().numpy()
+    F = gpu_ops.path_force(act, xd).cpu().numpy()
+    X2 = gpu_ops.qoi_xsquared(xd).cpu().numpy()
+    chi = gpu_ops.qoi_susceptibility(xd, p["T_final"]).cpu().numpy()
+    L = orc.lib()
+    for b in range(B):
+        assert_close(S[b], A.evaluate(x[b]), what="evaluate")
+        assert_close(F[b], A.force(x[b]), what="force")
+        assert_close(X2[b], L.orc_qoi_xsquared(x[b], M), what="QoIXsquared")
+        assert_close(chi[b], L.orc_qoi_susceptibility(x[b], M, p["T_final"]), tol=1e-10, what="QoISusceptibility")
+
+
+def test_path_golden_vectors(gpu_ops, golden):
+    """The survey's known answers straight through the ABI (no oracle in between)."""
+    from mlmcpathintegral_amd import abi
+    g = golden["rotor_M16"]
+    act = abi.path_action(2, 16, 4.0, 0.25)
+    x = dev(seq(16)[None, :])
+    assert_close(gpu_ops.path_evaluate(act, x).item(), g["S"])
+    assert_close(gpu_ops.path_force(act, x).cpu().numpy()[0, :4], g["force_0_3"])
+    g = golden["quartic_M16"]
+    act = abi.path_action(1, 16, 4.0, 1.0, 1.0, 1.0, 1.0)
+    assert_close(gpu_ops.path_evaluate(act, x).item(), g["S"])
+    assert_close(gpu_ops.path_force(act, x).cpu().numpy()[0, :4], g["force_0_3"])
+    assert_close(gpu_ops.qoi_xsquared(x).item(), g["X2"])
+
+
+def test_path_initialise(gpu_ops, orc):
+    act, A = make_path(orc, "rotor", dict(M=1024, T_final=128.0, m0=0.25))
+    x = gpu_ops.path_initialise(act, 3, SEED, chain0=5).cpu().numpy()
+    for b in range(3):
+        assert (x[b] == A.dev_initialise(SEED, 5 + b)).all() or np.max(np.abs(x[b] - A.dev_initialise(SEED, 5 + b))) < 1e-15
+    act, A = make_path(orc, "quartic", dict(M=64, T_final=8.0, lam=1.0, x0=1.0))
+    assert (gpu_ops.path_initialise(act, 2, SEED).cpu().numpy() == 0).all()
+
+
+HMC_CASES = [
+    # name, params, nt, dt, B   -- covers the periodic register-resident geometry (M = NT*R), every R,
+    # and the segmented geometry with halo nt+1 (M not a multiple of 64, and M > 8192)
+    ("harmonic", dict(M=128, T_final=4.0, m0=1.0, mu2=1.0), 100, 0.0558, 4),
+    ("quartic", dict(M=1024, T_final=128.0, m0=1.0, mu2=1.0, lam=1.0, x0=1.0), 10, 0.09, 3),
+    ("quartic", dict(M=8192, T_final=1024.0, m0=1.0, mu2=1.0, lam=1.0, x0=1.0), 7, 0.05, 2),
+    ("quartic", dict(M=1000, T_final=125.0, m0=1.0, mu2=1.0, lam=1.0, x0=1.0), 12, 0.08, 2),
+    ("quartic", dict(M=32768, T_final=4096.0, m0=1.0, mu2=1.0, lam=1.0, x0=1.0), 20, 0.05, 2),
+    ("rotor", dict(M=64, T_final=8.0, m0=0.25), 10, 0.1, 5),
+    ("rotor", dict(M=4096, T_final=512.0, m0=0.25), 10, 0.1, 2),
+    ("rotor", dict(M=65536, T_final=8192.0, m0=0.25), 25, 0.1, 2),
+    ("rotor", dict(M=330, T_final=40.0, m0=0.25), 5, 0.1, 2),
+]
+
+
+@pytest.mark.parametrize("name,p,nt,dt,B", HMC_CASES)
+def test_hmc_trajectories_match_oracle(gpu_ops, orc, name, p, nt, dt, B):
+    """Three consecutive HMCSampler::draw calls per chain; same Philox momenta / accept uniforms."""
+    act, A = make_path(orc, name, p)
+    M = p["M"]
+    rng = np.random.default_rng(M + nt)
+    x0 = rng.uniform(-1.0, 1.0, (B, M)) if name != "rotor" else rng.uniform(-np.pi, np.pi, (B, M))
+    xd = dev(x0)
+    hmc = gpu_ops.PathHMC(act, B, nt, dt, n_rep=1, seed=SEED, chain0=40)
+    xo = x0.copy()
+    for t in range(3):
+        acc = hmc.draw(xd).cpu().numpy()
+        en = hmc.energies.cpu().numpy()
+        for b in range(B):
+            a, e, dH = A.dev_hmc_trajectory(xo[b], nt, dt, SEED, 40 + b, t)
+            assert_close(en[b], e, tol=1e-11, what=f"energies t={t} b={b}")
+            assert acc[b] == a, f"accept flag t={t} b={b} (dH={dH})"
+        assert_close(xd.cpu().numpy(), xo, tol=1e-10, what=f"state after draw {t}")
+    assert hmc.n_total == 3
+
+
+@pytest.mark.parametrize("M,R_expected", [(128, 2), (256, 4), (512, 8), (1024, 16)])
+def test_hmc_register_geometries(gpu_ops, orc, M, R_expected):
+    """Large batches select R = M/64 sites per thread (one wave per chain): exercise every
+    register-resident variant and spot-check chains of the batch against the oracle."""
+    act, A = make_path(orc, "quartic", dict(M=M, T_final=M / 8.0, m0=1.0, mu2=1.0, lam=1.0, x0=1.0))
+    B, nt, dt = 2100, 6, 0.1
+    g = torch.Generator().manual_seed(M)
+    x0 = (torch.rand((B, M), generator=g, dtype=torch.float64) * 2 - 1)
+    xd = x0.cuda()
+    hmc = gpu_ops.PathHMC(act, B, nt, dt, seed=SEED, chain0=0)
+    acc = hmc.draw(xd).cpu().numpy()
+    got = xd.cpu().numpy()
+    for b in (0, 1, 63, 1050, 2099):
+        xo = x0[b].numpy().copy()
+        a, e, _ = A.dev_hmc_trajectory(xo, nt, dt, SEED, b, 0)
+        assert acc[b] == a
+        assert_close(got[b], xo, tol=1e-10, what=f"chain {b}")
+        assert_close(hmc.energies[b].cpu().numpy(), e, tol=1e-11)
+
+
+def test_hmc_n_rep_short_circuit(gpu_ops, orc):
+    """hmcsampler.cc:10-12: `accept = accept or single_step()` stops integrating after the first
+    accepted repetition; repetition r uses Philox step traj0 + r."""
+    act, A = make_path(orc, "quartic", dict(M=256, T_final=32.0, m0=1.0, mu2=1.0, lam=1.0, x0=1.0))
+    B, nt, dt, n_rep = 6, 10, 0.35, 3  # large dt: a mix of accepts and rejects
+    rng = np.random.default_rng(0)
+    x0 = rng.uniform(-1, 1, (B, 256))
+    xd = dev(x0)
+    hmc = gpu_ops.PathHMC(act, B, nt, dt, n_rep=n_rep, seed=SEED, chain0=0)
+    xo = x0.copy()
+    seen = set()
+    for d in range(4):
+        acc = hmc.draw(xd).cpu().numpy()
+        for b in range(B):
+            a = 0
+            for r in range(n_rep):
+                if a:
+                    break
+                a, _, _ = A.dev_hmc_trajectory(xo[b], nt, dt, SEED, b, d * n_rep + r)
+            assert acc[b] == a
+            seen.add(int(a))
+        assert_close(xd.cpu().numpy(), xo, tol=1e-10)
+    assert seen == {0, 1}, "test should exercise both outcomes"
+
+
+@pytest.mark.parametrize("M,B", [(16, 2), (128, 3), (4096, 2), (10000, 2)])
+def test_rotor_sweeps_match_oracle(gpu_ops, orc, M, B):
+    act, A = make_path(orc, "rotor", dict(M=M, T_final=M / 8.0, m0=0.25))
+    rng = np.random.default_rng(M)
+    x0 = rng.uniform(-np.pi, np.pi, (B, M))
+    xd, scratch = dev(x0), torch.empty((B, M), dtype=torch.float64, device="cuda")
+    xo = x0.copy()
+    sweep = 0
+    for n_or, n_hb in ((1, 0), (0, 1), (3, 2), (5, 1)):
+        gpu_ops.path_sweep_draw(act, xd, scratch, n_or, n_hb, SEED, 7, sweep)
+        for b in range(B):
+            for s in range(n_or + n_hb):
+                A.dev_sweep(xo[b], s >= n_or, SEED, 7 + b, sweep + s)
+        sweep += n_or + n_hb
+        assert_angles_close(xd.cpu().numpy(), xo, what=f"rotor sweeps ({n_or},{n_hb})")
+
+
+def test_path_sweep_unsupported_action(gpu_ops):
+    """action/action.hh:73-96: heat bath / overrelaxation are errors for HO and quartic."""
+    from mlmcpathintegral_amd import abi
+    act = abi.path_action(1, 64, 8.0, 1.0, 1.0, 1.0, 1.0)
+    x = torch.zeros((1, 64), dtype=torch.float64, device="cuda")
+    with pytest.raises(abi.MlmcpiError, match="not implemented"):
+        gpu_ops.path_sweep_draw(act, x, torch.empty_like(x), 1, 1, 1, 0, 0)
+
+
+# ---- 2-D actions -------------------------------------------------------------------------------------------
+def make_lattice(orc, kind, Mt, Mx, **kw):
+    from mlmcpathintegral_amd import abi
+    if kind == "gff":
+        return abi.lattice_action(3, Mt, Mx, mass=kw["mass"]), orc.Action(orc.GFF, Mt=Mt, Mx=Mx, mass=kw["mass"])
+    return abi.lattice_action(4, Mt, Mx, beta=kw["beta"]), orc.Action(orc.SCHWINGER, Mt=Mt, Mx=Mx, beta=kw["beta"])
+
+
+@pytest.mark.parametrize("kind,Mt,Mx,kw", [("gff", 4, 4, dict(mass=10.0)), ("gff", 64, 64, dict(mass=10.0)),
+                                           ("gff", 30, 30, dict(mass=2.0)), ("schwinger", 4, 4, dict(beta=1.0)),
+                                           ("schwinger", 16, 6, dict(beta=2.5)), ("schwinger", 130, 70, dict(beta=1.0))])
+def test_lattice_evaluate_force_qoi(gpu_ops, orc, kind, Mt, Mx, kw):
+    act, A = make_lattice(orc, kind, Mt, Mx, **kw)
+    n, B = A.size, 2
+    rng = np.random.default_rng(n)
+    x = np.vstack([seq(n), rng.uniform(-3, 3, n)])
+    xd = dev(x)
+    S = gpu_ops.lattice_evaluate(act, xd).cpu().numpy()
+    F = gpu_ops.lattice_force(act, xd).cpu().numpy()
+    L = orc.lib()
+    for b in range(B):
+        assert_close(S[b], A.evaluate(x[b]), what="evaluate")
+        assert_close(F[b], A.force(x[b]), what="force")
+    if kind == "gff":
+        q = gpu_ops.qoi_phi_squared(xd).cpu().numpy()
+        for b in range(B):
+            assert_close(q[b], L.orc_qoi_2d_phi_squared(x[b], n))
+    else:
+        plaq = gpu_ops.qoi_avg_plaquette(xd, Mt, Mx).cpu().numpy()
+        chi = gpu_ops.qoi_2d_susceptibility(xd, Mt, Mx).cpu().numpy()
+        for b in range(B):
+            assert_close(plaq[b], L.orc_qoi_avg_plaquette(x[b], Mt, Mx))
+            assert_close(chi[b], L.orc_qoi_2d_susceptibility(x[b], Mt, Mx), tol=1e-10)
+
+
+def test_lattice_golden_vectors(gpu_ops, golden):
+    from mlmcpathintegral_amd import abi
+    g = golden["schwinger_4x4"]
+    act = abi.lattice_action(4, 4, 4, beta=1.0)
+    x = dev(seq(32)[None, :])
+    assert_close(gpu_ops.lattice_evaluate(act, x).item(), g["S"])
+    assert_close(gpu_ops.qoi_avg_plaquette(x, 4, 4).item(), g["plaq"])
+    assert_close(gpu_ops.lattice_force(act, x).cpu().numpy()[0, :4], g["force_0_3"])
+    g = golden["gff_4x4"]
+    act = abi.lattice_action(3, 4, 4, mass=10.0)
+    x = dev(seq(16)[None, :])
+    assert_close(gpu_ops.lattice_evaluate(act, x).item(), g["S"])
+    assert_close(gpu_ops.qoi_phi_squared(x).item(), g["phi2"])
+    assert_close(gpu_ops.lattice_force(act, x).cpu().numpy()[0, :4], g["force_0_3"])
+
+
+def test_lattice_initialise(gpu_ops, orc):
+    for kind, kw in (("schwinger", dict(beta=1.0)), ("gff", dict(mass=10.0))):
+        act, A = make_lattice(orc, kind, 16, 16, **kw)
+        x = gpu_ops.lattice_initialise(act, 2, SEED, chain0=3).cpu().numpy()
+        for b in range(2):
+            assert_close(x[b], A.dev_initialise(SEED, 3 + b), tol=1e-13)
+
+
+SWEEP_CASES = [
+    # kind, Mt, Mx, params, B  -- tiny lattices (buffer wraps around the torus several times), one tile,
+    # several tiles with ragged edges, rectangular Schwinger lattices
+    ("gff", 4, 4, dict(mass=10.0), 2),
+    ("gff", 16, 16, dict(mass=10.0), 3),
+    ("gff", 64, 64, dict(mass=10.0), 2),
+    ("gff", 130, 130, dict(mass=10.0), 1),
+    ("schwinger", 4, 4, dict(beta=1.0), 2),
+    ("schwinger", 16, 16, dict(beta=1.0), 3),
+    ("schwinger", 6, 10, dict(beta=4.0), 2),
+    ("schwinger", 64, 32, dict(beta=1.0), 2),
+    ("schwinger", 130, 70, dict(beta=1.0), 1),
+]
+
+
+@pytest.mark.parametrize("fuse", [1, 3])
+@pytest.mark.parametrize("kind,Mt,Mx,kw,B", SWEEP_CASES)
+def test_lattice_sweeps_match_oracle(gpu_ops, orc, kind, Mt, Mx, kw, B, fuse):
+    act, A = make_lattice(orc, kind, Mt, Mx, **kw)
+    n = A.size
+    rng = np.random.default_rng(n)
+    x0 = rng.uniform(-np.pi, np.pi, (B, n))
+    xd, scratch = dev(x0), torch.empty((B, n), dtype=torch.float64, device="cuda")
+    xo = x0.copy()
+    sweep = 100
+    for n_or, n_hb in ((1, 0), (0, 1), (2, 1), (4, 2)):
+        gpu_ops.lattice_sweep_draw(act, xd, scratch, n_or, n_hb, SEED, 11, sweep, fuse=fuse)
+        for b in range(B):
+            for s in range(n_or + n_hb):
+                A.dev_sweep(xo[b], s >= n_or, SEED, 11 + b, sweep + s)
+        sweep += n_or + n_hb
+        got = xd.cpu().numpy()
+        if kind == "schwinger":
+            assert_angles_close(got, xo, what=f"sweeps ({n_or},{n_hb}) fuse={fuse}")
+        else:
+            assert_close(got, xo, tol=1e-11, what=f"sweeps ({n_or},{n_hb}) fuse={fuse}")
+
+
+def test_sweep_rejects_odd_lattice(gpu_ops):
+    from mlmcpathintegral_amd import abi
+    act = abi.lattice_action(4, 5, 4, beta=1.0)
+    x = torch.zeros((1, 40), dtype=torch.float64, device="cuda")
+    with pytest.raises(abi.MlmcpiError, match="even"):
+        gpu_ops.lattice_sweep_draw(act, x, torch.empty_like(x), 1, 0, 1, 0, 0)
+    with pytest.raises(abi.MlmcpiError, match="squared"):
+        gpu_ops.lattice_evaluate(abi.lattice_action(3, 8, 4, mass=1.0), x)
+
+
+@pytest.mark.parametrize("kind,Mt,Mx,kw", [("gff", 16, 16, dict(mass=10.0)), ("schwinger", 16, 8, dict(beta=1.0))])
+def test_lattice_hmc_matches_oracle(gpu_ops, orc, kind, Mt, Mx, kw):
+    act, A = make_lattice(orc, kind, Mt, Mx, **kw)
+    n, B, nt, dt = A.size, 3, 8, 0.05
+    rng = np.random.default_rng(3)
+    x0 = rng.uniform(-1, 1, (B, n))
+    xd = dev(x0)
+    hmc = gpu_ops.LatticeHMC(act, B, nt, dt, seed=SEED, chain0=2)
+    xo = x0.copy()
+    for t in range(3):
+        acc = hmc.draw(xd).cpu().numpy()
+        en = hmc.energies.cpu().numpy()
+        for b in range(B):
+            a, e, _ = A.dev_hmc_trajectory(xo[b], nt, dt, SEED, 2 + b, t)
+            assert_close(en[b], e, tol=1e-11)
+            assert acc[b] == a
+        assert_close(xd.cpu().numpy(), xo, tol=1e-10)
+
+
+# ---- full-size properties (BASELINE sizes; the oracle would take too long) -----------------------------
+def test_schwinger_1024_properties(gpu_ops, orc, golden):
+    """1024 x 1024, beta = 1: (i) overrelaxation sweeps conserve the action; (ii) the result is
+    independent of how many sweeps are fused per launch (halo logic at scale, bit-exact); (iii) chain b
+    of a batch equals the same chain run alone; (iv) QoIs of the uniform start agree with the oracle."""
+    from mlmcpathintegral_amd import abi
+    act = abi.lattice_action(4, 1024, 1024, beta=1.0)
+    B = 2
+    x = gpu_ops.lattice_initialise(act, B, SEED, chain0=0)
+    A = orc.Action(orc.SCHWINGER, Mt=1024, Mx=1024, beta=1.0)
+    x0 = x[0].cpu().numpy()
+    assert_close(gpu_ops.lattice_evaluate(act, x)[0].item(), A.evaluate(x0), tol=1e-12)
+    assert_close(gpu_ops.qoi_2d_susceptibility(x, 1024, 1024)[0].item(),
+                 orc.lib().orc_qoi_2d_susceptibility(x0, 1024, 1024), tol=1e-9)
+    S0 = gpu_ops.lattice_evaluate(act, x).cpu().numpy()
+    a, b1 = x.clone(), x.clone()
+    scratch = torch.empty_like(x)
+    gpu_ops.lattice_sweep_draw(act, a, scratch, 4, 2, SEED, 0, 0, fuse=1)
+    gpu_ops.lattice_sweep_draw(act, b1, scratch, 4, 2, SEED, 0, 0, fuse=3)
+    assert torch.equal(a, b1), "fused and unfused sweeps must agree bit for bit"
+    single = x[1:2].clone()
+    gpu_ops.lattice_sweep_draw(act, single, torch.empty_like(single), 4, 2, SEED, 1, 0, fuse=2)
+    assert torch.equal(single[0], a[1]), "a chain's result must not depend on the batch it runs in"
+    c = x.clone()
+    gpu_ops.lattice_sweep_draw(act, c, scratch, 5, 0, SEED, 0, 0, fuse=2)
+    S1 = gpu_ops.lattice_evaluate(act, c).cpu().numpy()
+    assert_close(S1, S0, tol=1e-11, what="action conservation under overrelaxation")
+    assert ((a >= -np.pi - 1e-12) & (a < np.pi + 1e-12)).all()
+
+
+def test_rotor_65536_and_gff_512_properties(gpu_ops):
+    from mlmcpathintegral_amd import abi
+    act = abi.path_action(2, 65536, 8192.0, 0.25)
+    x = gpu_ops.path_initialise(act, 2, SEED)
+    S0 = gpu_ops.path_evaluate(act, x).cpu().numpy()
+    scratch = torch.empty_like(x)
+    gpu_ops.path_sweep_draw(act, x, scratch, 6, 0, SEED, 0, 0)
+    assert_close(gpu_ops.path_evaluate(act, x).cpu().numpy(), S0, tol=1e-11, what="rotor OR conserves S")
+    act = abi.lattice_action(3, 512, 512, mass=10.0)
+    phi = gpu_ops.lattice_initialise(act, 2, SEED)
+    S0 = gpu_ops.lattice_evaluate(act, phi).cpu().numpy()
+    a, b = phi.clone(), phi.clone()
+    scratch = torch.empty_like(phi)
+    gpu_ops.lattice_sweep_draw(act, a, scratch, 6, 1, SEED, 0, 0, fuse=1)
+    gpu_ops.lattice_sweep_draw(act, b, scratch, 6, 1, SEED, 0, 0, fuse=4)
+    assert torch.equal(a, b)
+    c = phi.clone()
+    gpu_ops.lattice_sweep_draw(act, c, scratch, 6, 0, SEED, 0, 0, fuse=3)
+    assert_close(gpu_ops.lattice_evaluate(act, c).cpu().numpy(), S0, tol=1e-11, what="GFF OR conserves S")

@@ -1,0 +1,123 @@
+"""GPU: expectation values of the device chains against closed forms and the reference's own runs
+(SURVEY.md 8(c)).  Errors are the scatter of independent per-chain means (robust against
+autocorrelation); the bar is 4 combined standard errors (north_star asks for 2 sigma on a single
+comparison; several comparisons are made here, hence the wider gate, and the measured deviation
+is printed)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+SEED = 20240607
+
+
+def chain_mean_and_error(samples):
+    """samples [n_draws, B] -> mean, standard error from the B independent chain means"""
+    m = samples.mean(dim=0)
+    return float(m.mean()), float(m.std(unbiased=True)) / math.sqrt(m.numel())
+
+
+def test_schwinger_16x16_expectation_values(gpu_ops, golden):
+    from mlmcpathintegral_amd import abi
+    ref = golden["reference_runs"]["schwinger_16x16_beta1"]
+    act = abi.lattice_action(4, 16, 16, beta=1.0)
+    B, burn, n = 256, 200, 1500
+    x = gpu_ops.lattice_initialise(act, B, SEED)
+    scratch = torch.empty_like(x)
+    plaq, q2 = [], []
+    sweep = 0
+    for k in range(burn + n):
+        gpu_ops.lattice_sweep_draw(act, x, scratch, 1, 1, SEED, 0, sweep)  # 1 OR + 1 HB as the reference run
+        sweep += 2
+        if k >= burn:
+            plaq.append(gpu_ops.qoi_avg_plaquette(x, 16, 16))
+            q2.append(gpu_ops.qoi_2d_susceptibility(x, 16, 16))
+    mp, ep = chain_mean_and_error(torch.stack(plaq))
+    mq, eq = chain_mean_and_error(torch.stack(q2))
+    print(f"plaq {mp:.6f} +- {ep:.6f} (I1/I0 {ref['plaq_analytic']}, reference {ref['plaq']} +- {ref['plaq_err']})")
+    print(f"Q2   {mq:.4f} +- {eq:.4f} (analytic {ref['Q2_analytic']}, reference {ref['Q2']} +- {ref['Q2_err']})")
+    assert abs(mp - ref["plaq_analytic"]) < 4 * ep
+    assert abs(mp - ref["plaq"]) < 4 * math.hypot(ep, ref["plaq_err"])
+    assert abs(mq - ref["Q2_analytic"]) < 4 * eq
+    assert abs(mq - ref["Q2"]) < 4 * math.hypot(eq, ref["Q2_err"])
+
+
+def test_gff_16x16_expectation_value(gpu_ops, golden):
+    from mlmcpathintegral_amd import abi
+    ref = golden["reference_runs"]["gff_16x16_mass10"]
+    act = abi.lattice_action(3, 16, 16, mass=10.0)
+    B, burn, n = 256, 500, 2000
+    phi = gpu_ops.lattice_initialise(act, B, SEED)
+    scratch = torch.empty_like(phi)
+    vals, sweep = [], 0
+    for k in range(burn + n):
+        gpu_ops.lattice_sweep_draw(act, phi, scratch, 1, 1, SEED, 0, sweep)
+        sweep += 2
+        if k >= burn:
+            vals.append(gpu_ops.qoi_phi_squared(phi))
+    m, e = chain_mean_and_error(torch.stack(vals))
+    print(f"phi2 {m:.6f} +- {e:.6f} (analytic {ref['phi2_analytic']}, reference {ref['phi2']} +- {ref['phi2_err']})")
+    assert abs(m - ref["phi2_analytic"]) < 4 * e
+    assert abs(m - ref["phi2"]) < 4 * math.hypot(e, ref["phi2_err"])
+
+
+def test_harmonic_oscillator_hmc_config1(gpu_ops, golden):
+    """BASELINE config 1 (HO, M_lat=128, T=4, nt=100, tuned dt=0.0558) on the device chains."""
+    from mlmcpathintegral_amd import abi
+    ref = golden["reference_runs"]["config1_ho_M128"]
+    act = abi.path_action(0, 128, 4.0, 1.0, 1.0)
+    B, burn, n = 512, 100, 400
+    x = gpu_ops.path_initialise(act, B, SEED)
+    hmc = gpu_ops.PathHMC(act, B, 100, ref["tuned_dt"], seed=SEED)
+    vals = []
+    for k in range(burn + n):
+        hmc.draw(x, count_stats=k >= burn)
+        if k >= burn:
+            vals.append(gpu_ops.qoi_xsquared(x))
+    m, e = chain_mean_and_error(torch.stack(vals))
+    p_acc = float(hmc.n_accepted.double().mean()) / hmc.n_total
+    print(f"x2 {m:.6f} +- {e:.6f} (analytic {ref['analytic_x2']}, reference {ref['numerical']} +- {ref['error']}); "
+          f"p_accept {p_acc:.4f} (reference {ref['p_accept']})")
+    assert abs(m - ref["analytic_x2"]) < 4 * e
+    assert abs(p_acc - ref["p_accept"]) < 0.02
+
+
+def test_rotor_heatbath_matches_reference_order_chain(gpu_ops, orc):
+    """Rotor M=32: device multicolour chains vs the oracle's reference-order (lexicographic,
+    mt19937_64) OverrelaxedHeatBathSampler chain: topological susceptibility and <cos dx>."""
+    from mlmcpathintegral_amd import abi
+    M, T, m0 = 32, 4.0, 0.25
+    act = abi.path_action(2, M, T, m0)
+    B, burn, n = 256, 200, 1000
+    x = gpu_ops.path_initialise(act, B, SEED)
+    scratch = torch.empty_like(x)
+    chi, cosd, sweep = [], [], 0
+    for k in range(burn + n):
+        gpu_ops.path_sweep_draw(act, x, scratch, 1, 1, SEED, 0, sweep)
+        sweep += 2
+        if k >= burn:
+            chi.append(gpu_ops.qoi_susceptibility(x, T))
+            cosd.append(torch.cos(x[:, 1] - x[:, 0]))
+    mchi, echi = chain_mean_and_error(torch.stack(chi))
+    mcos, ecos = chain_mean_and_error(torch.stack(cosd))
+    L = orc.lib()
+    A = orc.Action(orc.ROTOR, M=M, T_final=T, m0=m0)
+    hb = L.orc_heatbath_new(A.h, 1, 1, 500, 0)
+    y = np.zeros(M)
+    rc, rcos = [], []
+    for _ in range(40000):
+        L.orc_heatbath_draw(hb, y)
+        rc.append(L.orc_qoi_susceptibility(y, M, T))
+        rcos.append(math.cos(y[1] - y[0]))
+    L.orc_heatbath_free(hb)
+    rc, rcos = np.array(rc), np.array(rcos)
+    # reference chain errors from 40 batch means
+    def batch_err(v):
+        bm = v.reshape(40, -1).mean(axis=1)
+        return bm.std(ddof=1) / math.sqrt(40)
+    print(f"chi {mchi:.5f} +- {echi:.5f} vs reference-order {rc.mean():.5f} +- {batch_err(rc):.5f}; "
+          f"cos {mcos:.5f} +- {ecos:.5f} vs {rcos.mean():.5f} +- {batch_err(rcos):.5f}")
+    assert abs(mchi - rc.mean()) < 4 * math.hypot(echi, batch_err(rc))
+    assert abs(mcos - rcos.mean()) < 4 * math.hypot(ecos, batch_err(rcos))
