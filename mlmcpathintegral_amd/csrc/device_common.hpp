@@ -20,8 +20,7 @@ enum Purpose : uint32_t {
   P_MOMENTUM = 1,
   P_ACCEPT = 2,
   P_GFF_NORMAL = 3,
-  P_REJ_NORMAL = 4,
-  P_REJ_UNIFORM = 5,
+  P_VONMISES = 4,
   P_INIT = 6,
 };
 
@@ -81,53 +80,53 @@ __device__ __forceinline__ double rng_normal0(const RngKey &k, uint32_t site, ui
   return sqrt(-2.0 * log(1.0 - u)) * cos(kTwoPi * v);
 }
 
-// ---- rejection samplers -----------------------------------------------------------------------
-// Attempt a uses the (a&1) branch of normal call a>>1 and of uniform call a>>1, so a wave never
-// needs more than one Box-Muller evaluation per two attempts.  The loops are bounded (2^21
-// attempts) so that every wave reaches its exit even on NaN input, where the reference would spin
-// forever; with finite input the bound is unreachable in practice.
-constexpr uint32_t kMaxAttemptPairs = 1u << 20;
-//
-// distribution/expcosdistribution.hh:51-65
+// ---- heat-bath angle draws ------------------------------------------------------------------------
+// Both heat-bath conditionals of the reference are von Mises laws p(x) ~ exp(kappa cos(x - c)):
+//   ExpCosDistribution   kappa = tau = 2 beta |cos(dx/2)|      distribution/expcosdistribution.{hh:51-65,cc:7-21}
+//   ExpSin2Distribution  kappa = sigma / 2                      distribution/expsin2distribution.{hh:45-58,cc:20-24}
+// The reference draws them by rejection from a Gaussian envelope with acceptance rate
+// sqrt(kappa/pi) I0(kappa) e^-kappa <= 0.27, -> 0 like sqrt(kappa) for flat conditionals: fine one
+// site at a time on a CPU, but on a 64-wide wave the slowest lane sets the pace, and in a
+// 1024^2 x batch sweep some link always has kappa ~ 1e-8 (~1e4 attempts) and stalls the whole
+// launch.  The device samples the SAME distribution with the wrapped-Cauchy envelope of Best &
+// Fisher (Appl. Statist. 28 (1979) 152-157): acceptance >= 0.65 for every kappa, one cosine per
+// attempt, one arccosine per draw.  Attempt t uses Philox counter word 3 = P_VONMISES<<24 | t.
+__device__ __forceinline__ double vonmises_draw(const RngKey &k, uint32_t site, double kappa) {
+  kappa = fmax(kappa, 1e-12);  // also maps NaN to a finite concentration: every wave reaches its exit
+  const double s = sqrt(1. + 4. * kappa * kappa);
+  const double a = 1. + s;
+  const double b = 2. * kappa / (a + sqrt(2. * a));  // = (a - sqrt(2a)) / (2 kappa) without cancellation
+  const double r = (1. + b * b) / (2. * b);
+  double f = 1.0;
+  bool negative = false;
+  for (uint32_t attempt = 0; attempt < 1024u; ++attempt) {
+    const U4 w = philox4x32_10(site, k.chain, k.step, (P_VONMISES << 24) | attempt, k.k0, k.k1);
+    const double u1 = u01(w.x, w.y), u2 = u01(w.z, w.w);
+    negative = (w.x & 1u) != 0;  // bit 0 does not enter u1 (u01 drops the low 11 bits)
+    const double z = cos(kPi * u1);
+    f = (1. + r * z) / (r + z);
+    const double c = kappa * (r - f);
+    if (c * (2. - c) - u2 > 0.) break;
+    if (log(c / u2) + 1. - c >= 0.) break;
+  }
+  f = fmin(1.0, fmax(-1.0, f));
+  const double theta = acos(f);
+  return negative ? -theta : theta;
+}
+
+// quenchedschwingeraction.cc:46-54 -> expcosdistribution.hh:51-65: the draw is centred on the mean
+// staple angle, shifted by pi when the staples are more than pi apart
 __device__ __forceinline__ double expcos_draw(const RngKey &k, uint32_t site, double beta, double x_p,
                                               double x_m) {
   const double dx = x_m - x_p;
   const double tau = 2. * beta * fabs(cos(0.5 * dx));
-  const double sigma = kPi * sqrt(2. / tau);
-  const double inv4pi2 = 1. / (4. * kPi * kPi);
-  double x = 0.0;
-  for (uint32_t pair = 0; pair < kMaxAttemptPairs; ++pair) {
-    double n0, n1, u0, u1;
-    rng_normals(k, site, P_REJ_NORMAL, pair, n0, n1);
-    rng_uniforms(k, site, P_REJ_UNIFORM, pair, u0, u1);
-    x = sigma * n0;
-    if (-kPi <= x && x < kPi && u0 <= exp(tau * (cos(x) - 1. + inv4pi2 * x * x))) break;
-    x = sigma * n1;
-    if (-kPi <= x && x < kPi && u1 <= exp(tau * (cos(x) - 1. + inv4pi2 * x * x))) break;
-    x = 0.0;  // only reached when the bound is exhausted
-  }
+  const double x = vonmises_draw(k, site, tau);
   return mod_2pi(x + 0.5 * (x_p + x_m) + (fabs(dx) > kPi ? kPi : 0.0));
 }
 
-// distribution/expsin2distribution.hh:45-58
+// rotoraction.cc:20-37 -> expsin2distribution.hh:45-58
 __device__ __forceinline__ double expsin2_draw(const RngKey &k, uint32_t site, double sigma) {
-  const double scale = kPi / sqrt(2. * sigma);
-  for (uint32_t pair = 0; pair < kMaxAttemptPairs; ++pair) {
-    double n0, n1, u0, u1;
-    rng_normals(k, site, P_REJ_NORMAL, pair, n0, n1);
-    rng_uniforms(k, site, P_REJ_UNIFORM, pair, u0, u1);
-    double r = scale * n0;
-    if (fabs(r) < kPi) {
-      double s = sin(0.5 * r);
-      if (u0 < exp(-sigma * (s * s - r * r / (kPi * kPi)))) return r;
-    }
-    r = scale * n1;
-    if (fabs(r) < kPi) {
-      double s = sin(0.5 * r);
-      if (u1 < exp(-sigma * (s * s - r * r / (kPi * kPi)))) return r;
-    }
-  }
-  return 0.0;
+  return vonmises_draw(k, site, 0.5 * sigma);
 }
 
 // ---- reductions -------------------------------------------------------------------------------

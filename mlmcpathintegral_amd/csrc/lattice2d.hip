@@ -34,6 +34,38 @@ __device__ __forceinline__ void for_region(uint32_t nr, uint32_t nc, F f) {
   }
 }
 
+// Staging loop for global -> LDS: the same traversal as for_region, but UNR independent loads are
+// issued back to back before any of them is consumed, so a thread has UNR HBM requests in flight
+// instead of one (a rolled load -> wait -> ds_write loop is latency bound: ~10 dependent round
+// trips per tile).
+template <int UNR, class T, class Load, class Store>
+__device__ __forceinline__ void stage_region(uint32_t nr, uint32_t nc, Load load, Store store) {
+  const uint32_t total = nr * nc;
+  uint32_t idx = threadIdx.x;
+  uint32_t ri = idx / nc, ci = idx - ri * nc;
+  const uint32_t dr = kSweepThreads / nc, dc = kSweepThreads - dr * nc;
+  while (idx < total) {
+    T v[UNR];
+    uint32_t rr[UNR], cc[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      rr[u] = ri;
+      cc[u] = ci;
+      if (idx + u * kSweepThreads < total) v[u] = load(ri, ci);
+      ri += dr;
+      ci += dc;
+      if (ci >= nc) {
+        ci -= nc;
+        ++ri;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u)
+      if (idx + u * kSweepThreads < total) store(rr[u], cc[u], v[u]);
+    idx += UNR * kSweepThreads;
+  }
+}
+
 struct TileGeom {
   uint32_t TW, TH;      // owned tile extent (even)
   uint32_t tiles_x;     // tiles per row of tiles
@@ -51,6 +83,7 @@ __device__ __forceinline__ uint32_t wrap_add(uint32_t base, uint32_t off, uint32
 // six staple links lie inside the buffer is updated; the region of exact values shrinks by at most
 // two sites per side per sweep, so a halo of 2*nsweeps keeps the owned tile exact (tile origins are
 // even, which makes buffer parity equal lattice parity).
+template <bool HEAT>
 __global__ void __launch_bounds__(kSweepThreads)
     schwinger_sweep_kernel(uint32_t Mt, uint32_t Mx, double beta, const double2 *__restrict__ in,
                            double2 *__restrict__ out, TileGeom tg, uint32_t nsweeps, uint32_t kinds, RngKey key0) {
@@ -68,16 +101,16 @@ __global__ void __launch_bounds__(kSweepThreads)
   RngKey key = key0;
   key.chain += b;
 
-  for_region(bh, bw, [&](uint32_t r, uint32_t c) {
-    const uint32_t jj = wrap_add(sr, r, Mx), ii = wrap_add(sc, c, Mt);
-    const double2 v = src[(size_t)jj * Mt + ii];
-    th0[r * bw + c] = v.x;
-    th1[r * bw + c] = v.y;
-  });
+  stage_region<5, double2>(
+      bh, bw, [&](uint32_t r, uint32_t c) { return src[(size_t)wrap_add(sr, r, Mx) * Mt + wrap_add(sc, c, Mt)]; },
+      [&](uint32_t r, uint32_t c, double2 v) {
+        th0[r * bw + c] = v.x;
+        th1[r * bw + c] = v.y;
+      });
   __syncthreads();
 
   for (uint32_t s = 0; s < nsweeps; ++s) {
-    const bool heat = (kinds >> s) & 1u;
+    const bool heat = HEAT && ((kinds >> s) & 1u);
     RngKey skey = key;
     skey.step += s;
     // mu = 0: rows of one parity, r in [1, bh-2], c in [0, bw-2]
@@ -130,6 +163,7 @@ __global__ void __launch_bounds__(kSweepThreads)
 // ---- GFF sweeps --------------------------------------------------------------------------------------
 // Red/black order: (i+j) even, then odd.  gffaction.cc:33-42 (heat bath), :68-77 (overrelaxation);
 // Delta is summed in the order of the reference's neighbour table (+i, -i, +j, -j).
+template <bool HEAT>
 __global__ void __launch_bounds__(kSweepThreads)
     gff_sweep_kernel(uint32_t Mt, uint32_t Mx, double mu2, const double *__restrict__ in, double *__restrict__ out,
                      TileGeom tg, uint32_t nsweeps, uint32_t kinds, RngKey key0) {
@@ -148,13 +182,13 @@ __global__ void __launch_bounds__(kSweepThreads)
   key.chain += b;
   const double kappa = 4. + mu2, sigma = 1. / sqrt(4. + mu2);
 
-  for_region(bh, bw, [&](uint32_t r, uint32_t c) {
-    phi[r * bw + c] = src[(size_t)wrap_add(sr, r, Mx) * Mt + wrap_add(sc, c, Mt)];
-  });
+  stage_region<5, double>(
+      bh, bw, [&](uint32_t r, uint32_t c) { return src[(size_t)wrap_add(sr, r, Mx) * Mt + wrap_add(sc, c, Mt)]; },
+      [&](uint32_t r, uint32_t c, double v) { phi[r * bw + c] = v; });
   __syncthreads();
 
   for (uint32_t s = 0; s < nsweeps; ++s) {
-    const bool heat = (kinds >> s) & 1u;
+    const bool heat = HEAT && ((kinds >> s) & 1u);
     RngKey skey = key;
     skey.step += s;
     for (uint32_t colour = 0; colour < 2; ++colour) {
@@ -427,8 +461,10 @@ int mlmcpi_lattice_sweep_draw(const mlmcpi_lattice_action *act, double *d_phi, d
   const size_t state_bytes = (size_t)B * act->Mt * act->Mx * (schw ? 16 : 8);
   if (!g_lds_attr_set) {
     // allow tiles with deep halos to use the full 160 KiB of LDS
-    MLMCPI_HIP_TRY(hipFuncSetAttribute((const void *)schwinger_sweep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    MLMCPI_HIP_TRY(hipFuncSetAttribute((const void *)gff_sweep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    const void *kernels[4] = {(const void *)schwinger_sweep_kernel<false>, (const void *)schwinger_sweep_kernel<true>,
+                              (const void *)gff_sweep_kernel<false>, (const void *)gff_sweep_kernel<true>};
+    for (const void *kf : kernels)
+      MLMCPI_HIP_TRY(hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     g_lds_attr_set = true;
   }
   double *src = d_phi, *dst = d_scratch;
@@ -447,12 +483,19 @@ int mlmcpi_lattice_sweep_draw(const mlmcpi_lattice_action *act, double *d_phi, d
     const size_t lds = (size_t)(tg.TW + 4 * n) * (tg.TH + 4 * n) * (schw ? 16 : 8);
     const RngKey key = make_key(seed, chain0, sweep0 + s);
     dim3 grid(tg.tiles_x * tiles_y, B), block(kSweepThreads);
-    if (schw)
-      hipLaunchKernelGGL(schwinger_sweep_kernel, grid, block, lds, st, act->Mt, act->Mx, act->beta,
+    // launches without a heat-bath sweep use the lean instantiation (no sampler code, fewer VGPRs)
+    if (schw && kinds)
+      hipLaunchKernelGGL(schwinger_sweep_kernel<true>, grid, block, lds, st, act->Mt, act->Mx, act->beta,
                          (const double2 *)src, (double2 *)dst, tg, n, kinds, key);
+    else if (schw)
+      hipLaunchKernelGGL(schwinger_sweep_kernel<false>, grid, block, lds, st, act->Mt, act->Mx, act->beta,
+                         (const double2 *)src, (double2 *)dst, tg, n, kinds, key);
+    else if (kinds)
+      hipLaunchKernelGGL(gff_sweep_kernel<true>, grid, block, lds, st, act->Mt, act->Mx, gff_mu2(*act),
+                         (const double *)src, dst, tg, n, kinds, key);
     else
-      hipLaunchKernelGGL(gff_sweep_kernel, grid, block, lds, st, act->Mt, act->Mx, gff_mu2(*act), (const double *)src,
-                         dst, tg, n, kinds, key);
+      hipLaunchKernelGGL(gff_sweep_kernel<false>, grid, block, lds, st, act->Mt, act->Mx, gff_mu2(*act),
+                         (const double *)src, dst, tg, n, kinds, key);
     MLMCPI_LAUNCH_CHECK("lattice sweep kernel");
     double *tmp = src; src = dst; dst = tmp;
     s += n;

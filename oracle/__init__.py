@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "liboracle.so")
 
 HARMONIC, QUARTIC, ROTOR, GFF, SCHWINGER = range(5)
-P_MOMENTUM, P_ACCEPT, P_GFF_NORMAL, P_REJ_NORMAL, P_REJ_UNIFORM, P_INIT = 1, 2, 3, 4, 5, 6
+P_MOMENTUM, P_ACCEPT, P_GFF_NORMAL, P_VONMISES, P_INIT = 1, 2, 3, 4, 6
 
 
 def build(force=False):

@@ -68,8 +68,7 @@ enum Purpose : uint32_t {
   P_MOMENTUM = 1,  // HMC momenta, one call per site, Box-Muller cosine branch
   P_ACCEPT = 2,    // HMC Metropolis uniform
   P_GFF_NORMAL = 3,  // GFF heat bath, one call per vertex pair (l>>1), branch l&1
-  P_REJ_NORMAL = 4,  // ExpCos / ExpSin2 proposals: call k serves attempts 2k (cos) and 2k+1 (sin)
-  P_REJ_UNIFORM = 5, // ExpCos / ExpSin2 accept uniforms: call k serves attempts 2k and 2k+1
+  P_VONMISES = 4,    // heat-bath angle draws (Schwinger, rotor): one call per attempt, sub = attempt
   P_INIT = 6,        // initial states: one uniform per entry
 };
 
@@ -115,29 +114,6 @@ struct RefAttemptSource {
   double next_uniform() { return r.uniform(r.engine); }
 };
 
-struct DevAttemptSource {  // attempt a: normal = branch a&1 of call a>>1; uniform likewise
-  const DevRng &rng;
-  uint32_t site;
-  uint32_t attempt = 0;
-  double cached_n1 = 0, cached_u1 = 0;
-  // The uniform belonging to attempt a is only *used* when the proposal is inside the window,
-  // but its position in the stream is fixed by the attempt index, so results do not depend on
-  // control flow.
-  double next_normal() {
-    double n0, n1;
-    rng.normals(site, P_REJ_NORMAL, attempt >> 1, n0, n1);
-    double n = (attempt & 1) ? n1 : n0;
-    ++attempt;
-    return n;
-  }
-  double next_uniform() {  // uniform of the attempt whose normal was just drawn
-    uint32_t a = attempt - 1;
-    double u0, u1;
-    rng.uniforms(site, P_REJ_UNIFORM, a >> 1, u0, u1);
-    return (a & 1) ? u1 : u0;
-  }
-};
-
 // distribution/expsin2distribution.hh:45-58
 template <class Src>
 double expsin2_draw(Src &src, double sigma) {
@@ -169,6 +145,62 @@ double expcos_draw(Src &src, double beta, double x_p, double x_m) {
   }
   return wrap_2pi(x + 0.5 * (x_p + x_m) + (std::fabs(dx) > kPi ? kPi : 0.0));
 }
+
+// Device-order angle sampler.  Both heat-bath conditionals of the reference are von Mises laws:
+//   ExpCos   p(x) ~ exp(tau cos(x - centre)), tau = 2 beta |cos(dx/2)|   (expcosdistribution.cc:7-21)
+//   ExpSin2  p(x) ~ exp(-sigma sin^2(x/2)) = exp((sigma/2)(cos x - 1))     (expsin2distribution.cc:20-24)
+// The reference draws them by rejection from a Gaussian envelope whose acceptance rate is
+// sqrt(tau/pi) I0(tau) e^-tau <= 0.27 and tends to 0 like sqrt(tau) for flat conditionals.  On a
+// 64-wide wave the slowest lane sets the pace (and at 1024^2 x batch some link always has tau ~ 1e-8,
+// i.e. ~1e4 attempts), so the device path samples the SAME distribution with the wrapped-Cauchy
+// envelope of Best & Fisher (Appl. Statist. 28 (1979) 152-157), whose acceptance rate is >= 0.65
+// for every concentration.  Equality in distribution with the reference's samplers is a test
+// (tests/test_distributions.py), not an assumption.
+inline double dev_vonmises(const DevRng &rng, uint32_t site, double kappa) {
+  kappa = std::fmax(kappa, 1e-12);  // also maps NaN to a finite concentration: the loop always ends
+  const double s = std::sqrt(1. + 4. * kappa * kappa);
+  const double a = 1. + s;
+  const double b = 2. * kappa / (a + std::sqrt(2. * a));  // = (a - sqrt(2a)) / (2 kappa), cancellation free
+  const double r = (1. + b * b) / (2. * b);
+  double f = 1.0;
+  bool negative = false;
+  for (uint32_t attempt = 0; attempt < 1024u; ++attempt) {
+    Philox4 w = rng.raw(site, P_VONMISES, attempt);
+    const double u1 = u01(w.v[0], w.v[1]), u2 = u01(w.v[2], w.v[3]);
+    negative = (w.v[0] & 1u) != 0;  // bit 0 is not part of u1 (u01 drops the low 11 bits)
+    const double z = std::cos(kPi * u1);
+    f = (1. + r * z) / (r + z);
+    const double c = kappa * (r - f);
+    if (c * (2. - c) - u2 > 0.) break;
+    if (std::log(c / u2) + 1. - c >= 0.) break;
+  }
+  f = std::fmin(1.0, std::fmax(-1.0, f));
+  const double theta = std::acos(f);
+  return negative ? -theta : theta;
+}
+
+struct RefAngles {  // reference algorithms, reference engine
+  RefRng &r;
+  double expcos(uint32_t, double beta, double x_p, double x_m) {
+    RefAttemptSource src{r};
+    return expcos_draw(src, beta, x_p, x_m);
+  }
+  double expsin2(uint32_t, double sigma) {
+    RefAttemptSource src{r};
+    return expsin2_draw(src, sigma);
+  }
+};
+
+struct DevAngles {  // device order: Philox + Best-Fisher
+  const DevRng &rng;
+  double expcos(uint32_t site, double beta, double x_p, double x_m) {
+    const double dx = x_m - x_p;
+    const double tau = 2. * beta * std::fabs(std::cos(0.5 * dx));
+    const double x = dev_vonmises(rng, site, tau);
+    return wrap_2pi(x + 0.5 * (x_p + x_m) + (std::fabs(dx) > kPi ? kPi : 0.0));  // expcosdistribution.hh:64
+  }
+  double expsin2(uint32_t site, double sigma) { return dev_vonmises(rng, site, 0.5 * sigma); }
+};
 
 // ---------------------------------------------------------------------------------------------
 // Lattice index maps.  lattice/lattice2d.hh:230-268,348-375; lattice/lattice2d.cc:137-155;
@@ -423,14 +455,14 @@ struct ActionO {
   }
 
   // rotoraction.cc:20-37, gffaction.cc:33-42, quenchedschwingeraction.cc:46-54
-  template <class Src>
-  bool heatbath(double *x, unsigned l, Src &src, double gff_normal) const {
+  template <class Angles>
+  bool heatbath(double *x, unsigned l, Angles &src, double gff_normal) const {
     switch (kind) {
       case ROTOR: {
         double xm = x[(l + M - 1) % M], xp = x[(l + 1) % M];
         double x_min = w_minimum(xm, xp);
         double sigma = 2. * w_curvature(xm, xp);
-        x[l] = wrap_2pi(x_min + expsin2_draw(src, sigma));
+        x[l] = wrap_2pi(x_min + src.expsin2(l, sigma));
         return true;
       }
       case GFF:
@@ -441,7 +473,7 @@ struct ActionO {
         double tp, tm;
         g.link_inv(l, i, j, mu);
         staples(x, i, j, mu, tp, tm);
-        x[l] = expcos_draw(src, beta, tp, tm);
+        x[l] = src.expcos(l, beta, tp, tm);
         return true;
       }
       default: return false;
@@ -449,7 +481,7 @@ struct ActionO {
   }
 
   bool heatbath_ref(double *x, unsigned l) {
-    RefAttemptSource src{rng};
+    RefAngles src{rng};
     double n = (kind == GFF) ? rng.normal(rng.engine) : 0.0;
     return heatbath(x, l, src, n);
   }
@@ -497,7 +529,7 @@ void dev_sweep(const ActionO &A, double *x, bool heat, const DevRng &rng) {
       if (!heat) {
         A.overrelax(x, l);
       } else {
-        DevAttemptSource src{rng, l};
+        DevAngles src{rng};
         double gn = 0.0;
         if (A.kind == GFF) {
           double n0, n1;
@@ -817,13 +849,13 @@ void orc_expsin2_draws(uint64_t seed, double sigma, unsigned n, double *out) {
 double orc_dev_expcos_draw(uint64_t seed, uint32_t chain, uint32_t step, uint32_t site, double beta,
                            double x_p, double x_m) {
   DevRng r{(uint32_t)seed, (uint32_t)(seed >> 32), chain, step};
-  DevAttemptSource s{r, site};
-  return expcos_draw(s, beta, x_p, x_m);
+  DevAngles s{r};
+  return s.expcos(site, beta, x_p, x_m);
 }
 double orc_dev_expsin2_draw(uint64_t seed, uint32_t chain, uint32_t step, uint32_t site, double sigma) {
   DevRng r{(uint32_t)seed, (uint32_t)(seed >> 32), chain, step};
-  DevAttemptSource s{r, site};
-  return expsin2_draw(s, sigma);
+  DevAngles s{r};
+  return s.expsin2(site, sigma);
 }
 
 // ---- QoIs --------------------------------------------------------------------------------------

@@ -2,9 +2,15 @@
 
 Tolerances (north_star: bit-exact for integer/index work, stated fp tolerance otherwise):
   * Philox words and uniforms: bit-exact;
-  * deterministic fp64 functions (evaluate, force, QoI, single updates, whole sweeps and HMC
-    trajectories with the same counter-based random numbers): |diff| <= 1e-12 * scale, the slack
-    covering libm-vs-ocml transcendentals, FMA contraction and summation order;
+  * deterministic fp64 functions (evaluate, force, QoI, single updates, overrelaxation sweeps and
+    HMC trajectories with the same counter-based random numbers): |diff| <= 1e-12 * scale, the
+    slack covering libm-vs-ocml transcendentals, FMA contraction and summation order;
+  * heat-bath sweeps: the accepted proposal is sigma * n with sigma = pi sqrt(2/tau) (ExpCos) or
+    pi / sqrt(2 sigma) (ExpSin2); where the conditional distribution is nearly flat (tau -> 0) a
+    rounding difference d in the staples or in the Box-Muller normal is amplified by
+    ~ |x| tan(dx/2) / 2, so one sweep from identical inputs is compared at 2e-10 and two
+    consecutive heat-bath sweeps at 1e-8 (single draws with given staples: 4e-12, see
+    test_expcos_draws_match_oracle);
   * expectation values: within 4 combined standard errors of the reference chain / closed form
     (tests/test_gpu_statistics.py).
 """
@@ -19,6 +25,8 @@ pytestmark = pytest.mark.gpu
 
 SEED = 0x1234567812345678
 TOL = 1e-12
+# angular tolerance (before the x4 of assert_angles_close) by number of heat-bath sweeps in the case
+HB_TOL = {0: 1e-12, 1: 5e-11, 2: 2.5e-9}
 
 
 def dev(a):
@@ -58,7 +66,7 @@ def test_philox_known_answers_on_device(gpu_ops):
         assert [f"{x:08x}" for x in out] == v["out"]
 
 
-@pytest.mark.parametrize("purpose,sub", [(1, 0), (3, 0), (4, 7), (5, 123456)])
+@pytest.mark.parametrize("purpose,sub", [(1, 0), (3, 0), (4, 7), (6, 123456)])
 def test_random_streams_match_oracle(gpu_ops, orc, purpose, sub):
     n, chain, step = 1000, 17, 9001
     got = gpu_ops.test_random(SEED, chain, step, purpose, sub, n).cpu().numpy()
@@ -213,7 +221,7 @@ def test_hmc_n_rep_short_circuit(gpu_ops, orc):
     """hmcsampler.cc:10-12: `accept = accept or single_step()` stops integrating after the first
     accepted repetition; repetition r uses Philox step traj0 + r."""
     act, A = make_path(orc, "quartic", dict(M=256, T_final=32.0, m0=1.0, mu2=1.0, lam=1.0, x0=1.0))
-    B, nt, dt, n_rep = 6, 10, 0.35, 3  # large dt: a mix of accepts and rejects
+    B, nt, dt, n_rep = 6, 10, 0.30, 3  # large dt: a mix of accepts and rejects (about 50 % each)
     rng = np.random.default_rng(0)
     x0 = rng.uniform(-1, 1, (B, 256))
     xd = dev(x0)
@@ -242,13 +250,15 @@ def test_rotor_sweeps_match_oracle(gpu_ops, orc, M, B):
     xd, scratch = dev(x0), torch.empty((B, M), dtype=torch.float64, device="cuda")
     xo = x0.copy()
     sweep = 0
-    for n_or, n_hb in ((1, 0), (0, 1), (3, 2), (5, 1)):
+    for n_or, n_hb in ((1, 0), (6, 0), (0, 1), (3, 2), (5, 1)):
+        xd.copy_(dev(xo))  # every case starts from identical inputs on both sides
         gpu_ops.path_sweep_draw(act, xd, scratch, n_or, n_hb, SEED, 7, sweep)
         for b in range(B):
             for s in range(n_or + n_hb):
                 A.dev_sweep(xo[b], s >= n_or, SEED, 7 + b, sweep + s)
         sweep += n_or + n_hb
-        assert_angles_close(xd.cpu().numpy(), xo, what=f"rotor sweeps ({n_or},{n_hb})")
+        tol = HB_TOL[min(n_hb, 2)]
+        assert_angles_close(xd.cpu().numpy(), xo, tol=tol, what=f"rotor sweeps ({n_or},{n_hb})")
 
 
 def test_path_sweep_unsupported_action(gpu_ops):
@@ -344,7 +354,8 @@ def test_lattice_sweeps_match_oracle(gpu_ops, orc, kind, Mt, Mx, kw, B, fuse):
     xd, scratch = dev(x0), torch.empty((B, n), dtype=torch.float64, device="cuda")
     xo = x0.copy()
     sweep = 100
-    for n_or, n_hb in ((1, 0), (0, 1), (2, 1), (4, 2)):
+    for n_or, n_hb in ((1, 0), (5, 0), (0, 1), (2, 1), (4, 2)):
+        xd.copy_(dev(xo))  # every case starts from identical inputs on both sides
         gpu_ops.lattice_sweep_draw(act, xd, scratch, n_or, n_hb, SEED, 11, sweep, fuse=fuse)
         for b in range(B):
             for s in range(n_or + n_hb):
@@ -352,7 +363,7 @@ def test_lattice_sweeps_match_oracle(gpu_ops, orc, kind, Mt, Mx, kw, B, fuse):
         sweep += n_or + n_hb
         got = xd.cpu().numpy()
         if kind == "schwinger":
-            assert_angles_close(got, xo, what=f"sweeps ({n_or},{n_hb}) fuse={fuse}")
+            assert_angles_close(got, xo, tol=HB_TOL[min(n_hb, 2)], what=f"sweeps ({n_or},{n_hb}) fuse={fuse}")
         else:
             assert_close(got, xo, tol=1e-11, what=f"sweeps ({n_or},{n_hb}) fuse={fuse}")
 
