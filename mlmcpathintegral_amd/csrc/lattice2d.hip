@@ -119,14 +119,14 @@ __global__ void __launch_bounds__(kSweepThreads)
       const uint32_t nr = (bh - 2 - r_first) / 2 + 1;
       for_region(nr, bw - 1, [&](uint32_t ri, uint32_t c) {
         const uint32_t r = r_first + 2 * ri, o = r * bw + c;
-        const double tp = mod_2pi(th0[o + bw] + th1[o] - th1[o + 1]);
-        const double tm = mod_2pi(th0[o - bw] + th1[o - bw + 1] - th1[o - bw]);
+        const double tp = mod_2pi_fast(th0[o + bw] + th1[o] - th1[o + 1]);
+        const double tm = mod_2pi_fast(th0[o - bw] + th1[o - bw + 1] - th1[o - bw]);
         double v;
         if (heat) {
           const uint32_t jj = wrap_add(sr, r, Mx), ii = wrap_add(sc, c, Mt);
           v = expcos_draw(skey, 2 * (jj * Mt + ii), beta, tp, tm);
         } else {
-          v = mod_2pi((tp + tm) - th0[o]);
+          v = mod_2pi_fast((tp + tm) - th0[o]);
         }
         th0[o] = v;
       });
@@ -138,14 +138,14 @@ __global__ void __launch_bounds__(kSweepThreads)
       const uint32_t nc = (bw - 2 - c_first) / 2 + 1;
       for_region(bh - 1, nc, [&](uint32_t r, uint32_t ci) {
         const uint32_t c = c_first + 2 * ci, o = r * bw + c;
-        const double tp = mod_2pi(th0[o] + th1[o + 1] - th0[o + bw]);
-        const double tm = mod_2pi(th0[o + bw - 1] + th1[o - 1] - th0[o - 1]);
+        const double tp = mod_2pi_fast(th0[o] + th1[o + 1] - th0[o + bw]);
+        const double tm = mod_2pi_fast(th0[o + bw - 1] + th1[o - 1] - th0[o - 1]);
         double v;
         if (heat) {
           const uint32_t jj = wrap_add(sr, r, Mx), ii = wrap_add(sc, c, Mt);
           v = expcos_draw(skey, 2 * (jj * Mt + ii) + 1, beta, tp, tm);
         } else {
-          v = mod_2pi((tp + tm) - th1[o]);
+          v = mod_2pi_fast((tp + tm) - th1[o]);
         }
         th1[o] = v;
       });

@@ -339,9 +339,9 @@ __global__ void __launch_bounds__(256)
         if (heat) {
           const double sigma = 2. * (sig_scale * fabs(cos(0.5 * (xp - xm))));
           const uint32_t gsite = (uint32_t)(((uint64_t)g0 + k) % M);
-          xn = mod_2pi(x_min + expsin2_draw(skey, gsite, sigma));
+          xn = mod_2pi_fast(x_min + expsin2_draw(skey, gsite, sigma));
         } else {
-          xn = mod_2pi(2.0 * x_min - buf[k]);
+          xn = mod_2pi_fast(2.0 * x_min - buf[k]);
         }
         buf[k] = xn;
       }
