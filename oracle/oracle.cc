@@ -160,8 +160,9 @@ inline double dev_vonmises(const DevRng &rng, uint32_t site, double kappa) {
   kappa = std::fmax(kappa, 1e-12);  // also maps NaN to a finite concentration: the loop always ends
   const double s = std::sqrt(1. + 4. * kappa * kappa);
   const double a = 1. + s;
-  const double b = 2. * kappa / (a + std::sqrt(2. * a));  // = (a - sqrt(2a)) / (2 kappa), cancellation free
-  const double r = (1. + b * b) / (2. * b);
+  const double w = a + std::sqrt(2. * a);
+  // r = (1 + b^2)/(2 b) with b = (a - sqrt(2a))/(2 kappa) = 2 kappa / w (cancellation free), one division
+  const double r = (w * w + 4. * kappa * kappa) / (4. * kappa * w);
   double f = 1.0;
   bool negative = false;
   for (uint32_t attempt = 0; attempt < 1024u; ++attempt) {
