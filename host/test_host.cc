@@ -1,0 +1,143 @@
+// test_host.cc -- self-checking test of the C++ host layer (include/mlmcpi/*.hh) on a GPU.
+// Known answers: SURVEY.md 8(c) (recorded from the compiled reference).  Exit code 0 = all passed.
+//   test_host            run all checks
+//   test_host --fatal X  provoke error path X (the process must print "ERROR: ..." and exit(1))
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+#include "mlmcpi/montecarlo.hh"
+
+using namespace mlmcpi;
+
+static int failures = 0;
+#define EXPECT(cond, ...)                    \
+  do {                                       \
+    if (!(cond)) {                           \
+      ++failures;                            \
+      std::printf("FAIL %s:%d: ", __FILE__, __LINE__); \
+      std::printf(__VA_ARGS__);              \
+      std::printf("\n");                     \
+    }                                        \
+  } while (0)
+
+static bool close(double a, double b, double tol = 1e-12) { return std::fabs(a - b) <= tol * std::fmax(1.0, std::fabs(b)); }
+
+static void fill_sin(std::shared_ptr<SampleState> s) {
+  for (size_t l = 0; l < s->data.size(); ++l) s->data[l] = std::sin(l + 1.0);
+}
+
+int main(int argc, char **argv) {
+  if (argc == 3 && !std::strcmp(argv[1], "--fatal")) {
+    std::string what = argv[2];
+    if (what == "gff_not_square") {
+      GFFAction a(std::make_shared<Lattice2D>(8, 4, CoarsenBoth), nullptr, 1.0);
+    } else if (what == "heatbath_on_quartic") {
+      auto lat = std::make_shared<Lattice1D>(16, 4.0);
+      auto act = std::make_shared<QuarticOscillatorAction>(lat, RenormalisationNone, 1.0, 1.0, 1.0, 1.0);
+      OverrelaxedHeatBathSampler s(act, OverrelaxedHeatBathParameters());
+    } else if (what == "per_site_update") {
+      auto lat = std::make_shared<Lattice1D>(16, 4.0);
+      auto act = std::make_shared<RotorAction>(lat, RenormalisationNone, 0.25);
+      auto st = std::make_shared<SampleState>(16);
+      act->heatbath_update(st, 3);
+    } else if (what == "qoi_wrong_size") {
+      auto lat = std::make_shared<Lattice1D>(16, 4.0);
+      QoIXsquared q(lat);
+      q.evaluate(std::make_shared<SampleState>(8));
+    } else if (what == "coarsen_odd") {
+      Lattice1D(7, 1.0).coarse_lattice();
+    }
+    return 0;  // not reached when the error path works
+  }
+
+  // ---- rotor M=16: S, force, and host/device mirroring ------------------------------------------
+  {
+    auto lat = std::make_shared<Lattice1D>(16, 4.0);
+    auto act = std::make_shared<RotorAction>(lat, RenormalisationNone, 0.25);
+    auto x = std::make_shared<SampleState>(16), f = std::make_shared<SampleState>(16);
+    fill_sin(x);
+    EXPECT(close(act->evaluate(x), 3.7784124306337965), "rotor S = %.17g", act->evaluate(x));
+    act->force(x, f);
+    const double want[4] = {0.83637060305662203, 0.76260008151417336, 0.087208194898979019, -0.58128546045789198};
+    for (int j = 0; j < 4; ++j) EXPECT(close(f->data[j], want[j]), "rotor force[%d] = %.17g", j, (double)f->data[j]);
+    x->data[0] = 0.5;  // host write must reach the device before the next kernel
+    const double S1 = act->evaluate(x);
+    x->data[0] = std::sin(1.0);
+    EXPECT(!close(S1, 3.7784124306337965) && close(act->evaluate(x), 3.7784124306337965), "lazy host->device sync");
+    QoISusceptibility chi(lat);
+    EXPECT(std::isfinite(chi.evaluate(x)), "chi finite");
+  }
+  // ---- quartic M=16 ------------------------------------------------------------------------------
+  {
+    auto lat = std::make_shared<Lattice1D>(16, 4.0);
+    auto act = std::make_shared<QuarticOscillatorAction>(lat, RenormalisationNone, 1.0, 1.0, 1.0, 1.0);
+    auto x = std::make_shared<SampleState>(16);
+    fill_sin(x);
+    EXPECT(close(act->evaluate(x), 20.749620303495885), "quartic S");
+    EXPECT(close(QoIXsquared(lat).evaluate(x), 0.49705796311310979), "quartic X2");
+    auto coarse = std::dynamic_pointer_cast<QMAction>(act->coarse_action());
+    EXPECT(coarse && coarse->sample_size() == 8 && coarse->get_coarsening_level() == 1, "coarse action");
+  }
+  // ---- Schwinger 4x4 and GFF 4x4 --------------------------------------------------------------------
+  {
+    auto lat = std::make_shared<Lattice2D>(4, 4, CoarsenBoth);
+    EXPECT(lat->link_cart2lin(-1, -1, 1) == 31, "link_cart2lin");
+    const unsigned want_nb[8] = {1, 3, 4, 12, 5, 13, 7, 15};
+    for (int k = 0; k < 8; ++k) EXPECT(lat->get_neighbour_vertices()[0][k] == want_nb[k], "neighbour %d", k);
+    auto act = std::make_shared<QuenchedSchwingerAction>(lat, nullptr, RenormalisationNone, 1.0);
+    auto x = std::make_shared<SampleState>(act->sample_size()), f = std::make_shared<SampleState>(act->sample_size());
+    fill_sin(x);
+    EXPECT(close(act->evaluate(x), 8.7055541417150231), "schwinger S");
+    EXPECT(close(QoIAvgPlaquette(lat).evaluate(x), 0.45590286614281106), "plaquette");
+    act->force(x, f);
+    EXPECT(close(f->data[3], -1.9435851018986892), "schwinger force[3]");
+    auto gff = std::make_shared<GFFAction>(lat, nullptr, 10.0);
+    auto phi = std::make_shared<SampleState>(16);
+    fill_sin(phi);
+    EXPECT(close(gff->getmu2(), 6.25) && close(gff->evaluate(phi), 41.88143013055145), "gff S");
+    EXPECT(close(QoI2DPhiSquared(lat).evaluate(phi), 0.49705796311310979), "phi2");
+    auto rot = std::make_shared<Lattice2D>(4, 4, CoarsenRotate)->get_coarse_lattice();
+    const unsigned want_rot[8] = {4, 6, 5, 7, 1, 1, 2, 2};
+    EXPECT(rot && rot->is_rotated() && rot->getNvertices() == 8, "rotated coarse lattice");
+    for (int k = 0; k < 8 && rot; ++k) EXPECT(rot->get_neighbour_vertices()[0][k] == want_rot[k], "rotated neighbour %d", k);
+  }
+  // ---- BASELINE config 1: HO, M_lat = 128, single-level HMC through the estimator loop ------------------
+  {
+    auto lat = std::make_shared<Lattice1D>(128, 4.0);
+    auto act = std::make_shared<HarmonicOscillatorAction>(lat, RenormalisationNone, 1.0, 1.0);
+    act->set_seed(8923759);  // hmcsampler.hh:89
+    HMCParameters hp;
+    hp.nt = 100; hp.dt = 0.1; hp.n_burnin = 100; hp.n_rep = 1;
+    hp.tune_iterations = 30; hp.tune_samples = 500;  // shorter than the reference's 100 x 1000: same bisection
+    SingleLevelMCParameters mp;
+    mp.n_burnin = 500; mp.n_samples = 20000;
+    MonteCarloSingleLevel mc(act, std::make_shared<QoIXsquared>(lat), std::make_shared<HMCSamplerFactory>(hp), mp);
+    auto hmc = std::dynamic_pointer_cast<HMCSampler>(mc.get_sampler());
+    EXPECT(std::fabs(hmc->get_dt() - 0.0558) < 0.004, "tuned dt = %.4f (reference 0.0558)", hmc->get_dt());
+    mc.evaluate();
+    mc.show_statistics();
+    auto st = mc.get_statistics();
+    const double exact = act->Xsquared_analytical();
+    std::printf(" analytic <x^2> = %.6f, numerical %.6f +- %.6f, p_accept %.4f\n", exact, st->average(), st->error(),
+                mc.get_sampler()->p_accept());
+    EXPECT(std::fabs(st->average() - exact) < 5 * st->error(), "HO <x^2> %.6f vs %.6f +- %.6f", st->average(), exact, st->error());
+    EXPECT(std::fabs(mc.get_sampler()->p_accept() - 0.8) < 0.05, "p_accept %.4f", mc.get_sampler()->p_accept());
+  }
+  // ---- Schwinger 16x16: OverrelaxedHeatBathSampler through the estimator loop, batch of chains ---------
+  {
+    auto lat = std::make_shared<Lattice2D>(16, 16, CoarsenBoth);
+    auto act = std::make_shared<QuenchedSchwingerAction>(lat, nullptr, RenormalisationNone, 1.0);
+    OverrelaxedHeatBathParameters hb;
+    hb.n_sweep_heatbath = 1; hb.n_sweep_overrelax = 1; hb.n_burnin = 100;
+    SingleLevelMCParameters mp;
+    mp.n_burnin = 100; mp.n_samples = 20000; mp.n_autocorr_window = 100;
+    MonteCarloSingleLevel mc(act, std::make_shared<QoIAvgPlaquette>(lat), std::make_shared<OverrelaxedHeatBathSamplerFactory>(hb), mp);
+    mc.evaluate();
+    auto st = mc.get_statistics();
+    std::printf(" plaquette %.6f +- %.6f (I1/I0 = 0.446390)\n", st->average(), st->error());
+    EXPECT(std::fabs(st->average() - 0.446390) < 5 * st->error(), "plaquette");
+  }
+  std::printf(failures ? "%d FAILURES\n" : "host layer: all checks passed\n", failures);
+  return failures ? 1 : 0;
+}

@@ -1,0 +1,229 @@
+// sampler.hh -- MCMCStep (montecarlo/mcmcstep.hh:21-72), Sampler / SamplerFactory
+// (sampler/sampler.hh:20-43), HMCSampler (sampler/hmcsampler.{hh,cc}) and
+// OverrelaxedHeatBathSampler (sampler/overrelaxedheatbathsampler.{hh,cc}) driving device chains.
+#ifndef MLMCPI_SAMPLER_HH
+#define MLMCPI_SAMPLER_HH
+#include <cmath>
+#include <iomanip>
+#include <iostream>
+#include <memory>
+#include <typeinfo>
+
+#include "action.hh"
+
+namespace mlmcpi {
+
+class MCMCStep {
+public:
+  MCMCStep() : accept(false), copy_if_rejected(false) { reset_stats(); }
+  virtual ~MCMCStep() {}
+  void reset_stats() { n_total_samples = 0; n_accepted_samples = 0; }
+  /** acceptance probability; with a batch, averaged over its chains */
+  double p_accept() { return n_accepted_samples / (1. * n_total_samples); }
+  virtual void show_stats() {
+    std::cout << std::setprecision(5) << std::fixed;
+    std::cout << "  acceptance probability  p = " << p_accept() << std::endl;
+    std::cout << "  rejection probability 1-p = " << 1. - p_accept() << std::endl;
+  }
+  bool accepted() const { return accept; }
+  virtual void set_state(std::shared_ptr<SampleState> x_state) = 0;
+  virtual double cost_per_sample() { fatal(std::string(" Cost per sample not defined for class ") + typeid(*this).name()); }
+
+protected:
+  mutable double n_accepted_samples;  // fractional for batches: mean over chains per draw
+  mutable unsigned int n_total_samples;
+  mutable bool accept;
+  mutable bool copy_if_rejected;
+};
+
+class Sampler : public MCMCStep {
+public:
+  Sampler() : MCMCStep() {}
+  virtual ~Sampler() {}
+  /** sampler/sampler.hh:36 */
+  virtual void draw(std::shared_ptr<SampleState> phi_state) = 0;
+};
+
+class SamplerFactory {
+public:
+  virtual ~SamplerFactory() {}
+  virtual std::shared_ptr<Sampler> get(std::shared_ptr<Action> action) = 0;
+};
+
+/** sampler/hmcsampler.hh:21-65 */
+struct HMCParameters {
+  unsigned int nt = 100;
+  double dt = 0.1;
+  unsigned int n_burnin = 100;
+  unsigned int n_rep = 1;
+  bool autotune = true;             // the reference always tunes (hmcsampler.hh:107)
+  unsigned int batch = 1;           // independent chains advanced together
+  unsigned int tune_iterations = 100, tune_samples = 1000;  // hmcsampler.cc:78,89
+};
+
+/** HMC on device chains.  One draw = n_rep fused trajectories (mlmcpi_path_hmc_draw for 1-D
+ *  actions, mlmcpi_lattice_hmc_draw for 2-D ones).  Construction follows hmcsampler.hh:84-109:
+ *  initialise_state, n_burnin draws, step-size auto-tuning, reset of the counters. */
+class HMCSampler : public Sampler {
+public:
+  HMCSampler(const std::shared_ptr<Action> action_, const HMCParameters hmc_param_)
+      : Sampler(), action(action_), nt_hmc(hmc_param_.nt), dt_hmc(hmc_param_.dt), n_rep(hmc_param_.n_rep),
+        n_burnin(hmc_param_.n_burnin), B(hmc_param_.batch), accept_flags(hmc_param_.batch, sizeof(int32_t)),
+        energies(4 * (size_t)hmc_param_.batch) {
+    qm = dynamic_cast<QMAction *>(action.get());
+    qft = dynamic_cast<QFTAction *>(action.get());
+    if (!qm && !qft) fatal("HMCSampler: action has no device implementation");
+    size_t bytes = 0;
+    if (qm) check(mlmcpi_path_hmc_workspace_bytes(&qm->abi_action(), B, nt_hmc, &bytes), "hmc_workspace_bytes");
+    else check(mlmcpi_lattice_hmc_workspace_bytes(&qft->abi_action(), B, &bytes), "hmc_workspace_bytes");
+    check(mlmcpi_malloc(&work, bytes), "mlmcpi_malloc");
+    phi_state_cur = std::make_shared<SampleState>(action->sample_size(), B);
+    action->initialise_state(phi_state_cur);
+    std::shared_ptr<SampleState> tmp = std::make_shared<SampleState>(action->sample_size(), B);
+    for (unsigned int i = 0; i < n_burnin; ++i) draw(tmp);
+    if (hmc_param_.autotune) autotune_stepsize(0.8, hmc_param_.tune_iterations, hmc_param_.tune_samples);
+    reset_stats();
+  }
+  virtual ~HMCSampler() { mlmcpi_free(work); }
+
+  /** hmcsampler.cc:8-19.  With a batch, `accepted()` reports chain 0 and rejected chains keep their
+   *  previous content in phi_state (copy_if_rejected == false), like the reference. */
+  void draw(std::shared_ptr<SampleState> phi_state) override {
+    const double mean_acc = step();
+    n_total_samples++;
+    n_accepted_samples += mean_acc;
+    // hmcsampler.cc:16-18: copy out only if accepted.  For a batch the whole current state is copied:
+    // a rejected chain's current state equals what the caller received at its last acceptance.
+    if (copy_if_rejected || accept || B > 1) phi_state->data = phi_state_cur->data;
+  }
+  void set_state(std::shared_ptr<SampleState> phi_state) override { phi_state_cur->data = phi_state->data; }
+  double get_dt() const { return dt_hmc; }
+  std::shared_ptr<SampleState> current_state() { return phi_state_cur; }
+
+  /** hmcsampler.cc:77-113: bisection on [dt/2, 2dt], fixed iteration count, result kept only if some
+   *  iterate came within 0.01 of the target.  Each iterate averages ~tune_samples trajectories. */
+  void autotune_stepsize(const double p_accept_target, unsigned iterations = 100, unsigned n_autotune_samples = 1000) {
+    const double tolerance = 1.E-2, dt_original = dt_hmc;
+    double dt_min = 0.5 * dt_hmc, dt_max = 2. * dt_hmc;
+    bool converged = false;
+    std::cout << std::setprecision(4) << std::fixed;
+    std::cout << " Auto-tuning HMC step size to achieve acceptance rate of " << p_accept_target << " ..." << std::endl;
+    std::cout << "  Starting with dt_{HMC} = " << dt_hmc << std::endl;
+    const unsigned draws = (n_autotune_samples + B - 1) / B;
+    for (unsigned int k = 0; k < iterations; ++k) {
+      reset_stats();
+      dt_hmc = 0.5 * (dt_min + dt_max);
+      for (unsigned int j = 0; j < draws; ++j) {
+        n_accepted_samples += single_step();
+        n_total_samples++;
+      }
+      if (p_accept() > p_accept_target) dt_min = dt_hmc; else dt_max = dt_hmc;
+      if (std::fabs(p_accept() - p_accept_target) < tolerance) converged = true;
+    }
+    if (converged) {
+      std::cout << "  Tuned         dt_{HMC} = " << dt_hmc << std::endl;
+    } else {
+      dt_hmc = dt_original;
+      std::cout << "  FAILED to tune, reverting to " << dt_hmc << std::endl;
+    }
+    std::cout << std::endl;
+    reset_stats();
+  }
+
+private:
+  double launch(unsigned reps) {
+    double *x = phi_state_cur->device_mutable();
+    if (qm)
+      check(mlmcpi_path_hmc_draw(&qm->abi_action(), x, B, nt_hmc, dt_hmc, reps, action->get_seed(), action->get_chain0(),
+                                 traj, work, (int32_t *)accept_flags.ptr(), (double *)energies.ptr(), nullptr), "path_hmc_draw");
+    else
+      check(mlmcpi_lattice_hmc_draw(&qft->abi_action(), x, B, nt_hmc, dt_hmc, reps, action->get_seed(),
+                                    action->get_chain0(), traj, work, (int32_t *)accept_flags.ptr(),
+                                    (double *)energies.ptr(), nullptr), "lattice_hmc_draw");
+    traj += reps;
+    std::vector<int32_t> flags = accept_flags.download<int32_t>();
+    double acc = 0;
+    for (int32_t f : flags) acc += f;
+    accept = flags[0] != 0;
+    return acc / B;
+  }
+  double step() { return launch(n_rep); }      // one draw
+  double single_step() { return launch(1); }   // hmcsampler.cc:22-69
+
+protected:
+  const std::shared_ptr<Action> action;
+  const unsigned int nt_hmc;
+  mutable double dt_hmc;
+  const unsigned int n_rep, n_burnin, B;
+  mutable std::shared_ptr<SampleState> phi_state_cur;
+  QMAction *qm = nullptr;
+  QFTAction *qft = nullptr;
+  void *work = nullptr;
+  DeviceVector accept_flags, energies;
+  uint32_t traj = 0;
+};
+
+/** sampler/overrelaxedheatbathsampler.hh:22-71 */
+struct OverrelaxedHeatBathParameters {
+  unsigned int n_sweep_heatbath = 1;
+  unsigned int n_sweep_overrelax = 10;
+  unsigned int n_burnin = 100;
+  bool random_order = true;  // accepted for compatibility: device sweeps are multicolour, which
+                             // needs no shuffling to be a valid sweep order
+  unsigned int batch = 1;
+};
+
+/** overrelaxedheatbathsampler.cc:8-37: n_sweep_overrelax overrelaxation sweeps, then
+ *  n_sweep_heatbath heat-bath sweeps, every sample accepted. */
+class OverrelaxedHeatBathSampler : public Sampler {
+public:
+  OverrelaxedHeatBathSampler(const std::shared_ptr<Action> action_, const OverrelaxedHeatBathParameters p)
+      : Sampler(), action(action_), n_sweep_heatbath(p.n_sweep_heatbath), n_sweep_overrelax(p.n_sweep_overrelax),
+        n_burnin(p.n_burnin), random_order(p.random_order) {
+    if (!action->has_local_updates()) fatal("heat bath update not implemented for this action ");
+    phi_state_cur = std::make_shared<SampleState>(action->sample_size(), p.batch);
+    scratch = std::make_shared<SampleState>(action->sample_size(), p.batch);
+    action->initialise_state(phi_state_cur);
+    std::shared_ptr<SampleState> tmp = std::make_shared<SampleState>(action->sample_size(), p.batch);
+    for (unsigned int i = 0; i < n_burnin; ++i) draw(tmp);
+    reset_stats();
+  }
+  void draw(std::shared_ptr<SampleState> phi_state) override {
+    action->sweep(phi_state_cur, scratch, n_sweep_overrelax, n_sweep_heatbath, sweep_counter);
+    sweep_counter += n_sweep_overrelax + n_sweep_heatbath;
+    accept = true;
+    n_total_samples++;
+    n_accepted_samples++;
+    phi_state->data = phi_state_cur->data;
+  }
+  void set_state(std::shared_ptr<SampleState> phi_state) override { phi_state_cur->data = phi_state->data; }
+  std::shared_ptr<SampleState> current_state() { return phi_state_cur; }
+
+protected:
+  const std::shared_ptr<Action> action;
+  const unsigned int n_sweep_heatbath, n_sweep_overrelax, n_burnin;
+  bool random_order;
+  mutable std::shared_ptr<SampleState> phi_state_cur, scratch;
+  uint32_t sweep_counter = 0;
+};
+
+class HMCSamplerFactory : public SamplerFactory {
+public:
+  explicit HMCSamplerFactory(const HMCParameters p) : param(p) {}
+  std::shared_ptr<Sampler> get(std::shared_ptr<Action> action) override { return std::make_shared<HMCSampler>(action, param); }
+private:
+  const HMCParameters param;
+};
+
+class OverrelaxedHeatBathSamplerFactory : public SamplerFactory {
+public:
+  explicit OverrelaxedHeatBathSamplerFactory(const OverrelaxedHeatBathParameters p) : param(p) {}
+  std::shared_ptr<Sampler> get(std::shared_ptr<Action> action) override {
+    return std::make_shared<OverrelaxedHeatBathSampler>(action, param);
+  }
+private:
+  const OverrelaxedHeatBathParameters param;
+};
+
+}  // namespace mlmcpi
+#endif

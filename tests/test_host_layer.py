@@ -1,0 +1,52 @@
+"""The C++ host layer (include/mlmcpi/*.hh): mirror of the reference's SampleState / Lattice /
+Action / Sampler / QoI / Statistics / MonteCarloSingleLevel classes over the C ABI."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "host", "test_host")
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "mlmcpathintegral_amd", "csrc")])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "host")])
+
+
+def run(*args, timeout=600):
+    if not os.path.exists(EXE):
+        build()
+    return subprocess.run([EXE, *args], capture_output=True, text=True, timeout=timeout)
+
+
+@pytest.mark.parametrize("case,message", [
+    ("coarsen_odd", "cannot coarsen 1d lattice with M = 7 points."),       # lattice/lattice1d.hh:81-86
+    ("gff_not_square", "Lattice has to be squared for GFF action"),        # action/qft/gffaction.hh:169-173
+    ("heatbath_on_quartic", "heat bath update not implemented for this action"),  # action/action.hh:73-79
+])
+def test_error_convention_without_gpu(case, message):
+    """Reference convention: "ERROR: ..." on stderr and exit(EXIT_FAILURE) (mpi/mpi_wrapper.cc:174-177)."""
+    r = run("--fatal", case)
+    assert r.returncode == 1
+    assert r.stderr.startswith("ERROR: ") and message in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,message", [
+    ("per_site_update", "heat bath update not implemented"),
+    ("qoi_wrong_size", "Evaluating QoISusceptibility on path of wrong size."),    # qoi/qm/qoixsquared.cc:9-11 (sic)
+])
+def test_error_convention_on_gpu(case, message):
+    r = run("--fatal", case)
+    assert r.returncode == 1 and message in r.stderr
+
+
+@pytest.mark.gpu
+def test_host_layer_on_gpu():
+    """Known answers through the C++ classes, lazy host/device mirroring, BASELINE config 1 (HO,
+    M_lat=128, HMC with auto-tuning) and a Schwinger heat-bath run through MonteCarloSingleLevel."""
+    r = run(timeout=900)
+    print(r.stdout[-2500:])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "all checks passed" in r.stdout
