@@ -47,12 +47,12 @@ __device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c
                                             uint32_t k1) {
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
-    uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-    uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-    c0 = hi1 ^ c1 ^ k0;
-    c1 = lo1;
-    c2 = hi0 ^ c3 ^ k1;
-    c3 = lo0;
+    // one v_mad_u64_u32 per product (hi and lo together) instead of v_mul_hi_u32 + v_mul_lo_u32
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    c0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    c1 = (uint32_t)p1;
+    c2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    c3 = (uint32_t)p0;
     k0 += 0x9E3779B9u;
     k1 += 0xBB67AE85u;
   }
@@ -129,46 +129,73 @@ __device__ __forceinline__ double cospi_unit(double u) {
   return outer ? copysign(cosx, t) : sinx;
 }
 
-__device__ __forceinline__ double vonmises_draw(const RngKey &k, uint32_t site, double kappa) {
-  kappa = fmax(kappa, 1e-12);  // also maps NaN to a finite concentration: every wave reaches its exit
+// The sampler in three pieces so that callers can run the (divergent) attempt loop as a per-lane
+// work queue: vm_envelope once per draw, vm_attempt until it returns true, vm_angle once.
+__device__ __forceinline__ double vm_clamp(double kappa) {
+  return fmax(kappa, 1e-12);  // also maps NaN to a finite concentration: every wave reaches its exit
+}
+
+__device__ __forceinline__ double vm_envelope(double kappa) {  // kappa already clamped
   const double s = sqrt(1. + 4. * kappa * kappa);
   const double a = 1. + s;
   const double w = a + sqrt(2. * a);
   // r = (1 + b^2) / (2 b) with b = (a - sqrt(2a)) / (2 kappa) = 2 kappa / w, in one division
-  const double r = (w * w + 4. * kappa * kappa) / (4. * kappa * w);
+  return (w * w + 4. * kappa * kappa) / (4. * kappa * w);
+}
+
+constexpr uint32_t kMaxVmAttempts = 1024u;
+
+// one proposal; returns true when accepted (or when the attempt bound is hit).  f = cos(theta).
+__device__ __forceinline__ bool vm_attempt(const RngKey &k, uint32_t site, uint32_t attempt, double kappa, double r,
+                                           double &f, bool &negative) {
+  const U4 q = philox4x32_10(site, k.chain, k.step, (P_VONMISES << 24) | attempt, k.k0, k.k1);
+  const double u1 = u01(q.x, q.y), u2 = u01(q.z, q.w);
+  negative = (q.x & 1u) != 0;  // bit 0 does not enter u1 (u01 drops the low 11 bits)
+  const double z = cospi_unit(u1);
+  f = (1. + r * z) / (r + z);
+  const double c = kappa * (r - f);
+  if (c * (2. - c) - u2 > 0.) return true;
+  // Exact test: log(c / u2) + 1 - c >= 0.  Squeeze in fp32 (hardware log) with a guard band that
+  // covers the fp32 rounding of c, u2 and of the logarithm; only draws inside the band (~1e-5 of
+  // them) pay for the fp64 logarithm, and the decision is always the fp64 one.
+  const float cf = (float)c;
+  const float lf = __logf(cf / (float)u2) + 1.0f - cf;
+  const float band = 2e-5f * (1.0f + cf);
+  if (lf > band) return true;
+  if (lf >= -band && log(c / u2) + 1. - c >= 0.) return true;
+  return attempt + 1 >= kMaxVmAttempts;
+}
+
+__device__ __forceinline__ double vm_angle(double f, bool negative) {
+  const double theta = acos(fmin(1.0, fmax(-1.0, f)));
+  return negative ? -theta : theta;
+}
+
+__device__ __forceinline__ double vonmises_draw(const RngKey &k, uint32_t site, double kappa) {
+  kappa = vm_clamp(kappa);
+  const double r = vm_envelope(kappa);
   double f = 1.0;
   bool negative = false;
-  for (uint32_t attempt = 0; attempt < 1024u; ++attempt) {
-    const U4 q = philox4x32_10(site, k.chain, k.step, (P_VONMISES << 24) | attempt, k.k0, k.k1);
-    const double u1 = u01(q.x, q.y), u2 = u01(q.z, q.w);
-    negative = (q.x & 1u) != 0;  // bit 0 does not enter u1 (u01 drops the low 11 bits)
-    const double z = cospi_unit(u1);
-    f = (1. + r * z) / (r + z);
-    const double c = kappa * (r - f);
-    if (c * (2. - c) - u2 > 0.) break;
-    // Exact test: log(c / u2) + 1 - c >= 0.  Squeeze in fp32 (hardware log) with a guard band that
-    // covers the fp32 rounding of c, u2 and of the logarithm; only draws inside the band (~1e-5 of
-    // them) pay for the fp64 logarithm, and the decision is always the fp64 one.
-    const float cf = (float)c;
-    const float lf = __logf(cf / (float)u2) + 1.0f - cf;
-    const float band = 2e-5f * (1.0f + cf);
-    if (lf > band) break;
-    if (lf >= -band && log(c / u2) + 1. - c >= 0.) break;
+  for (uint32_t attempt = 0; !vm_attempt(k, site, attempt, kappa, r, f, negative); ++attempt) {
   }
-  f = fmin(1.0, fmax(-1.0, f));
-  const double theta = acos(f);
-  return negative ? -theta : theta;
+  return vm_angle(f, negative);
 }
 
 // quenchedschwingeraction.cc:46-54 -> expcosdistribution.hh:51-65: the draw is centred on the mean
 // staple angle, shifted by pi when the staples are more than pi apart
+// concentration and centre of the ExpCos conditional for staples x_p, x_m in [-pi, pi]
+__device__ __forceinline__ void expcos_params(double beta, double x_p, double x_m, double &tau, double &centre) {
+  const double dx = x_m - x_p;
+  // |dx / 2| <= pi: cos(dx/2) = cos(pi u) with u = |dx| / (2 pi) in [0, 1]
+  tau = 2. * beta * fabs(cospi_unit(fmin(fabs(dx) * (0.5 / kPi), 1.0)));
+  centre = 0.5 * (x_p + x_m) + (fabs(dx) > kPi ? kPi : 0.0);
+}
+
 __device__ __forceinline__ double expcos_draw(const RngKey &k, uint32_t site, double beta, double x_p,
                                               double x_m) {
-  const double dx = x_m - x_p;
-  // the staples are in [-pi, pi], so |dx / 2| <= pi: cos(dx/2) = cos(pi u) with u = |dx| / (2 pi) in [0, 1]
-  const double tau = 2. * beta * fabs(cospi_unit(fmin(fabs(dx) * (0.5 / kPi), 1.0)));
-  const double x = vonmises_draw(k, site, tau);
-  return mod_2pi_fast(x + 0.5 * (x_p + x_m) + (fabs(dx) > kPi ? kPi : 0.0));
+  double tau, centre;
+  expcos_params(beta, x_p, x_m, tau, centre);
+  return mod_2pi_fast(vonmises_draw(k, site, tau) + centre);
 }
 
 // rotoraction.cc:20-37 -> expsin2distribution.hh:45-58

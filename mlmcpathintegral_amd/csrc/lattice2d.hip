@@ -9,21 +9,24 @@
 // RNG makes those recomputations bit-identical.  Per sweep HBM sees ~(1 + halo overhead) reads and
 // one write of every entry -- instead of the 4-5 passes of one-kernel-per-colour -- and k fused
 // sweeps divide that by k.
+#include <stdio.h>
+#include <stdlib.h>
+
 #include "internal.hpp"
 
 namespace mlmcpi {
 
-constexpr int kSweepThreads = 256;
+
 
 // linear iteration of a workgroup over an nr x nc region without per-element division
-template <class F>
+template <int NT, class F>
 __device__ __forceinline__ void for_region(uint32_t nr, uint32_t nc, F f) {
   const uint32_t total = nr * nc;
   uint32_t idx = threadIdx.x;
   if (idx >= total) return;
   uint32_t ri = idx / nc, ci = idx - ri * nc;
-  const uint32_t dr = kSweepThreads / nc, dc = kSweepThreads - dr * nc;
-  for (; idx < total; idx += kSweepThreads) {
+  uint32_t dr = NT / nc, dc = NT - dr * nc;
+  for (; idx < total; idx += NT) {
     f(ri, ci);
     ri += dr;
     ci += dc;
@@ -38,12 +41,12 @@ __device__ __forceinline__ void for_region(uint32_t nr, uint32_t nc, F f) {
 // issued back to back before any of them is consumed, so a thread has UNR HBM requests in flight
 // instead of one (a rolled load -> wait -> ds_write loop is latency bound: ~10 dependent round
 // trips per tile).
-template <int UNR, class T, class Load, class Store>
+template <int NT, int UNR, class T, class Load, class Store>
 __device__ __forceinline__ void stage_region(uint32_t nr, uint32_t nc, Load load, Store store) {
   const uint32_t total = nr * nc;
   uint32_t idx = threadIdx.x;
   uint32_t ri = idx / nc, ci = idx - ri * nc;
-  const uint32_t dr = kSweepThreads / nc, dc = kSweepThreads - dr * nc;
+  const uint32_t dr = NT / nc, dc = NT - dr * nc;
   while (idx < total) {
     T v[UNR];
     uint32_t rr[UNR], cc[UNR];
@@ -51,7 +54,7 @@ __device__ __forceinline__ void stage_region(uint32_t nr, uint32_t nc, Load load
     for (int u = 0; u < UNR; ++u) {
       rr[u] = ri;
       cc[u] = ci;
-      if (idx + u * kSweepThreads < total) v[u] = load(ri, ci);
+      if (idx + u * NT < total) v[u] = load(ri, ci);
       ri += dr;
       ci += dc;
       if (ci >= nc) {
@@ -61,8 +64,65 @@ __device__ __forceinline__ void stage_region(uint32_t nr, uint32_t nc, Load load
     }
 #pragma unroll
     for (int u = 0; u < UNR; ++u)
-      if (idx + u * kSweepThreads < total) store(rr[u], cc[u], v[u]);
-    idx += UNR * kSweepThreads;
+      if (idx + u * NT < total) store(rr[u], cc[u], v[u]);
+    idx += UNR * NT;
+  }
+}
+
+// Heat-bath colour phase as a per-lane work queue.  Each thread owns up to S cells of the region
+// (linear index tid + 256 m).  Their conditional parameters are set up first (no divergence), then
+// every lane runs rejection attempts on its CURRENT cell and moves on to its next cell as soon as one
+// is accepted, so a wave iterates max-over-lanes(sum of attempts) times instead of
+// sum-over-cells(max-over-lanes attempts); the arccosine and the LDS write-back run once per cell
+// afterwards, again without divergence.  Which random numbers a cell consumes is fixed by
+// (site, attempt), so the result does not depend on this scheduling.
+template <int NT, int S, class Setup, class Commit>
+__device__ __forceinline__ void heatbath_region(uint32_t nr, uint32_t nc, const RngKey &key, Setup setup,
+                                                Commit commit) {
+  const uint32_t total = nr * nc;
+  for (uint32_t b0 = 0; b0 < total; b0 += S * NT) {  // uniform trip count: the vote below needs every lane
+    double kap[S], env[S], cen[S], fv[S];
+    uint32_t site[S], off[S];
+    bool neg[S];
+    int n = 0;
+#pragma unroll
+    for (int m = 0; m < S; ++m) {
+      const uint32_t idx = b0 + m * NT + threadIdx.x;
+      kap[m] = 1.0; env[m] = 1.0; cen[m] = 0.0; fv[m] = 1.0; site[m] = 0; off[m] = 0; neg[m] = false;
+      if (idx < total) {
+        const uint32_t ri = idx / nc, ci = idx - ri * nc;
+        double tau;
+        setup(ri, ci, tau, cen[m], site[m], off[m]);
+        kap[m] = vm_clamp(tau);
+        env[m] = vm_envelope(kap[m]);
+        n = m + 1;
+      }
+    }
+    int cur = 0;
+    uint32_t attempt = 0;
+    while (__ballot(cur < n) != 0ull) {
+      if (cur < n) {
+        double k_ = kap[0], r_ = env[0];
+        uint32_t s_ = site[0];
+#pragma unroll
+        for (int m = 1; m < S; ++m)
+          if (cur == m) { k_ = kap[m]; r_ = env[m]; s_ = site[m]; }
+        double f;
+        bool ng;
+        if (vm_attempt(key, s_, attempt, k_, r_, f, ng)) {
+#pragma unroll
+          for (int m = 0; m < S; ++m)
+            if (cur == m) { fv[m] = f; neg[m] = ng; }
+          ++cur;
+          attempt = 0;
+        } else {
+          ++attempt;
+        }
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < S; ++m)
+      if (m < n) commit(off[m], mod_2pi_fast(vm_angle(fv[m], neg[m]) + cen[m]));
   }
 }
 
@@ -83,8 +143,8 @@ __device__ __forceinline__ uint32_t wrap_add(uint32_t base, uint32_t off, uint32
 // six staple links lie inside the buffer is updated; the region of exact values shrinks by at most
 // two sites per side per sweep, so a halo of 2*nsweeps keeps the owned tile exact (tile origins are
 // even, which makes buffer parity equal lattice parity).
-template <bool HEAT>
-__global__ void __launch_bounds__(kSweepThreads)
+template <bool HEAT, int NT>
+__global__ void __launch_bounds__(NT)
     schwinger_sweep_kernel(uint32_t Mt, uint32_t Mx, double beta, const double2 *__restrict__ in,
                            double2 *__restrict__ out, TileGeom tg, uint32_t nsweeps, uint32_t kinds, RngKey key0) {
   extern __shared__ double lds[];
@@ -101,7 +161,7 @@ __global__ void __launch_bounds__(kSweepThreads)
   RngKey key = key0;
   key.chain += b;
 
-  stage_region<5, double2>(
+  stage_region<NT, (NT >= 1024 ? 3 : 5), double2>(
       bh, bw, [&](uint32_t r, uint32_t c) { return src[(size_t)wrap_add(sr, r, Mx) * Mt + wrap_add(sc, c, Mt)]; },
       [&](uint32_t r, uint32_t c, double2 v) {
         th0[r * bw + c] = v.x;
@@ -117,18 +177,24 @@ __global__ void __launch_bounds__(kSweepThreads)
     for (uint32_t par = 0; par < 2; ++par) {
       const uint32_t r_first = par ? 1 : 2;
       const uint32_t nr = (bh - 2 - r_first) / 2 + 1;
-      for_region(nr, bw - 1, [&](uint32_t ri, uint32_t c) {
+      if (heat) {
+        heatbath_region<NT, 5>(
+            nr, bw - 1, skey,
+            [&](uint32_t ri, uint32_t c, double &tau, double &centre, uint32_t &site, uint32_t &o) {
+              const uint32_t r = r_first + 2 * ri;
+              o = r * bw + c;
+              const double tp = mod_2pi_fast(th0[o + bw] + th1[o] - th1[o + 1]);
+              const double tm = mod_2pi_fast(th0[o - bw] + th1[o - bw + 1] - th1[o - bw]);
+              expcos_params(beta, tp, tm, tau, centre);
+              site = 2 * (wrap_add(sr, r, Mx) * Mt + wrap_add(sc, c, Mt));
+            },
+            [&](uint32_t o, double v) { th0[o] = v; });
+      } else
+      for_region<NT>(nr, bw - 1, [&](uint32_t ri, uint32_t c) {
         const uint32_t r = r_first + 2 * ri, o = r * bw + c;
         const double tp = mod_2pi_fast(th0[o + bw] + th1[o] - th1[o + 1]);
         const double tm = mod_2pi_fast(th0[o - bw] + th1[o - bw + 1] - th1[o - bw]);
-        double v;
-        if (heat) {
-          const uint32_t jj = wrap_add(sr, r, Mx), ii = wrap_add(sc, c, Mt);
-          v = expcos_draw(skey, 2 * (jj * Mt + ii), beta, tp, tm);
-        } else {
-          v = mod_2pi_fast((tp + tm) - th0[o]);
-        }
-        th0[o] = v;
+        th0[o] = mod_2pi_fast((tp + tm) - th0[o]);
       });
       __syncthreads();
     }
@@ -136,26 +202,117 @@ __global__ void __launch_bounds__(kSweepThreads)
     for (uint32_t par = 0; par < 2; ++par) {
       const uint32_t c_first = par ? 1 : 2;
       const uint32_t nc = (bw - 2 - c_first) / 2 + 1;
-      for_region(bh - 1, nc, [&](uint32_t r, uint32_t ci) {
+      if (heat) {
+        heatbath_region<NT, 5>(
+            bh - 1, nc, skey,
+            [&](uint32_t r, uint32_t ci, double &tau, double &centre, uint32_t &site, uint32_t &o) {
+              const uint32_t c = c_first + 2 * ci;
+              o = r * bw + c;
+              const double tp = mod_2pi_fast(th0[o] + th1[o + 1] - th0[o + bw]);
+              const double tm = mod_2pi_fast(th0[o + bw - 1] + th1[o - 1] - th0[o - 1]);
+              expcos_params(beta, tp, tm, tau, centre);
+              site = 2 * (wrap_add(sr, r, Mx) * Mt + wrap_add(sc, c, Mt)) + 1;
+            },
+            [&](uint32_t o, double v) { th1[o] = v; });
+      } else
+      for_region<NT>(bh - 1, nc, [&](uint32_t r, uint32_t ci) {
         const uint32_t c = c_first + 2 * ci, o = r * bw + c;
         const double tp = mod_2pi_fast(th0[o] + th1[o + 1] - th0[o + bw]);
         const double tm = mod_2pi_fast(th0[o + bw - 1] + th1[o - 1] - th0[o - 1]);
-        double v;
-        if (heat) {
-          const uint32_t jj = wrap_add(sr, r, Mx), ii = wrap_add(sc, c, Mt);
-          v = expcos_draw(skey, 2 * (jj * Mt + ii) + 1, beta, tp, tm);
-        } else {
-          v = mod_2pi_fast((tp + tm) - th1[o]);
-        }
-        th1[o] = v;
+        th1[o] = mod_2pi_fast((tp + tm) - th1[o]);
       });
       __syncthreads();
     }
   }
 
   double2 *dst = out + (size_t)b * Mt * Mx;
-  for_region(oh, ow, [&](uint32_t r, uint32_t c) {
+  for_region<NT>(oh, ow, [&](uint32_t r, uint32_t c) {
     const uint32_t o = (r + H) * bw + (c + H);
+    dst[(size_t)(j0 + r) * Mt + (i0 + c)] = make_double2(th0[o], th1[o]);
+  });
+}
+
+// ---- Schwinger overrelaxation, specialised ---------------------------------------------------------------
+// Same sweep (same colour order, same update regions, therefore bit-identical results) as
+// schwinger_sweep_kernel<false, 256>, for launches of K overrelaxation sweeps on lattices that the
+// TW x TH tiles divide.  Everything the generic kernel recomputes per update is hoisted:
+//   * tile geometry is compile time, so every neighbour is an immediate offset of one LDS address;
+//   * each thread's cells (linear index tid + 256 m) are the same in every sweep, so their LDS
+//     offsets are computed once and kept in registers (M0 + M1 VGPRs);
+//   * LDS rows are padded to an odd number of doubles and the mu = 1 phases run with lanes along
+//     rows, so column-parity phases are bank-conflict free instead of stride-2.
+// Per update that leaves the ~18 fp64 instructions of the update itself (6 adds, 3 mod_2pi).
+template <int TW, int TH, int K>
+__global__ void __launch_bounds__(256)
+    schwinger_or_kernel(uint32_t Mt, uint32_t Mx, const double2 *__restrict__ in, double2 *__restrict__ out,
+                        uint32_t tiles_x) {
+  constexpr int NT = 256, H = 2 * K, BW = TW + 2 * H, BH = TH + 2 * H, P = BW + 1;
+  constexpr int NR0 = (BH - 2) / 2, NC0 = BW - 1, T0 = NR0 * NC0, M0 = (T0 + NT - 1) / NT;
+  constexpr int NCI = (BW - 2) / 2, NR1 = BH - 1, T1 = NCI * NR1, M1 = (T1 + NT - 1) / NT;
+  extern __shared__ double lds[];
+  double *th0 = lds, *th1 = lds + BH * P;
+  const uint32_t tile = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
+  const uint32_t i0 = tx * TW, j0 = ty * TH;
+  const uint32_t sc = (uint32_t)(((uint64_t)i0 + Mt - (H % Mt)) % Mt);
+  const uint32_t sr = (uint32_t)(((uint64_t)j0 + Mx - (H % Mx)) % Mx);
+  const double2 *src = in + (size_t)b * Mt * Mx;
+
+  stage_region<NT, 5, double2>(
+      BH, BW, [&](uint32_t r, uint32_t c) { return src[(size_t)wrap_add(sr, r, Mx) * Mt + wrap_add(sc, c, Mt)]; },
+      [&](uint32_t r, uint32_t c, double2 v) {
+        th0[r * P + c] = v.x;
+        th1[r * P + c] = v.y;
+      });
+
+  // cell offsets: mu = 0, even rows (odd rows: - P); mu = 1, even columns (odd columns: - 1)
+  int o0[M0], o1[M1];
+#pragma unroll
+  for (int m = 0; m < M0; ++m) {
+    const int idx = tid + NT * m, ri = idx / NC0, c = idx - ri * NC0;
+    o0[m] = (2 + 2 * ri) * P + c;
+  }
+#pragma unroll
+  for (int m = 0; m < M1; ++m) {
+    const int idx = tid + NT * m, ci = idx / NR1, r = idx - ci * NR1;
+    o1[m] = r * P + 2 + 2 * ci;
+  }
+  __syncthreads();
+
+  for (int s = 0; s < K; ++s) {
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+#pragma unroll
+      for (int m = 0; m < M0; ++m) {
+        if ((m + 1) * NT <= T0 || (int)tid + NT * m < T0) {
+          const double *q0 = th0 + (o0[m] - par * P);
+          const double *q1 = th1 + (o0[m] - par * P);
+          const double tp = mod_2pi_fast(q0[P] + q1[0] - q1[1]);
+          const double tm = mod_2pi_fast(q0[-P] + q1[1 - P] - q1[-P]);
+          th0[o0[m] - par * P] = mod_2pi_fast((tp + tm) - q0[0]);
+        }
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+#pragma unroll
+      for (int m = 0; m < M1; ++m) {
+        if ((m + 1) * NT <= T1 || (int)tid + NT * m < T1) {
+          const double *q0 = th0 + (o1[m] - par);
+          const double *q1 = th1 + (o1[m] - par);
+          const double tp = mod_2pi_fast(q0[0] + q1[1] - q0[P]);
+          const double tm = mod_2pi_fast(q0[P - 1] + q1[-1] - q0[-1]);
+          th1[o1[m] - par] = mod_2pi_fast((tp + tm) - q1[0]);
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  double2 *dst = out + (size_t)b * Mt * Mx;
+  for_region<NT>(TH, TW, [&](uint32_t r, uint32_t c) {
+    const uint32_t o = (r + H) * P + (c + H);
     dst[(size_t)(j0 + r) * Mt + (i0 + c)] = make_double2(th0[o], th1[o]);
   });
 }
@@ -163,8 +320,8 @@ __global__ void __launch_bounds__(kSweepThreads)
 // ---- GFF sweeps --------------------------------------------------------------------------------------
 // Red/black order: (i+j) even, then odd.  gffaction.cc:33-42 (heat bath), :68-77 (overrelaxation);
 // Delta is summed in the order of the reference's neighbour table (+i, -i, +j, -j).
-template <bool HEAT>
-__global__ void __launch_bounds__(kSweepThreads)
+template <bool HEAT, int NT>
+__global__ void __launch_bounds__(NT)
     gff_sweep_kernel(uint32_t Mt, uint32_t Mx, double mu2, const double *__restrict__ in, double *__restrict__ out,
                      TileGeom tg, uint32_t nsweeps, uint32_t kinds, RngKey key0) {
   extern __shared__ double lds[];
@@ -182,7 +339,7 @@ __global__ void __launch_bounds__(kSweepThreads)
   key.chain += b;
   const double kappa = 4. + mu2, sigma = 1. / sqrt(4. + mu2);
 
-  stage_region<5, double>(
+  stage_region<NT, (NT >= 1024 ? 3 : 5), double>(
       bh, bw, [&](uint32_t r, uint32_t c) { return src[(size_t)wrap_add(sr, r, Mx) * Mt + wrap_add(sc, c, Mt)]; },
       [&](uint32_t r, uint32_t c, double v) { phi[r * bw + c] = v; });
   __syncthreads();
@@ -192,7 +349,7 @@ __global__ void __launch_bounds__(kSweepThreads)
     RngKey skey = key;
     skey.step += s;
     for (uint32_t colour = 0; colour < 2; ++colour) {
-      for_region(bh - 2, (bw - 2) / 2, [&](uint32_t ri, uint32_t ci) {
+      for_region<NT>(bh - 2, (bw - 2) / 2, [&](uint32_t ri, uint32_t ci) {
         const uint32_t r = 1 + ri;
         const uint32_t c = 1 + ((r + 1 + colour) & 1u) + 2 * ci;
         const uint32_t o = r * bw + c;
@@ -217,7 +374,7 @@ __global__ void __launch_bounds__(kSweepThreads)
   }
 
   double *dst = out + (size_t)b * Mt * Mx;
-  for_region(oh, ow, [&](uint32_t r, uint32_t c) { dst[(size_t)(j0 + r) * Mt + (i0 + c)] = phi[(r + H) * bw + (c + H)]; });
+  for_region<NT>(oh, ow, [&](uint32_t r, uint32_t c) { dst[(size_t)(j0 + r) * Mt + (i0 + c)] = phi[(r + H) * bw + (c + H)]; });
 }
 
 // ---- streaming kernels: evaluate, force, QoI ----------------------------------------------------------
@@ -389,7 +546,81 @@ static int launch_lattice_reduce(uint32_t Mt, uint32_t Mx, double mu2, const dou
   return MLMCPI_OK;
 }
 
+struct SweepGeom {
+  TileGeom tg;
+  uint32_t tiles_y, NT;
+  size_t lds_bytes;
+  bool overridden;  // MLMCPI_SWEEP_TILE given: use the generic kernels with that geometry
+};
+
+// Tile shape and workgroup size for a launch of `nsweeps` fused sweeps.  Default: 64 x 32 owned sites,
+// 256 threads (4 workgroups per CU at one sweep).  MLMCPI_SWEEP_TILE=TWxTHxNT overrides (tuning knob;
+// results never depend on it).
+static SweepGeom choose_geometry(uint32_t Mt, uint32_t Mx, uint32_t nsweeps, bool schw) {
+  uint32_t TW = 64, TH = 32, NT = 256;
+  bool overridden = false;
+  if (const char *e = getenv("MLMCPI_SWEEP_TILE")) {
+    unsigned a = 0, b = 0, c = 0;
+    if (sscanf(e, "%ux%ux%u", &a, &b, &c) == 3 && a >= 2 && b >= 2 && a % 2 == 0 && b % 2 == 0 &&
+        (c == 256 || c == 512 || c == 1024)) {
+      TW = a; TH = b; NT = c;
+      overridden = true;
+    }
+  }
+  SweepGeom g;
+  g.overridden = overridden;
+  g.tg.TW = Mt < TW ? Mt : TW;
+  g.tg.TH = Mx < TH ? Mx : TH;
+  g.tg.tiles_x = (Mt + g.tg.TW - 1) / g.tg.TW;
+  g.tiles_y = (Mx + g.tg.TH - 1) / g.tg.TH;
+  g.NT = NT;
+  g.lds_bytes = (size_t)(g.tg.TW + 4 * nsweeps) * (g.tg.TH + 4 * nsweeps) * (schw ? 16 : 8);
+  return g;
+}
+
+template <bool SCHW, bool HEAT, int NT>
+static void launch_sweep_nt(const SweepGeom &g, dim3 grid, hipStream_t st, uint32_t Mt, uint32_t Mx, double coupling,
+                            const double *src, double *dst, uint32_t n, uint32_t kinds, RngKey key) {
+  if (SCHW)
+    hipLaunchKernelGGL((schwinger_sweep_kernel<HEAT, NT>), grid, dim3(NT), g.lds_bytes, st, Mt, Mx, coupling,
+                       (const double2 *)src, (double2 *)dst, g.tg, n, kinds, key);
+  else
+    hipLaunchKernelGGL((gff_sweep_kernel<HEAT, NT>), grid, dim3(NT), g.lds_bytes, st, Mt, Mx, coupling, src, dst, g.tg, n,
+                       kinds, key);
+}
+
+template <bool SCHW, bool HEAT>
+static int launch_sweep(const SweepGeom &g, dim3 grid, hipStream_t st, uint32_t Mt, uint32_t Mx, double coupling,
+                        const double *src, double *dst, uint32_t n, uint32_t kinds, RngKey key) {
+  switch (g.NT) {
+    case 1024: launch_sweep_nt<SCHW, HEAT, 1024>(g, grid, st, Mt, Mx, coupling, src, dst, n, kinds, key); break;
+    case 512: launch_sweep_nt<SCHW, HEAT, 512>(g, grid, st, Mt, Mx, coupling, src, dst, n, kinds, key); break;
+    default: launch_sweep_nt<SCHW, HEAT, 256>(g, grid, st, Mt, Mx, coupling, src, dst, n, kinds, key);
+  }
+  MLMCPI_LAUNCH_CHECK("lattice sweep kernel");
+  return MLMCPI_OK;
+}
+
+template <bool HEAT, int NT>
+static int allow_full_lds() {
+  // tiles with deep halos may use the whole 160 KiB of LDS
+  MLMCPI_HIP_TRY(hipFuncSetAttribute((const void *)schwinger_sweep_kernel<HEAT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  MLMCPI_HIP_TRY(hipFuncSetAttribute((const void *)gff_sweep_kernel<HEAT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  return MLMCPI_OK;
+}
+
 static bool g_lds_attr_set = false;
+static int init_sweep_kernels() {
+  if (g_lds_attr_set) return MLMCPI_OK;
+  if (int rc = allow_full_lds<false, 256>()) return rc;
+  if (int rc = allow_full_lds<true, 256>()) return rc;
+  if (int rc = allow_full_lds<false, 512>()) return rc;
+  if (int rc = allow_full_lds<true, 512>()) return rc;
+  if (int rc = allow_full_lds<false, 1024>()) return rc;
+  if (int rc = allow_full_lds<true, 1024>()) return rc;
+  g_lds_attr_set = true;
+  return MLMCPI_OK;
+}
 
 }  // namespace mlmcpi
 
@@ -448,55 +679,52 @@ int mlmcpi_lattice_sweep_draw(const mlmcpi_lattice_action *act, double *d_phi, d
   MLMCPI_REQUIRE(d_phi && d_scratch && d_phi != d_scratch && B > 0, "bad arguments");
   MLMCPI_REQUIRE(act->Mt % 2 == 0 && act->Mx % 2 == 0, "multicolour sweeps need even Mt, Mx (got %u x %u)", act->Mt,
                  act->Mx);
-  if (fuse == 0) fuse = 1;
+  if (fuse == 0) fuse = 3;  // library default: best measured trade-off of halo recomputation vs HBM passes
   if (fuse > kMaxFuse) fuse = kMaxFuse;
   hipStream_t st = as_stream(stream);
   const bool schw = act->kind == MLMCPI_SCHWINGER;
-  TileGeom tg;
-  tg.TW = act->Mt < 64 ? act->Mt : 64;
-  tg.TH = act->Mx < 32 ? act->Mx : 32;
-  tg.tiles_x = (act->Mt + tg.TW - 1) / tg.TW;
-  const uint32_t tiles_y = (act->Mx + tg.TH - 1) / tg.TH;
   const uint32_t total = n_overrelax + n_heatbath;
   const size_t state_bytes = (size_t)B * act->Mt * act->Mx * (schw ? 16 : 8);
-  if (!g_lds_attr_set) {
-    // allow tiles with deep halos to use the full 160 KiB of LDS
-    const void *kernels[4] = {(const void *)schwinger_sweep_kernel<false>, (const void *)schwinger_sweep_kernel<true>,
-                              (const void *)gff_sweep_kernel<false>, (const void *)gff_sweep_kernel<true>};
-    for (const void *kf : kernels)
-      MLMCPI_HIP_TRY(hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    g_lds_attr_set = true;
-  }
+  if (int rc = init_sweep_kernels()) return rc;
   double *src = d_phi, *dst = d_scratch;
   uint32_t s = 0;
   while (s < total) {
     uint32_t n = total - s < fuse ? total - s : fuse;
-    // shrink the fused count until the tile + halo fits in LDS
-    for (;;) {
-      const size_t cells = (size_t)(tg.TW + 4 * n) * (tg.TH + 4 * n);
-      if (cells * (schw ? 16 : 8) <= 160 * 1024 || n == 1) break;
+    SweepGeom g;
+    for (;;) {  // shrink the fused count until the tile + halo fits in LDS
+      g = choose_geometry(act->Mt, act->Mx, n, schw);
+      if (g.lds_bytes <= 160 * 1024 || n == 1) break;
       --n;
     }
     uint32_t kinds = 0;
     for (uint32_t q = 0; q < n; ++q)
       if (s + q >= n_overrelax) kinds |= 1u << q;
-    const size_t lds = (size_t)(tg.TW + 4 * n) * (tg.TH + 4 * n) * (schw ? 16 : 8);
     const RngKey key = make_key(seed, chain0, sweep0 + s);
-    dim3 grid(tg.tiles_x * tiles_y, B), block(kSweepThreads);
+    dim3 grid(g.tg.tiles_x * g.tiles_y, B);
+    int rc;
+    if (schw && !kinds && !g.overridden && act->Mt % 64 == 0 && act->Mx % 32 == 0 && n <= 4) {
+      // specialised overrelaxation kernel (bit-identical to the generic one)
+      const size_t lds = (size_t)2 * (32 + 4 * n) * (64 + 4 * n + 1) * sizeof(double);
+      dim3 sgrid((act->Mt / 64) * (act->Mx / 32), B);
+      const double2 *in2 = (const double2 *)src;
+      double2 *out2 = (double2 *)dst;
+      switch (n) {
+        case 1: hipLaunchKernelGGL((schwinger_or_kernel<64, 32, 1>), sgrid, dim3(256), lds, st, act->Mt, act->Mx, in2, out2, act->Mt / 64); break;
+        case 2: hipLaunchKernelGGL((schwinger_or_kernel<64, 32, 2>), sgrid, dim3(256), lds, st, act->Mt, act->Mx, in2, out2, act->Mt / 64); break;
+        case 3: hipLaunchKernelGGL((schwinger_or_kernel<64, 32, 3>), sgrid, dim3(256), lds, st, act->Mt, act->Mx, in2, out2, act->Mt / 64); break;
+        default: hipLaunchKernelGGL((schwinger_or_kernel<64, 32, 4>), sgrid, dim3(256), lds, st, act->Mt, act->Mx, in2, out2, act->Mt / 64);
+      }
+      MLMCPI_LAUNCH_CHECK("schwinger_or_kernel");
+      rc = MLMCPI_OK;
+    } else
     // launches without a heat-bath sweep use the lean instantiation (no sampler code, fewer VGPRs)
-    if (schw && kinds)
-      hipLaunchKernelGGL(schwinger_sweep_kernel<true>, grid, block, lds, st, act->Mt, act->Mx, act->beta,
-                         (const double2 *)src, (double2 *)dst, tg, n, kinds, key);
-    else if (schw)
-      hipLaunchKernelGGL(schwinger_sweep_kernel<false>, grid, block, lds, st, act->Mt, act->Mx, act->beta,
-                         (const double2 *)src, (double2 *)dst, tg, n, kinds, key);
-    else if (kinds)
-      hipLaunchKernelGGL(gff_sweep_kernel<true>, grid, block, lds, st, act->Mt, act->Mx, gff_mu2(*act),
-                         (const double *)src, dst, tg, n, kinds, key);
+    if (schw)
+      rc = kinds ? launch_sweep<true, true>(g, grid, st, act->Mt, act->Mx, act->beta, src, dst, n, kinds, key)
+                 : launch_sweep<true, false>(g, grid, st, act->Mt, act->Mx, act->beta, src, dst, n, kinds, key);
     else
-      hipLaunchKernelGGL(gff_sweep_kernel<false>, grid, block, lds, st, act->Mt, act->Mx, gff_mu2(*act),
-                         (const double *)src, dst, tg, n, kinds, key);
-    MLMCPI_LAUNCH_CHECK("lattice sweep kernel");
+      rc = kinds ? launch_sweep<false, true>(g, grid, st, act->Mt, act->Mx, gff_mu2(*act), src, dst, n, kinds, key)
+                 : launch_sweep<false, false>(g, grid, st, act->Mt, act->Mx, gff_mu2(*act), src, dst, n, kinds, key);
+    if (rc) return rc;
     double *tmp = src; src = dst; dst = tmp;
     s += n;
   }

@@ -340,6 +340,7 @@ SWEEP_CASES = [
     ("schwinger", 16, 16, dict(beta=1.0), 3),
     ("schwinger", 6, 10, dict(beta=4.0), 2),
     ("schwinger", 64, 32, dict(beta=1.0), 2),
+    ("schwinger", 128, 64, dict(beta=1.0), 2),  # 2 x 2 tiles of the specialised overrelaxation kernel
     ("schwinger", 130, 70, dict(beta=1.0), 1),
 ]
 
@@ -417,6 +418,14 @@ def test_schwinger_1024_properties(gpu_ops, orc, golden):
     gpu_ops.lattice_sweep_draw(act, a, scratch, 4, 2, SEED, 0, 0, fuse=1)
     gpu_ops.lattice_sweep_draw(act, b1, scratch, 4, 2, SEED, 0, 0, fuse=3)
     assert torch.equal(a, b1), "fused and unfused sweeps must agree bit for bit"
+    # the specialised overrelaxation kernel (compile-time tile geometry) against the generic one
+    os.environ["MLMCPI_SWEEP_TILE"] = "64x32x256"
+    try:
+        gen = x.clone()
+        gpu_ops.lattice_sweep_draw(act, gen, scratch, 4, 2, SEED, 0, 0, fuse=2)
+    finally:
+        del os.environ["MLMCPI_SWEEP_TILE"]
+    assert torch.equal(a, gen), "specialised and generic sweep kernels must agree bit for bit"
     single = x[1:2].clone()
     gpu_ops.lattice_sweep_draw(act, single, torch.empty_like(single), 4, 2, SEED, 1, 0, fuse=2)
     assert torch.equal(single[0], a[1]), "a chain's result must not depend on the batch it runs in"
