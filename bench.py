@@ -97,7 +97,7 @@ def main():
         scratch = torch.empty_like(x)
         units_per_step = sites * (a.n_overrelax + a.n_heatbath) * B
         fuse = a.fuse or 3  # library default
-        state = {"sweep": 0}
+        state = {"sweep": 0, "x": x, "scratch": scratch}
 
         def step(record):
             s = state["sweep"]
@@ -105,10 +105,13 @@ def main():
                 e0, e1, e2 = ev(), ev(), ev()
                 e0.record()
             # same arithmetic as one call with (n_overrelax, n_heatbath); split only to time the two kernels
-            ops.lattice_sweep_draw(act, x, scratch, a.n_overrelax, 0, a.seed, chain0, s, fuse)
+            # (ping-pong form: the buffers swap roles instead of being copied back)
+            cur, oth = ops.lattice_sweep_draw_pingpong(act, state["x"], state["scratch"], a.n_overrelax, 0, a.seed,
+                                                       chain0, s, fuse)
             if record:
                 e1.record()
-            ops.lattice_sweep_draw(act, x, scratch, 0, a.n_heatbath, a.seed, chain0, s + a.n_overrelax, fuse)
+            state["x"], state["scratch"] = ops.lattice_sweep_draw_pingpong(act, cur, oth, 0, a.n_heatbath, a.seed, chain0,
+                                                                           s + a.n_overrelax, fuse)
             if record:
                 e2.record()
                 or_events.append((e0, e1))
@@ -117,8 +120,8 @@ def main():
 
         def qoi():
             if a.workload == "schwinger":
-                return ops.qoi_avg_plaquette(x, size, size)
-            return ops.qoi_phi_squared(x)
+                return ops.qoi_avg_plaquette(state["x"], size, size)
+            return ops.qoi_phi_squared(state["x"])
         bytes_per_unit = 16.0  # each entry read once and written once per sweep
     else:
         kind = abi.ROTOR if a.workload == "rotor_hmc" else abi.QUARTIC

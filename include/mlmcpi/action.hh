@@ -182,8 +182,10 @@ public:
   }
   void sweep(std::shared_ptr<SampleState> phi, std::shared_ptr<SampleState> scratch, unsigned n_or, unsigned n_hb,
              uint32_t sweep0) override {
-    check(mlmcpi_lattice_sweep_draw(&abi, phi->device_mutable(), scratch->device_mutable(), phi->batch(), n_or, n_hb,
-                                    seed, chain0, sweep0, fuse, nullptr), "lattice_sweep_draw");
+    int32_t in_scratch = 0;
+    check(mlmcpi_lattice_sweep_draw_pingpong(&abi, phi->device_mutable(), scratch->device_mutable(), phi->batch(), n_or,
+                                             n_hb, seed, chain0, sweep0, fuse, &in_scratch, nullptr), "lattice_sweep_draw");
+    if (in_scratch) phi->swap_device(*scratch);  // no copy: the buffers exchange roles
   }
   std::string info_string() const override {
     std::stringstream s;

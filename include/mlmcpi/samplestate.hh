@@ -13,6 +13,7 @@
 #include <iostream>
 #include <memory>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../mlmcpi_hip.h"
@@ -88,6 +89,14 @@ public:
     to_device();
     host_valid = false;
     return dev;
+  }
+  /** Exchange device buffers with a state of equal shape (ping-pong sweeps end in the scratch). */
+  void swap_device(SampleState &other) {
+    if (M != other.M || B != other.B) fatal("SampleState shape mismatch in swap_device");
+    to_device();
+    other.to_device();
+    std::swap(dev, other.dev);
+    host_valid = other.host_valid = false;
   }
   unsigned int size() const { return M; }
   unsigned int batch() const { return B; }

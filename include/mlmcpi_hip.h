@@ -147,6 +147,11 @@ int mlmcpi_lattice_initialise(const mlmcpi_lattice_action *act, double *d_phi, u
 int mlmcpi_lattice_sweep_draw(const mlmcpi_lattice_action *act, double *d_phi, double *d_scratch, uint32_t B,
                               uint32_t n_overrelax, uint32_t n_heatbath, uint64_t seed, uint32_t chain0,
                               uint32_t sweep0, uint32_t fuse, void *stream);
+/* Same, without the final device-to-device copy: the sweeps ping-pong between d_a (input) and d_b;
+ * *result_in_b tells the caller which buffer holds the result (swap your pointers when it is 1). */
+int mlmcpi_lattice_sweep_draw_pingpong(const mlmcpi_lattice_action *act, double *d_a, double *d_b, uint32_t B,
+                                       uint32_t n_overrelax, uint32_t n_heatbath, uint64_t seed, uint32_t chain0,
+                                       uint32_t sweep0, uint32_t fuse, int32_t *result_in_b, void *stream);
 /* QoI2DPhiSquared (qoi/qft/qoi2dphisquared.cc:8-15), QoIAvgPlaquette (qoi/qft/qoiavgplaquette.cc:8-27),
  * QoI2DSusceptibility (qoi/qft/qoi2dsusceptibility.cc:8-27); d_out[b]. */
 int mlmcpi_qoi_phi_squared(const double *d_phi, uint32_t n_vertices, uint32_t B, double *d_out, void *stream);

@@ -65,6 +65,8 @@ SIGNATURES = {
     "mlmcpi_lattice_force": (_i, [_LA, _vp, _vp, _u32, _vp]),
     "mlmcpi_lattice_initialise": (_i, [_LA, _vp, _u32, _u64, _u32, _vp]),
     "mlmcpi_lattice_sweep_draw": (_i, [_LA, _vp, _vp, _u32, _u32, _u32, _u64, _u32, _u32, _u32, _vp]),
+    "mlmcpi_lattice_sweep_draw_pingpong": (_i, [_LA, _vp, _vp, _u32, _u32, _u32, _u64, _u32, _u32, _u32,
+                                                C.POINTER(C.c_int32), _vp]),
     "mlmcpi_qoi_phi_squared": (_i, [_vp, _u32, _u32, _vp, _vp]),
     "mlmcpi_qoi_avg_plaquette": (_i, [_vp, _u32, _u32, _u32, _vp, _vp]),
     "mlmcpi_qoi_2d_susceptibility": (_i, [_vp, _u32, _u32, _u32, _vp, _vp]),

@@ -24,6 +24,30 @@ __device__ __forceinline__ double mod_2pi_fast(double x) {
   return fma(-kTwoPi, floor((x + kPi) * (1.0 / kTwoPi)), x);
 }
 
+// sin(d) for the leapfrog force of the rotor: two-term Cody-Waite reduction to |r| <= pi/2 (exact
+// enough for |d| up to ~1e6, far beyond any angle difference a stable trajectory produces) and the
+// degree-21 Taylor polynomial (truncation < 1.3e-18): ~20 fp64 instructions, against ~175 for the
+// general sin() with its Payne-Hanek path.  Absolute error ~1e-16.
+__device__ __forceinline__ double sin_reduced(double d) {
+  const double n = rint(d * 0.31830988618379067154);           // d / pi
+  double r = fma(-n, 3.14159265358979311600e+00, d);            // pi, high part
+  r = fma(-n, 1.22464679914735317723e-16, r);                   // pi - high part
+  const double r2 = r * r;
+  double p = -1.9572941063391261231e-20;                        // -1/21!
+  p = fma(p, r2, 8.2206352466243297170e-18);                    //  1/19!
+  p = fma(p, r2, -2.8114572543455207632e-15);                   // -1/17!
+  p = fma(p, r2, 7.6471637318198164759e-13);                    //  1/15!
+  p = fma(p, r2, -1.6059043836821614599e-10);                   // -1/13!
+  p = fma(p, r2, 2.5052108385441718775e-08);                    //  1/11!
+  p = fma(p, r2, -2.7557319223985890653e-06);                   // -1/9!
+  p = fma(p, r2, 1.9841269841269841270e-04);                    //  1/7!
+  p = fma(p, r2, -8.3333333333333333333e-03);                   // -1/5!
+  p = fma(p, r2, 1.6666666666666666667e-01);                    //  1/3!
+  const double sr = fma(-r * r2, p, r);                          // r - r^3 (1/3! - r^2/5! + ...)
+  // (-1)^n: n is an integer-valued double; its parity is the low bit of the converted integer
+  return ((long long)n & 1) ? -sr : sr;
+}
+
 // ---- RNG contract ------------------------------------------------------------------
 enum Purpose : uint32_t {
   P_MOMENTUM = 1,

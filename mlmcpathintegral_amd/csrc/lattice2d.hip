@@ -672,9 +672,9 @@ int mlmcpi_lattice_initialise(const mlmcpi_lattice_action *act, double *d_phi, u
   return MLMCPI_OK;
 }
 
-int mlmcpi_lattice_sweep_draw(const mlmcpi_lattice_action *act, double *d_phi, double *d_scratch, uint32_t B,
-                              uint32_t n_overrelax, uint32_t n_heatbath, uint64_t seed, uint32_t chain0,
-                              uint32_t sweep0, uint32_t fuse, void *stream) {
+static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, double *d_scratch, uint32_t B,
+                           uint32_t n_overrelax, uint32_t n_heatbath, uint64_t seed, uint32_t chain0, uint32_t sweep0,
+                           uint32_t fuse, int32_t *result_in_b, void *stream) {
   if (int rc = check_lattice(act)) return rc;
   MLMCPI_REQUIRE(d_phi && d_scratch && d_phi != d_scratch && B > 0, "bad arguments");
   MLMCPI_REQUIRE(act->Mt % 2 == 0 && act->Mx % 2 == 0, "multicolour sweeps need even Mt, Mx (got %u x %u)", act->Mt,
@@ -728,8 +728,24 @@ int mlmcpi_lattice_sweep_draw(const mlmcpi_lattice_action *act, double *d_phi, d
     double *tmp = src; src = dst; dst = tmp;
     s += n;
   }
-  if (src != d_phi) MLMCPI_HIP_TRY(hipMemcpyAsync(d_phi, src, state_bytes, hipMemcpyDeviceToDevice, st));
+  if (result_in_b)
+    *result_in_b = (src != d_phi) ? 1 : 0;
+  else if (src != d_phi)
+    MLMCPI_HIP_TRY(hipMemcpyAsync(d_phi, src, state_bytes, hipMemcpyDeviceToDevice, st));
   return MLMCPI_OK;
+}
+
+int mlmcpi_lattice_sweep_draw(const mlmcpi_lattice_action *act, double *d_phi, double *d_scratch, uint32_t B,
+                              uint32_t n_overrelax, uint32_t n_heatbath, uint64_t seed, uint32_t chain0,
+                              uint32_t sweep0, uint32_t fuse, void *stream) {
+  return sweep_draw_impl(act, d_phi, d_scratch, B, n_overrelax, n_heatbath, seed, chain0, sweep0, fuse, nullptr, stream);
+}
+
+int mlmcpi_lattice_sweep_draw_pingpong(const mlmcpi_lattice_action *act, double *d_a, double *d_b, uint32_t B,
+                                       uint32_t n_overrelax, uint32_t n_heatbath, uint64_t seed, uint32_t chain0,
+                                       uint32_t sweep0, uint32_t fuse, int32_t *result_in_b, void *stream) {
+  MLMCPI_REQUIRE(result_in_b, "result_in_b is NULL");
+  return sweep_draw_impl(act, d_a, d_b, B, n_overrelax, n_heatbath, seed, chain0, sweep0, fuse, result_in_b, stream);
 }
 
 int mlmcpi_qoi_phi_squared(const double *d_phi, uint32_t n_vertices, uint32_t B, double *d_out, void *stream) {

@@ -219,10 +219,10 @@ __global__ void __launch_bounds__(R >= 8 ? 512 : 1024)
     if (KIND == MLMCPI_ROTOR) {
       // one sine per link: d_r = sin(x_r - x_{r-1}); F_r = c1 (d_r - d_{r+1}), identical to
       // c1 (sin(x-x_m) + sin(x-x_p)) because sin is odd
-      double dprev = sin(x[0] - xl);
+      double dprev = sin_reduced(x[0] - xl);
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        const double dnext = sin((r == R - 1 ? xr : x[r + 1]) - x[r]);
+        const double dnext = sin_reduced((r == R - 1 ? xr : x[r + 1]) - x[r]);
         p[r] -= dtp * (P.c1 * (dprev - dnext));
         dprev = dnext;
         __builtin_amdgcn_sched_barrier(0);

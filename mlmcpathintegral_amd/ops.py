@@ -126,6 +126,15 @@ def lattice_sweep_draw(act, phi, scratch, n_overrelax, n_heatbath, seed, chain0,
              seed, chain0, sweep0, fuse, _stream())
 
 
+def lattice_sweep_draw_pingpong(act, a, b, n_overrelax, n_heatbath, seed, chain0, sweep0, fuse=0):
+    """Sweeps without the final copy; returns (state, scratch) -- the tensors swapped when needed."""
+    _check_state(a, lattice_size(act))
+    flag = C.c_int32(0)
+    abi.call("mlmcpi_lattice_sweep_draw_pingpong", C.byref(act), _p(a), _p(b), a.shape[0], n_overrelax, n_heatbath,
+             seed, chain0, sweep0, fuse, C.byref(flag), _stream())
+    return (b, a) if flag.value else (a, b)
+
+
 def qoi_phi_squared(phi):
     out = torch.empty(phi.shape[0], dtype=torch.float64, device=phi.device)
     abi.call("mlmcpi_qoi_phi_squared", _p(phi), phi.shape[1], phi.shape[0], _p(out), _stream())

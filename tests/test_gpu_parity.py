@@ -369,6 +369,17 @@ def test_lattice_sweeps_match_oracle(gpu_ops, orc, kind, Mt, Mx, kw, B, fuse):
             assert_close(got, xo, tol=1e-11, what=f"sweeps ({n_or},{n_hb}) fuse={fuse}")
 
 
+def test_pingpong_sweeps_equal_copy_form(gpu_ops):
+    from mlmcpathintegral_amd import abi
+    for act, n in ((abi.lattice_action(4, 64, 32, beta=1.0), 2 * 64 * 32), (abi.lattice_action(3, 32, 32, mass=5.0), 32 * 32)):
+        x = gpu_ops.lattice_initialise(act, 3, SEED)
+        for n_or, n_hb in ((1, 0), (2, 1), (3, 3), (10, 1)):
+            a, b = x.clone(), x.clone()
+            gpu_ops.lattice_sweep_draw(act, a, torch.empty_like(a), n_or, n_hb, SEED, 0, 5)
+            res, other = gpu_ops.lattice_sweep_draw_pingpong(act, b, torch.empty_like(b), n_or, n_hb, SEED, 0, 5)
+            assert torch.equal(res, a) and res.data_ptr() != other.data_ptr()
+
+
 def test_sweep_rejects_odd_lattice(gpu_ops):
     from mlmcpathintegral_amd import abi
     act = abi.lattice_action(4, 5, 4, beta=1.0)
