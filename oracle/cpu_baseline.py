@@ -29,8 +29,11 @@ def _worker(args):
         units = size * size * (n_or + n_hb)
         s = L.orc_heatbath_new(A.h, n_hb, n_or, 0, 0)
         draw = lambda x: L.orc_heatbath_draw(s, x)
-    else:  # rotor HMC, fixed dt (no auto-tune)
-        A = O.Action(O.ROTOR, M=size, T_final=size / 8.0, m0=0.25)
+    else:  # HMC, fixed dt (no auto-tune)
+        if workload == "quartic":
+            A = O.Action(O.QUARTIC, M=size, T_final=size / 8.0, m0=1.0, mu2=1.0, lam=1.0, x0=1.0)
+        else:
+            A = O.Action(O.ROTOR, M=size, T_final=size / 8.0, m0=0.25)
         units = size * (nt + 1)
         s = L.orc_hmc_new(A.h, nt, dt, 1, 0, 0, 0, 0)
         draw = lambda x: L.orc_hmc_draw(s, x)
