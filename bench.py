@@ -97,7 +97,7 @@ def main():
         x = ops.lattice_initialise(act, B, a.seed, chain0)
         scratch = torch.empty_like(x)
         units_per_step = sites * (a.n_overrelax + a.n_heatbath) * B
-        fuse = a.fuse or 3  # library default
+        fuse = a.fuse or 2  # library default
         state = {"sweep": 0, "x": x, "scratch": scratch}
 
         def step(record):

@@ -242,11 +242,11 @@ __global__ void __launch_bounds__(NT)
 //   * LDS rows are padded to an odd number of doubles and the mu = 1 phases run with lanes along
 //     rows, so column-parity phases are bank-conflict free instead of stride-2.
 // Per update that leaves the ~18 fp64 instructions of the update itself (6 adds, 3 mod_2pi).
-template <int TW, int TH, int K>
-__global__ void __launch_bounds__(256)
+template <int TW, int TH, int K, int NT>
+__global__ void __launch_bounds__(NT)
     schwinger_or_kernel(uint32_t Mt, uint32_t Mx, const double2 *__restrict__ in, double2 *__restrict__ out,
                         uint32_t tiles_x) {
-  constexpr int NT = 256, H = 2 * K, BW = TW + 2 * H, BH = TH + 2 * H, P = BW + 1;
+  constexpr int H = 2 * K, BW = TW + 2 * H, BH = TH + 2 * H, P = BW + 1;
   constexpr int NR0 = (BH - 2) / 2, NC0 = BW - 1, T0 = NR0 * NC0, M0 = (T0 + NT - 1) / NT;
   constexpr int NCI = (BW - 2) / 2, NR1 = BH - 1, T1 = NCI * NR1, M1 = (T1 + NT - 1) / NT;
   extern __shared__ double lds[];
@@ -679,7 +679,7 @@ static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, doub
   MLMCPI_REQUIRE(d_phi && d_scratch && d_phi != d_scratch && B > 0, "bad arguments");
   MLMCPI_REQUIRE(act->Mt % 2 == 0 && act->Mx % 2 == 0, "multicolour sweeps need even Mt, Mx (got %u x %u)", act->Mt,
                  act->Mx);
-  if (fuse == 0) fuse = 3;  // library default: best measured trade-off of halo recomputation vs HBM passes
+  if (fuse == 0) fuse = 2;  // library default: best measured trade-off of halo recomputation vs HBM passes
   if (fuse > kMaxFuse) fuse = kMaxFuse;
   hipStream_t st = as_stream(stream);
   const bool schw = act->kind == MLMCPI_SCHWINGER;
@@ -708,12 +708,20 @@ static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, doub
       dim3 sgrid((act->Mt / 64) * (act->Mx / 32), B);
       const double2 *in2 = (const double2 *)src;
       double2 *out2 = (double2 *)dst;
+      // more fused sweeps -> larger LDS image -> fewer resident workgroups: keep the wave count per CU up
+      // with wider workgroups (MLMCPI_OR_THREADS overrides: tuning knob)
+      uint32_t nt_or = 512;  // measured best for K = 1..4 (tools/scan_or.sh)
+      if (const char *e = getenv("MLMCPI_OR_THREADS")) { unsigned v = (unsigned)atoi(e); if (v == 256 || v == 512 || v == 1024) nt_or = v; }
+#define MLMCPI_OR(KK, NN) hipLaunchKernelGGL((schwinger_or_kernel<64, 32, KK, NN>), sgrid, dim3(NN), lds, st, act->Mt, act->Mx, in2, out2, act->Mt / 64)
+#define MLMCPI_OR_K(KK) do { if (nt_or == 1024) MLMCPI_OR(KK, 1024); else if (nt_or == 512) MLMCPI_OR(KK, 512); else MLMCPI_OR(KK, 256); } while (0)
       switch (n) {
-        case 1: hipLaunchKernelGGL((schwinger_or_kernel<64, 32, 1>), sgrid, dim3(256), lds, st, act->Mt, act->Mx, in2, out2, act->Mt / 64); break;
-        case 2: hipLaunchKernelGGL((schwinger_or_kernel<64, 32, 2>), sgrid, dim3(256), lds, st, act->Mt, act->Mx, in2, out2, act->Mt / 64); break;
-        case 3: hipLaunchKernelGGL((schwinger_or_kernel<64, 32, 3>), sgrid, dim3(256), lds, st, act->Mt, act->Mx, in2, out2, act->Mt / 64); break;
-        default: hipLaunchKernelGGL((schwinger_or_kernel<64, 32, 4>), sgrid, dim3(256), lds, st, act->Mt, act->Mx, in2, out2, act->Mt / 64);
+        case 1: MLMCPI_OR_K(1); break;
+        case 2: MLMCPI_OR_K(2); break;
+        case 3: MLMCPI_OR_K(3); break;
+        default: MLMCPI_OR_K(4);
       }
+#undef MLMCPI_OR_K
+#undef MLMCPI_OR
       MLMCPI_LAUNCH_CHECK("schwinger_or_kernel");
       rc = MLMCPI_OK;
     } else
