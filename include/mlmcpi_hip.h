@@ -126,6 +126,21 @@ int mlmcpi_path_sweep_draw(const mlmcpi_path_action *act, double *d_x, double *d
                            uint32_t n_overrelax, uint32_t n_heatbath, uint64_t seed, uint32_t chain0,
                            uint32_t sweep0, void *stream);
 
+/* TwoLevelMetropolisStep::draw (montecarlo/twolevelmetropolisstep.cc:35-89) for the harmonic / quartic
+ * oscillator with the Gaussian conditioned fine action (action/qm/gaussianconditionedfineaction.cc:7-43)
+ * and QMAction::copy_from_{coarse,fine} (action/qm/qmaction.cc:7-24):
+ *   theta'[2j] = x_coarse[j];  theta'[2j+1] ~ N(Wmin(theta'[2j], theta'[2j+2]), 1/W'')
+ *   dS = [S_f(theta') - S_f(theta)] + [S_c(theta_C) - S_c(x_coarse)] + [S_cfa(theta) - S_cfa(theta')]
+ *   accept with min(1, exp(-dS)); accepted chains get theta <- theta'.
+ * `fine` lives on M sites, `coarse` on M/2 (its parameters are the caller's: same as fine for the quartic
+ * oscillator, renormalised or not for the HO).  d_theta [B*M] is the step's current fine state
+ * (MCMCStep::set_state), d_x_coarse [B*M/2] the coarse-level proposal.  d_terms (optional, [B*3]) receives
+ * the three action differences.  Philox step = `step`. */
+int mlmcpi_path_twolevel_workspace_bytes(const mlmcpi_path_action *fine, uint32_t B, size_t *bytes);
+int mlmcpi_path_twolevel_draw(const mlmcpi_path_action *fine, const mlmcpi_path_action *coarse, const double *d_x_coarse,
+                              double *d_theta, uint32_t B, uint64_t seed, uint32_t chain0, uint32_t step, void *d_work,
+                              int32_t *d_accept, double *d_terms, void *stream);
+
 /* ---- 2-D lattices --------------------------------------------------------------------------- */
 int mlmcpi_lattice_state_size(const mlmcpi_lattice_action *act, uint32_t *n); /* Action::sample_size */
 int mlmcpi_lattice_evaluate(const mlmcpi_lattice_action *act, const double *d_phi, uint32_t B, double *d_S,

@@ -48,6 +48,66 @@ __device__ __forceinline__ double sin_reduced(double d) {
   return ((long long)n & 1) ? -sr : sr;
 }
 
+// ---- lean fp64 primitives for the heat-bath sampler ---------------------------------------------------
+// The ocml division / sqrt / acos are correctly rounded over the whole double range (19 / 31 / ~95
+// instructions).  The sampler's operands are benign (finite, far from the denormal range), so the
+// scaling, fix-up and special-case code is dead weight; these versions keep the Newton / Goldschmidt
+// cores only and stay within ~1 ulp.
+__device__ __forceinline__ double fast_rcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  double e = fma(-x, y, 1.0);
+  y = fma(y, e, y);
+  e = fma(-x, y, 1.0);
+  return fma(y, e, y);
+}
+
+__device__ __forceinline__ double fast_div(double a, double b) {
+  const double y = fast_rcp(b);
+  const double q = a * y;
+  return fma(fma(-b, q, a), y, q);
+}
+
+__device__ __forceinline__ double fast_sqrt(double x) {  // x > 0, normal
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  double r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  return fma(fma(-g, g, x), h, g);
+}
+
+// acos on [-1, 1] after fdlibm's e_acos.c (rational approximation of (asin(x) - x) / x^3 in z),
+// evaluated branch-free: z = x^2 for |x| < 1/2, z = (1 - |x|) / 2 otherwise.
+__device__ __forceinline__ double fast_acos(double x) {
+  const double ax = fabs(x);
+  const bool small = ax < 0.5;
+  const double z = small ? x * x : 0.5 * (1.0 - ax);
+  double p = 3.47933107596021167570e-05;
+  p = fma(p, z, 7.91534994289814532176e-04);
+  p = fma(p, z, -4.00555345006794114027e-02);
+  p = fma(p, z, 2.01212532134862925881e-01);
+  p = fma(p, z, -3.25565818622400915405e-01);
+  p = fma(p, z, 1.66666666666666657415e-01);
+  p *= z;
+  double q = 7.70381505559019352791e-02;
+  q = fma(q, z, -6.88283971605453293030e-01);
+  q = fma(q, z, 2.02094576023350569471e+00);
+  q = fma(q, z, -2.40339491173441421878e+00);
+  q = fma(q, z, 1.0);
+  const double R = fast_div(p, q);
+  const double pio2_hi = 1.57079632679489655800e+00, pio2_lo = 6.12323399573676603587e-17;
+  // |x| < 1/2: pi/2 - (x + x R)
+  const double r_small = pio2_hi - (x - (pio2_lo - x * R));
+  // |x| >= 1/2: 2 (s + s R) for x > 0, pi - 2 (s + s R) for x < 0, s = sqrt(z)
+  const double s = (z > 0.0) ? fast_sqrt(z) : 0.0;
+  const double t = fma(s, R, s);
+  const double r_large = (x > 0.0) ? 2.0 * t : 2.0 * (pio2_hi - (t - pio2_lo));
+  return small ? r_small : r_large;
+}
+
 // ---- RNG contract ------------------------------------------------------------------
 enum Purpose : uint32_t {
   P_MOMENTUM = 1,
@@ -55,6 +115,8 @@ enum Purpose : uint32_t {
   P_GFF_NORMAL = 3,
   P_VONMISES = 4,
   P_INIT = 6,
+  P_FILLIN = 7,   // two-level step: Gaussian fill-in of the fine-only sites
+  P_ACCEPT2 = 8,  // two-level step: Metropolis uniform
 };
 
 struct RngKey {
@@ -160,11 +222,11 @@ __device__ __forceinline__ double vm_clamp(double kappa) {
 }
 
 __device__ __forceinline__ double vm_envelope(double kappa) {  // kappa already clamped
-  const double s = sqrt(1. + 4. * kappa * kappa);
+  const double s = fast_sqrt(1. + 4. * kappa * kappa);
   const double a = 1. + s;
-  const double w = a + sqrt(2. * a);
+  const double w = a + fast_sqrt(2. * a);
   // r = (1 + b^2) / (2 b) with b = (a - sqrt(2a)) / (2 kappa) = 2 kappa / w, in one division
-  return (w * w + 4. * kappa * kappa) / (4. * kappa * w);
+  return fast_div(w * w + 4. * kappa * kappa, 4. * kappa * w);
 }
 
 constexpr uint32_t kMaxVmAttempts = 1024u;
@@ -176,7 +238,7 @@ __device__ __forceinline__ bool vm_attempt(const RngKey &k, uint32_t site, uint3
   const double u1 = u01(q.x, q.y), u2 = u01(q.z, q.w);
   negative = (q.x & 1u) != 0;  // bit 0 does not enter u1 (u01 drops the low 11 bits)
   const double z = cospi_unit(u1);
-  f = (1. + r * z) / (r + z);
+  f = fast_div(1. + r * z, r + z);
   const double c = kappa * (r - f);
   if (c * (2. - c) - u2 > 0.) return true;
   // Exact test: log(c / u2) + 1 - c >= 0.  Squeeze in fp32 (hardware log) with a guard band that
@@ -191,7 +253,7 @@ __device__ __forceinline__ bool vm_attempt(const RngKey &k, uint32_t site, uint3
 }
 
 __device__ __forceinline__ double vm_angle(double f, bool negative) {
-  const double theta = acos(fmin(1.0, fmax(-1.0, f)));
+  const double theta = fast_acos(fmin(1.0, fmax(-1.0, f)));
   return negative ? -theta : theta;
 }
 

@@ -76,17 +76,19 @@ __device__ __forceinline__ double site_force(const PathP &P, double xl, double x
 enum ReduceOp { R_ENERGY = 0, R_XSQUARED = 1, R_WINDING = 2 };
 
 // grid (nsplit, B); partial[b*nsplit + s] = sum over the split's sites of the site term
+// `stride` > 1 evaluates on every stride-th entry of a longer path (the coarse points of a fine path,
+// action/qm/qmaction.cc:16-24, without materialising the copy)
 template <int KIND, int OP>
 __global__ void __launch_bounds__(256) path_reduce_kernel(PathP P, const double *__restrict__ x,
-                                                          double *__restrict__ partial) {
+                                                          double *__restrict__ partial, uint32_t stride) {
   __shared__ double red[4];
   const uint32_t b = blockIdx.y, M = P.M;
-  const double *xb = x + (size_t)b * M;
+  const double *xb = x + (size_t)b * M * stride;
   const uint32_t per = (M + gridDim.x - 1) / gridDim.x;
   const uint32_t lo = blockIdx.x * per, hi = min(M, lo + per);
   double acc[1] = {0.0};
   for (uint32_t j = lo + threadIdx.x; j < hi; j += blockDim.x) {
-    const double xj = xb[j], xl = xb[j == 0 ? M - 1 : j - 1];
+    const double xj = xb[(size_t)j * stride], xl = xb[(size_t)(j == 0 ? M - 1 : j - 1) * stride];
     if (OP == R_ENERGY) acc[0] += site_energy<KIND>(P, xj, xl);
     if (OP == R_XSQUARED) acc[0] += xj * xj;
     if (OP == R_WINDING) acc[0] += mod_2pi(xj - xl);
@@ -352,6 +354,106 @@ __global__ void __launch_bounds__(256)
   for (uint32_t k = threadIdx.x; k < olen; k += blockDim.x) xout[o0 + k] = buf[halo + k];
 }
 
+// ---- two-level Metropolis step (montecarlo/twolevelmetropolisstep.cc:35-89) ----------------------------------
+// Conditioned-action quantities of the Gaussian fill-in (action/qm/gaussianconditionedfineaction.cc:7-43):
+// HO  harmonicoscillatoraction.hh:163-189: W'' = 2 m0/a + a m0 mu2, x0 = (x- + x+) / (2 + a^2 mu2)
+// quartic quarticoscillatoraction.hh:160-194: W'' = (2/a + a mu2) m0 + 3 lambda a (xbar - x0)^2, x0 by 4 fixed-point steps
+template <int KIND>
+__device__ __forceinline__ void w_conditioned(const PathP &P, double x_m, double x_p, double &w_min, double &w_curv) {
+  if (KIND == MLMCPI_HARMONIC) {
+    w_curv = (2. / P.a + P.a * P.mu2) * P.m0;
+    w_min = (0.5 / (1. + 0.5 * P.a * P.a * P.mu2)) * (x_m + x_p);
+  } else {
+    const double xbar = 0.5 * (x_m + x_p);
+    const double rho = 1. / (1. + 0.5 * P.a * P.a * P.mu2);
+    double x = xbar;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const double sh = x - P.x0;
+      x = rho * (xbar - 0.5 * P.a * P.a * P.lambda / P.m0 * sh * sh * sh);
+    }
+    w_min = x;
+    w_curv = (2. / P.a + P.a * P.mu2) * P.m0 + 3. * P.lambda * P.a * (xbar - P.x0) * (xbar - P.x0);
+  }
+}
+
+// Builds the trial state theta' (even sites = coarse proposal, odd sites = Gaussian fill-in with Philox
+// normals, site = fine index) and accumulates the conditioned fine action of theta' and of the current
+// fine state theta.  Grid (nblk, B); partial[(b*nblk + blk)*2 + {0,1}] = {S_cfa(theta'), S_cfa(theta)}.
+template <int KIND>
+__global__ void __launch_bounds__(256)
+    twolevel_propose_kernel(PathP Pf, const double *__restrict__ x_coarse, const double *__restrict__ theta,
+                            double *__restrict__ theta_prime, double *__restrict__ partial, RngKey key0) {
+  __shared__ double red[8];
+  const uint32_t b = blockIdx.y, M = Pf.M, Mc = M / 2;
+  const double *xc = x_coarse + (size_t)b * Mc, *th = theta + (size_t)b * M;
+  double *tp = theta_prime + (size_t)b * M;
+  RngKey key = key0;
+  key.chain += b;
+  const uint32_t per = (Mc + gridDim.x - 1) / gridDim.x;
+  const uint32_t lo = blockIdx.x * per, hi = min(Mc, lo + per);
+  double acc[2] = {0.0, 0.0};
+  for (uint32_t j = lo + threadIdx.x; j < hi; j += blockDim.x) {
+    const uint32_t jn = (j + 1 == Mc) ? 0 : j + 1;
+    const double x_m = xc[j], x_p = xc[jn];
+    double w_min, w_curv;
+    w_conditioned<KIND>(Pf, x_m, x_p, w_min, w_curv);
+    const double sigma = 1. / sqrt(w_curv);
+    const double fill = w_min + rng_normal0(key, 2 * j + 1, P_FILLIN, 0) * sigma;
+    tp[2 * j] = x_m;
+    tp[2 * j + 1] = fill;
+    const double dxp = fill - w_min;
+    acc[0] += 0.5 * w_curv * dxp * dxp - 0.5 * log(w_curv);
+    const double t_m = th[2 * j], t_p = th[2 * jn];
+    w_conditioned<KIND>(Pf, t_m, t_p, w_min, w_curv);
+    const double dx = th[2 * j + 1] - w_min;
+    acc[1] += 0.5 * w_curv * dx * dx - 0.5 * log(w_curv);
+  }
+  block_sum<2>(acc, red);
+  if (threadIdx.x == 0) {
+    partial[((size_t)b * gridDim.x + blockIdx.x) * 2 + 0] = acc[0];
+    partial[((size_t)b * gridDim.x + blockIdx.x) * 2 + 1] = acc[1];
+  }
+}
+
+// en6 = [6][B]: S_f(theta'), S_f(theta), S_c(theta_C), S_c(x_c), then the CFA partials are summed here.
+// deltaS = (S_f' - S_f) + (S_c(theta_C) - S_c(x_c)) + (S_cfa(theta) - S_cfa(theta'))   (twolevelmetropolisstep.cc:46-68)
+__global__ void __launch_bounds__(256)
+    twolevel_accept_kernel(uint32_t M, double *__restrict__ theta, const double *__restrict__ theta_prime,
+                           const double *__restrict__ en4, const double *__restrict__ cfa_partial, uint32_t nblk,
+                           uint32_t B, int32_t *__restrict__ accept, double *__restrict__ terms, RngKey key0) {
+  const uint32_t b = blockIdx.y;
+  double cfa_p = 0.0, cfa_c = 0.0;
+  for (uint32_t k = 0; k < nblk; ++k) {
+    cfa_p += cfa_partial[((size_t)b * nblk + k) * 2 + 0];
+    cfa_c += cfa_partial[((size_t)b * nblk + k) * 2 + 1];
+  }
+  const double dS_fine = en4[b] - en4[B + b];
+  const double dS_coarse = en4[2 * B + b] - en4[3 * B + b];
+  const double dS_trial = cfa_c - cfa_p;
+  const double dS = dS_fine + dS_coarse + dS_trial;
+  bool acc;
+  if (dS < 0.0) {
+    acc = true;
+  } else {
+    RngKey key = key0;
+    key.chain += b;
+    double u, v;
+    rng_uniforms(key, 0, P_ACCEPT2, 0, u, v);
+    acc = u < exp(-dS);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    accept[b] = acc ? 1 : 0;
+    if (terms) {
+      terms[3 * b + 0] = dS_fine; terms[3 * b + 1] = dS_coarse; terms[3 * b + 2] = dS_trial;
+    }
+  }
+  if (!acc) return;
+  double *dst = theta + (size_t)b * M;
+  const double *src = theta_prime + (size_t)b * M;
+  for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < M; j += gridDim.x * blockDim.x) dst[j] = src[j];
+}
+
 // ---- host dispatch ---------------------------------------------------------------------------------------
 static int check_action(const mlmcpi_path_action *act) {
   if (!act) return fail(MLMCPI_ERR_INVALID, "action is NULL");
@@ -370,7 +472,8 @@ static uint32_t choose_split(uint32_t sites, uint32_t B) {
 }
 
 template <int OP>
-static int launch_reduce(const PathP &P, const double *d_x, uint32_t B, double scale, double *d_out, hipStream_t st) {
+static int launch_reduce(const PathP &P, const double *d_x, uint32_t B, double scale, double *d_out, hipStream_t st,
+                         uint32_t stride = 1) {
   const uint32_t nsplit = choose_split(P.M, B);
   void *ws = nullptr;
   int rc = scratch((size_t)B * nsplit * sizeof(double), &ws);
@@ -378,13 +481,13 @@ static int launch_reduce(const PathP &P, const double *d_x, uint32_t B, double s
   dim3 grid(nsplit, B), block(256);
   switch (P.kind) {
     case MLMCPI_HARMONIC:
-      hipLaunchKernelGGL((path_reduce_kernel<MLMCPI_HARMONIC, OP>), grid, block, 0, st, P, d_x, (double *)ws);
+      hipLaunchKernelGGL((path_reduce_kernel<MLMCPI_HARMONIC, OP>), grid, block, 0, st, P, d_x, (double *)ws, stride);
       break;
     case MLMCPI_QUARTIC:
-      hipLaunchKernelGGL((path_reduce_kernel<MLMCPI_QUARTIC, OP>), grid, block, 0, st, P, d_x, (double *)ws);
+      hipLaunchKernelGGL((path_reduce_kernel<MLMCPI_QUARTIC, OP>), grid, block, 0, st, P, d_x, (double *)ws, stride);
       break;
     default:
-      hipLaunchKernelGGL((path_reduce_kernel<MLMCPI_ROTOR, OP>), grid, block, 0, st, P, d_x, (double *)ws);
+      hipLaunchKernelGGL((path_reduce_kernel<MLMCPI_ROTOR, OP>), grid, block, 0, st, P, d_x, (double *)ws, stride);
   }
   MLMCPI_LAUNCH_CHECK("path_reduce_kernel");
   hipLaunchKernelGGL(path_finish_kernel, dim3((B + 255) / 256), dim3(256), 0, st, (const double *)ws, nsplit, B, OP,
@@ -594,6 +697,54 @@ int mlmcpi_path_sweep_draw(const mlmcpi_path_action *act, double *d_x, double *d
     s += n;
   }
   if (src != d_x) MLMCPI_HIP_TRY(hipMemcpyAsync(d_x, src, (size_t)B * P.M * 8, hipMemcpyDeviceToDevice, st));
+  return MLMCPI_OK;
+}
+
+// workspace: theta' [B*M] | energies [4][B] | CFA partials [B*nblk*2]
+static uint32_t twolevel_blocks(uint32_t M, uint32_t B) { return choose_split(M / 2, B); }
+
+int mlmcpi_path_twolevel_workspace_bytes(const mlmcpi_path_action *fine, uint32_t B, size_t *bytes) {
+  if (int rc = check_action(fine)) return rc;
+  MLMCPI_REQUIRE(bytes && B > 0, "bad arguments");
+  *bytes = align256((size_t)B * fine->M * 8) + align256((size_t)4 * B * 8) +
+           align256((size_t)B * twolevel_blocks(fine->M, B) * 2 * 8);
+  return MLMCPI_OK;
+}
+
+int mlmcpi_path_twolevel_draw(const mlmcpi_path_action *fine, const mlmcpi_path_action *coarse, const double *d_x_coarse,
+                              double *d_theta, uint32_t B, uint64_t seed, uint32_t chain0, uint32_t step, void *d_work,
+                              int32_t *d_accept, double *d_terms, void *stream) {
+  if (int rc = check_action(fine)) return rc;
+  if (int rc = check_action(coarse)) return rc;
+  MLMCPI_REQUIRE(d_x_coarse && d_theta && d_work && d_accept && B > 0, "bad arguments");
+  MLMCPI_REQUIRE(fine->M % 2 == 0 && coarse->M == fine->M / 2 && coarse->kind == fine->kind,
+                 "coarse action must live on the lattice with half the sites (M %u vs %u)", coarse->M, fine->M);
+  // conditionedfineaction.hh: the Gaussian fill-in exists for the harmonic and quartic oscillators
+  if (fine->kind == MLMCPI_ROTOR)
+    return fail(MLMCPI_ERR_UNSUPPORTED, "Gaussian conditioned fine action not defined for the rotor action");
+  hipStream_t st = as_stream(stream);
+  const PathP Pf = make_params(*fine), Pc = make_params(*coarse);
+  const uint32_t nblk = twolevel_blocks(Pf.M, B);
+  char *w = (char *)d_work;
+  double *theta_prime = (double *)w;
+  w += align256((size_t)B * Pf.M * 8);
+  double *en4 = (double *)w;
+  w += align256((size_t)4 * B * 8);
+  double *cfa = (double *)w;
+  const RngKey key = make_key(seed, chain0, step);
+  dim3 grid(nblk, B), block(256);
+  if (Pf.kind == MLMCPI_HARMONIC)
+    hipLaunchKernelGGL(twolevel_propose_kernel<MLMCPI_HARMONIC>, grid, block, 0, st, Pf, d_x_coarse, (const double *)d_theta, theta_prime, cfa, key);
+  else
+    hipLaunchKernelGGL(twolevel_propose_kernel<MLMCPI_QUARTIC>, grid, block, 0, st, Pf, d_x_coarse, (const double *)d_theta, theta_prime, cfa, key);
+  MLMCPI_LAUNCH_CHECK("twolevel_propose_kernel");
+  if (int rc = launch_reduce<R_ENERGY>(Pf, theta_prime, B, energy_scale(Pf), en4, st)) return rc;
+  if (int rc = launch_reduce<R_ENERGY>(Pf, d_theta, B, energy_scale(Pf), en4 + B, st)) return rc;
+  if (int rc = launch_reduce<R_ENERGY>(Pc, d_theta, B, energy_scale(Pc), en4 + 2 * (size_t)B, st, 2)) return rc;
+  if (int rc = launch_reduce<R_ENERGY>(Pc, d_x_coarse, B, energy_scale(Pc), en4 + 3 * (size_t)B, st)) return rc;
+  hipLaunchKernelGGL(twolevel_accept_kernel, dim3(choose_split(Pf.M, B), B), block, 0, st, Pf.M, d_theta,
+                     (const double *)theta_prime, (const double *)en4, (const double *)cfa, nblk, B, d_accept, d_terms, key);
+  MLMCPI_LAUNCH_CHECK("twolevel_accept_kernel");
   return MLMCPI_OK;
 }
 

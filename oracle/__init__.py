@@ -76,6 +76,7 @@ _SIGS = {
     "orc_dev_sweep": (None, [_vp, _dp, _i, _u64, _u32, _u32]),
     "orc_dev_hmc_trajectory": (_i, [_vp, _dp, _u32, _d, _u64, _u32, _u32, _dp, _dp]),
     "orc_dev_initialise": (None, [_vp, _dp, _u64, _u32]),
+    "orc_dev_twolevel_draw": (_i, [_vp, _vp, _dp, _dp, _u64, _u32, _u32, _dp]),
     "orc_stats_new": (_vp, [_u32]),
     "orc_stats_free": (None, [_vp]),
     "orc_stats_record": (None, [_vp, _dp, _u32]),
@@ -149,6 +150,12 @@ class Action:
         dH = np.zeros(1)
         acc = lib().orc_dev_hmc_trajectory(self.h, x, nt, dt, seed, chain, step, en, dH)
         return acc, en, dH[0]
+
+    def dev_twolevel_draw(self, coarse, x_coarse, theta, seed, chain, step):
+        """self = fine action; returns (accept, [dS_fine, dS_coarse, dS_trial]); theta updated in place."""
+        terms = np.zeros(3)
+        acc = lib().orc_dev_twolevel_draw(self.h, coarse.h, np.ascontiguousarray(x_coarse), theta, seed, chain, step, terms)
+        return acc, terms
 
     def dev_initialise(self, seed, chain):
         x = np.zeros(self.size)

@@ -70,6 +70,8 @@ enum Purpose : uint32_t {
   P_GFF_NORMAL = 3,  // GFF heat bath, one call per vertex pair (l>>1), branch l&1
   P_VONMISES = 4,    // heat-bath angle draws (Schwinger, rotor): one call per attempt, sub = attempt
   P_INIT = 6,        // initial states: one uniform per entry
+  P_FILLIN = 7,      // two-level step: Gaussian fill-in of fine-only sites (site = fine index)
+  P_ACCEPT2 = 8,     // two-level step: Metropolis uniform
 };
 
 inline double u01(uint32_t lo, uint32_t hi) {
@@ -393,6 +395,7 @@ struct ActionO {
   // action/qm/rotoraction.hh:195-213, action/qm/quarticoscillatoraction.hh:160-194
   double w_minimum(double xm, double xp) const {
     if (kind == ROTOR) return std::atan2(std::sin(xp) + std::sin(xm), std::cos(xp) + std::cos(xm));
+    if (kind == HARMONIC) return (0.5 / (1. + 0.5 * a * a * mu2)) * (xm + xp);  // harmonicoscillatoraction.hh:98,187-189
     if (kind == QUARTIC) {
       double xbar = 0.5 * (xm + xp), rho = 1. / (1. + 0.5 * a * a * mu2), x = xbar;
       for (int it = 0; it < 4; ++it) {
@@ -405,6 +408,7 @@ struct ActionO {
   }
   double w_curvature(double xm, double xp) const {
     if (kind == ROTOR) return 2.0 * m0 / a * std::fabs(std::cos(0.5 * (xp - xm)));
+    if (kind == HARMONIC) return (2. / a + a * mu2) * m0;  // harmonicoscillatoraction.hh:97,171-174
     if (kind == QUARTIC) {
       double x = 0.5 * (xm + xp);
       return (2. / a + a * mu2) * m0 + 3. * lambda * a * (x - x0) * (x - x0);
@@ -583,6 +587,55 @@ int dev_hmc_trajectory(const ActionO &A, double *x, unsigned nt, double dt, cons
     acc = u < std::exp(-dH);
   }
   if (acc) std::copy(xt.begin(), xt.end(), x);
+  return acc ? 1 : 0;
+}
+
+// Two-level Metropolis step, device order.  montecarlo/twolevelmetropolisstep.cc:35-89 with
+// action/qm/gaussianconditionedfineaction.cc:7-43 and action/qm/qmaction.cc:7-24.
+// theta (fine, current state of the step) is updated in place on acceptance; terms = the three action
+// differences (fine, coarse, trial).
+double cfa_gaussian(const ActionO &F, const double *x) {  // gaussianconditionedfineaction.cc:27-43, same order
+  unsigned M = F.M;
+  double xm = x[M - 2], xp = x[0];
+  double dx = x[M - 1] - F.w_minimum(xm, xp);
+  double curv = F.w_curvature(xm, xp);
+  double S = 0.5 * curv * dx * dx - 0.5 * std::log(curv);
+  for (unsigned j = 0; j < M / 2 - 1; ++j) {
+    xm = x[2 * j]; xp = x[2 * j + 2];
+    double d = x[2 * j + 1] - F.w_minimum(xm, xp);
+    double c = F.w_curvature(xm, xp);
+    S += 0.5 * c * d * d - 0.5 * std::log(c);
+  }
+  return S;
+}
+
+int dev_twolevel_draw(const ActionO &F, const ActionO &Cc, const double *x_coarse, double *theta, const DevRng &rng,
+                      double *terms) {
+  unsigned M = F.M, Mc = M / 2;
+  std::vector<double> tp(M), thetaC(Mc);
+  for (unsigned j = 0; j < Mc; ++j) tp[2 * j] = x_coarse[j];  // copy_from_coarse
+  for (unsigned j = 0; j < Mc; ++j) {                         // fill_fine_points
+    double xm = tp[2 * j], xp = tp[(2 * j + 2) % M];
+    double x0 = F.w_minimum(xm, xp), sigma = 1. / std::sqrt(F.w_curvature(xm, xp));
+    double n0, n1;
+    rng.normals(2 * j + 1, P_FILLIN, 0, n0, n1);
+    tp[2 * j + 1] = x0 + n0 * sigma;
+  }
+  double dS_fine = F.evaluate(tp.data()) - F.evaluate(theta);
+  for (unsigned j = 0; j < Mc; ++j) thetaC[j] = theta[2 * j];  // copy_from_fine
+  double dS_coarse = Cc.evaluate(thetaC.data()) - Cc.evaluate(x_coarse);
+  double dS_trial = cfa_gaussian(F, theta) - cfa_gaussian(F, tp.data());
+  double dS = dS_fine + dS_coarse + dS_trial;
+  if (terms) { terms[0] = dS_fine; terms[1] = dS_coarse; terms[2] = dS_trial; }
+  bool acc;
+  if (dS < 0.0) {
+    acc = true;
+  } else {
+    double u, v;
+    rng.uniforms(0, P_ACCEPT2, 0, u, v);
+    acc = u < std::exp(-dS);
+  }
+  if (acc) std::copy(tp.begin(), tp.end(), theta);
   return acc ? 1 : 0;
 }
 
@@ -942,6 +995,12 @@ void orc_dev_initialise(void *action, double *x, uint64_t seed, uint32_t chain) 
       x[l] = 0.0;
     }
   }
+}
+
+int orc_dev_twolevel_draw(void *fine, void *coarse, const double *x_coarse, double *theta, uint64_t seed,
+                          uint32_t chain, uint32_t step, double *terms) {
+  DevRng r{(uint32_t)seed, (uint32_t)(seed >> 32), chain, step};
+  return dev_twolevel_draw(*(ActionO *)fine, *(ActionO *)coarse, x_coarse, theta, r, terms);
 }
 
 // ---- statistics ------------------------------------------------------------------------------------

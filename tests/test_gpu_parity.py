@@ -242,6 +242,46 @@ def test_hmc_n_rep_short_circuit(gpu_ops, orc):
     assert seen == {0, 1}, "test should exercise both outcomes"
 
 
+@pytest.mark.parametrize("name,M,B", [("harmonic", 64, 3), ("quartic", 64, 3), ("quartic", 1000, 2), ("quartic", 32768, 2)])
+def test_twolevel_step_matches_oracle(gpu_ops, orc, name, M, B):
+    """TwoLevelMetropolisStep::draw with the Gaussian fill-in: trial state, the three action differences,
+    accept flags and the updated fine state against the oracle's device-order restatement."""
+    p = dict(M=M, T_final=M / 8.0, m0=1.0, mu2=1.0)
+    if name == "quartic":
+        p.update(lam=1.0, x0=1.0)
+    pc = dict(p, M=M // 2)
+    fine, F = make_path(orc, name, p)
+    coarse, Cc = make_path(orc, name, pc)
+    rng = np.random.default_rng(M)
+    step = gpu_ops.PathTwoLevelStep(fine, coarse, B, seed=SEED, chain0=9)
+    theta0 = rng.normal(0.5, 0.6, (B, M))
+    step.set_state(dev(theta0))
+    theta = theta0.copy()
+    seen = set()
+    for t in range(6):
+        # coarse proposals: smooth paths near / far from the current fine state -> both outcomes occur
+        xc = theta[:, ::2] * (1.0 if t % 2 else 0.6) + rng.normal(0, 0.05 if t % 2 else 0.3, (B, M // 2))
+        acc = step.draw(dev(xc)).cpu().numpy()
+        terms = step.terms.cpu().numpy()
+        for b in range(B):
+            a, want = F.dev_twolevel_draw(Cc, xc[b], theta[b], SEED, 9 + b, t)
+            assert_close(terms[b], want, tol=1e-10, scale=max(1.0, float(np.max(np.abs(want)))), what=f"action differences t={t} b={b}")
+            assert acc[b] == a, (t, b, want)
+            seen.add(int(a))
+        assert_close(step.theta.cpu().numpy(), theta, tol=1e-12, what=f"fine state after draw {t}")
+    assert seen == {0, 1}
+
+
+def test_twolevel_step_errors(gpu_ops):
+    from mlmcpathintegral_amd import abi
+    with pytest.raises(abi.MlmcpiError, match="not defined for the rotor"):
+        gpu_ops.PathTwoLevelStep(abi.path_action(2, 64, 8.0, 0.25), abi.path_action(2, 32, 8.0, 0.25), 1).draw(
+            torch.zeros((1, 32), dtype=torch.float64, device="cuda"))
+    with pytest.raises(abi.MlmcpiError, match="half the sites"):
+        gpu_ops.PathTwoLevelStep(abi.path_action(1, 64, 8.0), abi.path_action(1, 16, 8.0), 1).draw(
+            torch.zeros((1, 16), dtype=torch.float64, device="cuda"))
+
+
 @pytest.mark.parametrize("M,B", [(16, 2), (128, 3), (4096, 2), (10000, 2)])
 def test_rotor_sweeps_match_oracle(gpu_ops, orc, M, B):
     act, A = make_path(orc, "rotor", dict(M=M, T_final=M / 8.0, m0=0.25))
