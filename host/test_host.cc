@@ -6,7 +6,7 @@
 #include <cstdio>
 #include <cstring>
 
-#include "mlmcpi/montecarlo.hh"
+#include "mlmcpi/multilevel.hh"
 
 using namespace mlmcpi;
 
@@ -137,6 +137,38 @@ int main(int argc, char **argv) {
     auto st = mc.get_statistics();
     std::printf(" plaquette %.6f +- %.6f (I1/I0 = 0.446390)\n", st->average(), st->error());
     EXPECT(std::fabs(st->average() - 0.446390) < 5 * st->error(), "plaquette");
+  }
+  // ---- multilevel Monte Carlo (BASELINE config 5 shape, small): HO M_lat = 64, 3 levels, hierarchical
+  //      sampler with HMC on its coarsest level, Gaussian fill-in -------------------------------------------------
+  {
+    auto lat = std::make_shared<Lattice1D>(64, 4.0);
+    auto act = std::make_shared<HarmonicOscillatorAction>(lat, RenormalisationNone, 1.0, 1.0);
+    HMCParameters hp;
+    hp.nt = 20; hp.dt = 0.15; hp.n_burnin = 50; hp.tune_iterations = 12; hp.tune_samples = 300;
+    HierarchicalParameters hier;
+    hier.n_max_level = 3; hier.n_meas = 50;
+    auto cfa = std::make_shared<GaussianConditionedFineActionFactory>();
+    auto hfac = std::make_shared<HierarchicalSamplerFactory>(std::make_shared<HMCSamplerFactory>(hp), cfa, hier);
+    // single-level reference point through the hierarchical sampler itself
+    {
+      SingleLevelMCParameters mp;
+      mp.n_burnin = 300; mp.n_samples = 6000;
+      MonteCarloSingleLevel mc(act, std::make_shared<QoIXsquared>(lat), hfac, mp);
+      mc.evaluate();
+      auto st = mc.get_statistics();
+      std::printf(" hierarchical sampler, single level: <x^2> = %.6f +- %.6f (analytic %.6f), p_accept %.3f\n", st->average(),
+                  st->error(), act->Xsquared_analytical(), mc.get_sampler()->p_accept());
+      EXPECT(std::fabs(st->average() - act->Xsquared_analytical()) < 5 * st->error(), "hierarchical sampler <x^2>");
+    }
+    MultiLevelMCParameters mlp;
+    mlp.n_level = 3; mlp.n_burnin = 100; mlp.epsilon = 8e-3; mlp.n_min_samples_qoi = 200; mlp.n_meas = 50;
+    MonteCarloMultiLevel mlmc(act, std::make_shared<QoIXsquaredFactory>(), hfac, cfa, mlp);
+    mlmc.evaluate();
+    mlmc.show_statistics();
+    const double exact = act->Xsquared_analytical();
+    std::printf(" MLMC <x^2> = %.6f +- %.6f (analytic %.6f)\n", mlmc.numerical_result(), mlmc.statistical_error(), exact);
+    EXPECT(std::fabs(mlmc.numerical_result() - exact) < 5 * mlmc.statistical_error(), "MLMC estimate");
+    EXPECT(mlmc.level_statistics(0)->variance() < mlmc.level_statistics(2)->variance(), "variance decays towards fine levels");
   }
   std::printf(failures ? "%d FAILURES\n" : "host layer: all checks passed\n", failures);
   return failures ? 1 : 0;

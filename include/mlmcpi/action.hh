@@ -13,7 +13,8 @@
 
 namespace mlmcpi {
 
-enum RenormalisationType { RenormalisationNone = 0, RenormalisationPerturbative = 1, RenormalisationExact = 2 };
+/** action/renormalisation.hh:17-21 */
+enum RenormalisationType { RenormalisationNone = 0, RenormalisationPerturbative = 1, RenormalisationNonperturbative = 2 };
 
 class Action {
 public:
@@ -117,8 +118,17 @@ public:
     return 1. / (2. * m0 * std::sqrt(mu2) * std::sqrt(1 + 0.25 * a_lat * a_lat * mu2)) * (1. + std::pow(R, M_lat)) /
            (1. - std::pow(R, M_lat));
   }
+  /** harmonicoscillatoraction.hh:115-122 with RenormalisedHOParameters (harmonicoscillatorrenormalisation.hh:36-67) */
   std::shared_ptr<Action> coarse_action() override {
-    return std::make_shared<HarmonicOscillatorAction>(lattice->coarse_lattice(), renormalisation, m0, mu2);
+    double m0c = m0, mu2c = mu2;
+    if (renormalisation == RenormalisationPerturbative) {
+      m0c = m0 * (1. - 0.5 * a_lat * a_lat * mu2);
+      mu2c = mu2 * (1. + 0.25 * a_lat * a_lat * mu2);
+    } else if (renormalisation == RenormalisationNonperturbative) {
+      m0c = m0 / (1. + 0.5 * a_lat * a_lat * mu2);
+      mu2c = mu2 * (1. + 0.25 * a_lat * a_lat * mu2);
+    }
+    return std::make_shared<HarmonicOscillatorAction>(lattice->coarse_lattice(), renormalisation, m0c, mu2c);
   }
   const double mu2;
 };

@@ -1,0 +1,338 @@
+// multilevel.hh -- the multilevel glue of the reference for 1-D (QM) actions, on device chains:
+//   ConditionedFineAction            action/conditionedfineaction.hh:38-67
+//   GaussianConditionedFineAction    action/qm/gaussianconditionedfineaction.{hh,cc}
+//   TwoLevelMetropolisStep           montecarlo/twolevelmetropolisstep.{hh,cc}
+//   HierarchicalSampler              sampler/hierarchicalsampler.{hh,cc}
+//   MonteCarloMultiLevel             montecarlo/montecarlomultilevel.{hh,cc}
+// The two-level step (copy_from_coarse, Gaussian fill-in, three action differences, Metropolis test,
+// copy of accepted states) is one ABI call, mlmcpi_path_twolevel_draw.
+#ifndef MLMCPI_MULTILEVEL_HH
+#define MLMCPI_MULTILEVEL_HH
+#include <chrono>
+#include <cmath>
+
+#include "montecarlo.hh"
+
+namespace mlmcpi {
+
+class ConditionedFineAction {
+public:
+  virtual ~ConditionedFineAction() {}
+  /** the fine-level action whose fine-only points this object fills in */
+  virtual std::shared_ptr<QMAction> fine_action() const = 0;
+};
+
+/** Gaussian fill-in x_{2j+1} ~ N(Wminimum(x_2j, x_2j+2), 1/Wcurvature): harmonic and quartic oscillator.
+ *  fill_fine_points / evaluate run inside mlmcpi_path_twolevel_draw. */
+class GaussianConditionedFineAction : public ConditionedFineAction {
+public:
+  explicit GaussianConditionedFineAction(const std::shared_ptr<QMAction> action_) : action(action_) {
+    if (action->abi_action().kind == MLMCPI_ROTOR) fatal("Gaussian conditioned fine action not defined for the rotor action");
+  }
+  std::shared_ptr<QMAction> fine_action() const override { return action; }
+
+private:
+  const std::shared_ptr<QMAction> action;
+};
+
+class ConditionedFineActionFactory {
+public:
+  virtual ~ConditionedFineActionFactory() {}
+  virtual std::shared_ptr<ConditionedFineAction> get(std::shared_ptr<Action> action) = 0;
+};
+
+class GaussianConditionedFineActionFactory : public ConditionedFineActionFactory {
+public:
+  std::shared_ptr<ConditionedFineAction> get(std::shared_ptr<Action> action) override {
+    auto qm = std::dynamic_pointer_cast<QMAction>(action);
+    if (!qm) fatal("Gaussian conditioned fine action needs a 1-D action");
+    return std::make_shared<GaussianConditionedFineAction>(qm);
+  }
+};
+
+/** twolevelmetropolisstep.{hh,cc}: draws a fine-level sample from a coarse-level proposal. */
+class TwoLevelMetropolisStep : public MCMCStep {
+public:
+  TwoLevelMetropolisStep(const std::shared_ptr<Action> coarse_action_, const std::shared_ptr<Action> fine_action_,
+                         const std::shared_ptr<ConditionedFineAction> conditioned_fine_action_, unsigned int batch = 1,
+                         unsigned int n_meas = 200)
+      : MCMCStep(), coarse(std::dynamic_pointer_cast<QMAction>(coarse_action_)),
+        fine(std::dynamic_pointer_cast<QMAction>(fine_action_)), cfa(conditioned_fine_action_), B(batch),
+        accept_flags(batch, sizeof(int32_t)), cost_per_sample_(0.0) {
+    if (!coarse || !fine || !cfa) fatal("TwoLevelMetropolisStep: actions have no device implementation");
+    size_t bytes = 0;
+    check(mlmcpi_path_twolevel_workspace_bytes(&fine->abi_action(), B, &bytes), "twolevel_workspace_bytes");
+    check(mlmcpi_malloc(&work, bytes), "mlmcpi_malloc");
+    theta_fine = std::make_shared<SampleState>(fine->sample_size(), B);
+    // twolevelmetropolisstep.cc:23-31: cost per sample by timing draws (10 000 in the reference)
+    auto phi_fine = std::make_shared<SampleState>(fine->sample_size(), B);
+    auto phi_coarse = std::make_shared<SampleState>(coarse->sample_size(), B);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned int k = 0; k < n_meas; ++k) draw(phi_coarse, phi_fine);
+    check(mlmcpi_stream_synchronize(nullptr), "synchronize");
+    cost_per_sample_ = 1.E6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / (n_meas ? n_meas : 1);
+    theta_fine->data = std::make_shared<SampleState>(fine->sample_size(), B)->data;  // back to zeros
+    reset_stats();
+  }
+  ~TwoLevelMetropolisStep() { mlmcpi_free(work); }
+
+  /** twolevelmetropolisstep.cc:35-89 */
+  void draw(const std::shared_ptr<SampleState> phi_coarse_state, std::shared_ptr<SampleState> phi_state) {
+    check(mlmcpi_path_twolevel_draw(&fine->abi_action(), &coarse->abi_action(), phi_coarse_state->device(),
+                                    theta_fine->device_mutable(), B, fine->get_seed() ^ 0x5517A4B3ull, fine->get_chain0(),
+                                    step++, work, (int32_t *)accept_flags.ptr(), nullptr, nullptr), "path_twolevel_draw");
+    std::vector<int32_t> flags = accept_flags.download<int32_t>();
+    double acc = 0;
+    for (int32_t f : flags) acc += f;
+    accept = flags[0] != 0;
+    n_total_samples++;
+    n_accepted_samples += acc / B;
+    if (copy_if_rejected || accept || B > 1) phi_state->data = theta_fine->data;
+  }
+  void set_state(std::shared_ptr<SampleState> phi_state) override { theta_fine->data = phi_state->data; }
+  double cost_per_sample() override { return cost_per_sample_; }
+
+private:
+  const std::shared_ptr<QMAction> coarse, fine;
+  const std::shared_ptr<ConditionedFineAction> cfa;
+  const unsigned int B;
+  std::shared_ptr<SampleState> theta_fine;
+  void *work = nullptr;
+  DeviceVector accept_flags;
+  uint32_t step = 0;
+  double cost_per_sample_;
+};
+
+/** sampler/hierarchicalsampler.hh: parameters */
+struct HierarchicalParameters {
+  unsigned int n_max_level = 2;
+  unsigned int batch = 1;
+  unsigned int n_meas = 200;  // draws timed for cost_per_sample (10 000 in the reference)
+};
+
+/** hierarchicalsampler.cc:8-118: delayed acceptance through the level hierarchy; the coarsest level is
+ *  sampled by the sampler the factory provides (HMC in the reference's drivers). */
+class HierarchicalSampler : public Sampler {
+public:
+  HierarchicalSampler(const std::shared_ptr<Action> fine_action, const std::shared_ptr<SamplerFactory> coarse_sampler_factory,
+                      const std::shared_ptr<ConditionedFineActionFactory> cfa_factory, const HierarchicalParameters p)
+      : Sampler(), n_level(p.n_max_level - fine_action->get_coarsening_level()), cost_per_sample_(0.0) {
+    if (n_level < 1) fatal("hierarchical sampler needs at least one level");
+    action.push_back(fine_action);
+    for (unsigned int ell = 0; ell + 1 < n_level; ++ell) {
+      std::shared_ptr<Action> c = action[ell]->coarse_action();
+      c->set_seed(fine_action->get_seed(), fine_action->get_chain0());
+      action.push_back(c);
+      twolevel_step.push_back(std::make_shared<TwoLevelMetropolisStep>(c, action[ell], cfa_factory->get(action[ell]), p.batch, p.n_meas));
+    }
+    for (unsigned int ell = 0; ell < n_level; ++ell)
+      phi_sampler_state.push_back(std::make_shared<SampleState>(action[ell]->sample_size(), p.batch));
+    coarse_sampler = coarse_sampler_factory->get(action[n_level - 1]);
+    auto meas_state = std::make_shared<SampleState>(fine_action->sample_size(), p.batch);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned int k = 0; k < p.n_meas; ++k) draw(meas_state);
+    check(mlmcpi_stream_synchronize(nullptr), "synchronize");
+    cost_per_sample_ = 1.E6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / (p.n_meas ? p.n_meas : 1);
+  }
+
+  /** hierarchicalsampler.cc:55-81 */
+  void draw(std::shared_ptr<SampleState> phi_state) override {
+    accept = true;
+    for (unsigned int ell = 1; ell < n_level; ++ell) copy_from_fine(phi_sampler_state[ell - 1], phi_sampler_state[ell]);
+    for (int ell = (int)n_level - 1; ell >= 0; --ell) {
+      if (ell == (int)n_level - 1) {
+        coarse_sampler->set_state(phi_sampler_state[ell]);
+        coarse_sampler->draw(phi_sampler_state[ell]);
+        accept = accept && coarse_sampler->accepted();
+      } else {
+        twolevel_step[ell]->set_state(phi_sampler_state[ell]);
+        twolevel_step[ell]->draw(phi_sampler_state[ell + 1], phi_sampler_state[ell]);
+        accept = accept && twolevel_step[ell]->accepted();
+      }
+      if (!accept) break;
+    }
+    n_total_samples++;
+    n_accepted_samples += accept ? 1 : 0;
+    if (accept || copy_if_rejected) phi_state->data = phi_sampler_state[0]->data;
+  }
+  void set_state(std::shared_ptr<SampleState> phi_state) override { phi_sampler_state[0]->data = phi_state->data; }
+  double cost_per_sample() override { return cost_per_sample_; }
+  void show_stats() override {
+    std::cout << std::setprecision(4) << std::fixed << "  cost per sample = " << cost_per_sample() << " mu s" << std::endl;
+    std::cout << "  acceptance rate = " << p_accept() << std::endl;
+    for (unsigned int ell = 0; ell < n_level; ++ell)
+      std::cout << "  level " << ell << " : p = " << (ell == n_level - 1 ? coarse_sampler->p_accept() : twolevel_step[ell]->p_accept()) << std::endl;
+  }
+
+  /** QMAction::copy_from_fine (action/qm/qmaction.cc:16-24): x_coarse[j] = x_fine[2j].  Host-side strided
+   *  copy through the lazy mirror (levels are small compared with a trajectory; a device kernel is next). */
+  static void copy_from_fine(const std::shared_ptr<SampleState> fine, std::shared_ptr<SampleState> coarse) {
+    const size_t Mc = coarse->size(), B = coarse->batch();
+    for (size_t b = 0; b < B; ++b)
+      for (size_t j = 0; j < Mc; ++j) coarse->data[b * Mc + j] = static_cast<const SampleState::Data &>(fine->data)[b * 2 * Mc + 2 * j];
+  }
+
+private:
+  const unsigned int n_level;
+  std::vector<std::shared_ptr<Action>> action;
+  std::vector<std::shared_ptr<TwoLevelMetropolisStep>> twolevel_step;
+  std::vector<std::shared_ptr<SampleState>> phi_sampler_state;
+  std::shared_ptr<Sampler> coarse_sampler;
+  double cost_per_sample_;
+};
+
+class HierarchicalSamplerFactory : public SamplerFactory {
+public:
+  HierarchicalSamplerFactory(std::shared_ptr<SamplerFactory> coarse, std::shared_ptr<ConditionedFineActionFactory> cfa, HierarchicalParameters p)
+      : coarse_factory(coarse), cfa_factory(cfa), param(p) {}
+  std::shared_ptr<Sampler> get(std::shared_ptr<Action> action) override {
+    return std::make_shared<HierarchicalSampler>(action, coarse_factory, cfa_factory, param);
+  }
+private:
+  std::shared_ptr<SamplerFactory> coarse_factory;
+  std::shared_ptr<ConditionedFineActionFactory> cfa_factory;
+  const HierarchicalParameters param;
+};
+
+/** montecarlo/montecarlomultilevel.hh: parameters */
+struct MultiLevelMCParameters {
+  unsigned int n_level = 3;
+  unsigned int n_burnin = 100;
+  double epsilon = 1.0e-2;
+  unsigned int n_autocorr_window = 20, n_min_samples_qoi = 100;
+  bool sub_sample_coarse = true;  // hierarchical coarse samplers: draw ceil(2 tau_int) times between uses
+  unsigned int n_meas = 200;
+};
+
+/** montecarlomultilevel.cc:7-282: telescoping-sum estimator Q = sum_l E[Y_l], Y_L = Q_L on the coarsest
+ *  level, Y_l = Q_l(x_f) - Q_{l+1}(x_c) from the two-level step; sample numbers from the variance / cost
+ *  model of :148-164.  Levels are independent estimators (each owns its samplers and states), which is
+ *  what lets them be placed on different GPUs. */
+class MonteCarloMultiLevel {
+public:
+  MonteCarloMultiLevel(std::shared_ptr<Action> fine_action_, std::shared_ptr<QoIFactory> qoi_factory,
+                       std::shared_ptr<SamplerFactory> sampler_factory, std::shared_ptr<ConditionedFineActionFactory> cfa_factory,
+                       const MultiLevelMCParameters p)
+      : param(p), n_level(p.n_level) {
+    if (n_level < 2) fatal("multilevel method needs at least two levels");
+    action.push_back(fine_action_);
+    for (unsigned int level = 0; level + 1 < n_level; ++level) {
+      std::shared_ptr<Action> c = action[level]->coarse_action();
+      c->set_seed(fine_action_->get_seed() + 7919 * (level + 1), fine_action_->get_chain0());
+      action.push_back(c);
+      twolevel_step.push_back(std::make_shared<TwoLevelMetropolisStep>(c, action[level], cfa_factory->get(action[level]), 1, p.n_meas));
+      coarse_sampler.push_back(sampler_factory->get(c));  // sampler for level + 1
+    }
+    for (unsigned int level = 0; level < n_level; ++level) {
+      qoi.push_back(qoi_factory->get(action[level]));
+      phi_state.push_back(std::make_shared<SampleState>(action[level]->sample_size()));
+      phi_coarse_state.push_back(std::make_shared<SampleState>(action[level]->sample_size()));
+      stats_qoi.push_back(std::make_shared<Statistics>("Y_" + std::to_string(level), p.n_autocorr_window));
+      if (level + 1 < n_level) stats_coarse_sampler.push_back(std::make_shared<Statistics>("Q_sampler_" + std::to_string(level + 1), p.n_autocorr_window));
+    }
+    t_indep.assign(n_level - 1, 1.0);
+    n_indep.assign(n_level - 1, 0.0);
+    t_sampler.assign(n_level - 1, 0.0);
+    n_target.assign(n_level, p.n_min_samples_qoi);
+  }
+
+  void evaluate() {
+    for (unsigned int level = 0; level < n_level; ++level) stats_qoi[level]->hard_reset();
+    for (auto &s : stats_coarse_sampler) s->hard_reset();
+    // burn-in (montecarlomultilevel.cc:83-100)
+    for (int level = (int)n_level - 1; level >= 0; --level)
+      for (unsigned int j = 0; j < param.n_burnin; ++j) stats_qoi[level]->record_sample(sample_Y(level));
+    for (unsigned int level = 0; level < n_level; ++level) {
+      stats_qoi[level]->reset();
+      n_target[level] = param.n_min_samples_qoi;
+    }
+    const double two_epsilon_inv2 = 2. / (param.epsilon * param.epsilon);
+    bool sufficient = false;
+    do {
+      for (int level = (int)n_level - 1; level >= 0; --level)
+        for (unsigned int j = stats_qoi[level]->samples(); j < n_target[level]; ++j) stats_qoi[level]->record_sample(sample_Y(level));
+      sufficient = true;
+      double sum = 0;
+      for (unsigned int ell = 0; ell < n_level; ++ell) sum += std::sqrt(stats_qoi[ell]->variance() * cost_eff(ell));
+      for (unsigned int ell = 0; ell < n_level; ++ell) {
+        const double V = stats_qoi[ell]->variance(), C = cost_eff(ell);
+        n_target[ell] = (unsigned int)std::ceil(two_epsilon_inv2 * sum * std::sqrt(V / C) * stats_qoi[ell]->tau_int());
+        sufficient = sufficient && (stats_qoi[ell]->samples() >= n_target[ell]);
+      }
+    } while (!sufficient);
+  }
+  /** montecarlomultilevel.cc:255-271 */
+  double numerical_result() const {
+    double q = 0;
+    for (unsigned int ell = 0; ell < n_level; ++ell) q += stats_qoi[ell]->average();
+    return q;
+  }
+  double statistical_error() const {
+    double e2 = 0;
+    for (unsigned int ell = 0; ell < n_level; ++ell) e2 += stats_qoi[ell]->error() * stats_qoi[ell]->error();
+    return std::sqrt(e2);
+  }
+  void show_statistics() {
+    for (unsigned int ell = 0; ell < n_level; ++ell) std::cout << *stats_qoi[ell] << "  target samples = " << n_target[ell] << std::endl;
+    std::cout << " Q = " << std::setprecision(6) << numerical_result() << " +/- " << statistical_error() << std::endl;
+  }
+  std::shared_ptr<Statistics> level_statistics(unsigned int ell) { return stats_qoi[ell]; }
+
+private:
+  double sample_Y(int level) {
+    if (level == (int)n_level - 1) {
+      draw_coarse_sample(level, phi_state[level]);
+      return qoi[level]->evaluate(phi_state[level]);
+    }
+    draw_coarse_sample(level + 1, phi_coarse_state[level + 1]);
+    twolevel_step[level]->draw(phi_coarse_state[level + 1], phi_state[level]);
+    return qoi[level]->evaluate(phi_state[level]) - qoi[level + 1]->evaluate(phi_coarse_state[level + 1]);
+  }
+  /** montecarlomultilevel.cc:170-190 */
+  void draw_coarse_sample(const unsigned int level, std::shared_ptr<SampleState> state) {
+    const unsigned int k = level - 1;
+    if (param.sub_sample_coarse) {
+      const double tau = std::ceil(2. * stats_coarse_sampler[k]->tau_int());
+      while (t_sampler[k] < tau || stats_coarse_sampler[k]->samples() < 2) {
+        coarse_sampler[k]->draw(state);
+        stats_coarse_sampler[k]->record_sample(qoi[level]->evaluate(state));
+        t_sampler[k]++;
+      }
+    } else {
+      coarse_sampler[k]->draw(state);
+      t_sampler[k] = 1;
+    }
+    t_indep[k] = (n_indep[k] * t_indep[k] + t_sampler[k]) / (1.0 + n_indep[k]);
+    n_indep[k]++;
+    t_sampler[k] = 0;
+  }
+  /** montecarlomultilevel.cc:193-204 */
+  double cost_eff(const int ell) const {
+    if (ell == (int)n_level - 1) return t_indep[ell - 1] * coarse_sampler[ell - 1]->cost_per_sample();
+    return twolevel_step[ell]->cost_per_sample() + t_indep[ell] * coarse_sampler[ell]->cost_per_sample();
+  }
+
+  const MultiLevelMCParameters param;
+  const unsigned int n_level;
+  std::vector<std::shared_ptr<Action>> action;
+  std::vector<std::shared_ptr<TwoLevelMetropolisStep>> twolevel_step;
+  std::vector<std::shared_ptr<Sampler>> coarse_sampler;
+  std::vector<std::shared_ptr<QoI>> qoi;
+  std::vector<std::shared_ptr<SampleState>> phi_state, phi_coarse_state;
+  std::vector<std::shared_ptr<Statistics>> stats_qoi, stats_coarse_sampler;
+  std::vector<double> t_indep, n_indep, t_sampler;
+  std::vector<unsigned int> n_target;
+};
+
+/** QoI factories (qoi/qm/qoixsquared.hh etc.): a QoI per level */
+class QoIXsquaredFactory : public QoIFactory {
+public:
+  std::shared_ptr<QoI> get(std::shared_ptr<Action> action) override {
+    auto qm = std::dynamic_pointer_cast<QMAction>(action);
+    if (!qm) fatal("QoIXsquared needs a 1-D action");
+    return std::make_shared<QoIXsquared>(qm->get_lattice());
+  }
+};
+
+}  // namespace mlmcpi
+#endif

@@ -259,8 +259,9 @@ def test_twolevel_step_matches_oracle(gpu_ops, orc, name, M, B):
     theta = theta0.copy()
     seen = set()
     for t in range(6):
-        # coarse proposals: smooth paths near / far from the current fine state -> both outcomes occur
-        xc = theta[:, ::2] * (1.0 if t % 2 else 0.6) + rng.normal(0, 0.05 if t % 2 else 0.3, (B, M // 2))
+        # coarse proposals: the coarse points of the current fine state (accepted: the fill-in replaces a
+        # rougher path) alternate with very rough ones (rejected) -> both outcomes occur
+        xc = theta[:, ::2] + rng.normal(0, 1e-3 if t % 2 == 0 else 1.0, (B, M // 2))
         acc = step.draw(dev(xc)).cpu().numpy()
         terms = step.terms.cpu().numpy()
         for b in range(B):
