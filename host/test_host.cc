@@ -152,7 +152,7 @@ int main(int argc, char **argv) {
     // single-level reference point through the hierarchical sampler itself
     {
       SingleLevelMCParameters mp;
-      mp.n_burnin = 300; mp.n_samples = 6000;
+      mp.n_burnin = 200; mp.n_samples = 3000;
       MonteCarloSingleLevel mc(act, std::make_shared<QoIXsquared>(lat), hfac, mp);
       mc.evaluate();
       auto st = mc.get_statistics();
@@ -161,8 +161,11 @@ int main(int argc, char **argv) {
       EXPECT(std::fabs(st->average() - act->Xsquared_analytical()) < 5 * st->error(), "hierarchical sampler <x^2>");
     }
     MultiLevelMCParameters mlp;
-    mlp.n_level = 3; mlp.n_burnin = 100; mlp.epsilon = 8e-3; mlp.n_min_samples_qoi = 200; mlp.n_meas = 50;
+    mlp.n_level = 3; mlp.n_burnin = 100; mlp.epsilon = 2.5e-2; mlp.n_min_samples_qoi = 200; mlp.n_meas = 50;
+    std::printf(" constructing the multilevel estimator ...\n"); std::fflush(stdout);
     MonteCarloMultiLevel mlmc(act, std::make_shared<QoIXsquaredFactory>(), hfac, cfa, mlp);
+    std::printf(" running the multilevel estimator ...\n"); std::fflush(stdout);
+    mlmc.verbose = true;
     mlmc.evaluate();
     mlmc.show_statistics();
     const double exact = act->Xsquared_analytical();

@@ -239,9 +239,20 @@ public:
   void evaluate() {
     for (unsigned int level = 0; level < n_level; ++level) stats_qoi[level]->hard_reset();
     for (auto &s : stats_coarse_sampler) s->hard_reset();
-    // burn-in (montecarlomultilevel.cc:83-100)
+    // burn-in (montecarlomultilevel.cc:83-100): straight from the coarse samplers, no sub-sampling
     for (int level = (int)n_level - 1; level >= 0; --level)
-      for (unsigned int j = 0; j < param.n_burnin; ++j) stats_qoi[level]->record_sample(sample_Y(level));
+      for (unsigned int j = 0; j < param.n_burnin; ++j) {
+        double qoi_Y;
+        if (level == (int)n_level - 1) {
+          coarse_sampler[level - 1]->draw(phi_state[level]);
+          qoi_Y = qoi[level]->evaluate(phi_state[level]);
+        } else {
+          coarse_sampler[level]->draw(phi_coarse_state[level + 1]);
+          twolevel_step[level]->draw(phi_coarse_state[level + 1], phi_state[level]);
+          qoi_Y = qoi[level]->evaluate(phi_state[level]) - qoi[level + 1]->evaluate(phi_coarse_state[level + 1]);
+        }
+        stats_qoi[level]->record_sample(qoi_Y);
+      }
     for (unsigned int level = 0; level < n_level; ++level) {
       stats_qoi[level]->reset();
       n_target[level] = param.n_min_samples_qoi;
@@ -249,8 +260,10 @@ public:
     const double two_epsilon_inv2 = 2. / (param.epsilon * param.epsilon);
     bool sufficient = false;
     do {
-      for (int level = (int)n_level - 1; level >= 0; --level)
+      for (int level = (int)n_level - 1; level >= 0; --level) {
         for (unsigned int j = stats_qoi[level]->samples(); j < n_target[level]; ++j) stats_qoi[level]->record_sample(sample_Y(level));
+        if (verbose) std::cout << "  level " << level << ": " << stats_qoi[level]->samples() << " samples" << std::endl;
+      }
       sufficient = true;
       double sum = 0;
       for (unsigned int ell = 0; ell < n_level; ++ell) sum += std::sqrt(stats_qoi[ell]->variance() * cost_eff(ell));
@@ -277,6 +290,7 @@ public:
     std::cout << " Q = " << std::setprecision(6) << numerical_result() << " +/- " << statistical_error() << std::endl;
   }
   std::shared_ptr<Statistics> level_statistics(unsigned int ell) { return stats_qoi[ell]; }
+  bool verbose = false;
 
 private:
   double sample_Y(int level) {
@@ -292,8 +306,12 @@ private:
   void draw_coarse_sample(const unsigned int level, std::shared_ptr<SampleState> state) {
     const unsigned int k = level - 1;
     if (param.sub_sample_coarse) {
-      const double tau = std::ceil(2. * stats_coarse_sampler[k]->tau_int());
-      while (t_sampler[k] < tau || stats_coarse_sampler[k]->samples() < 2) {
+      // tau_int estimated from a window of n_autocorr_window lags is at most 1 + 2 n_autocorr_window; a
+      // larger value (or NaN) only arises from rounding noise when the first few samples coincide
+      double tau = std::ceil(2. * stats_coarse_sampler[k]->tau_int());
+      const double tau_max = 2. * (1. + 2. * param.n_autocorr_window);
+      if (!(tau <= tau_max)) tau = tau_max;
+      while (t_sampler[k] < tau) {
         coarse_sampler[k]->draw(state);
         stats_coarse_sampler[k]->record_sample(qoi[level]->evaluate(state));
         t_sampler[k]++;
