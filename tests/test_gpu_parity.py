@@ -270,7 +270,8 @@ def test_twolevel_step_matches_oracle(gpu_ops, orc, name, M, B):
             assert acc[b] == a, (t, b, want)
             seen.add(int(a))
         assert_close(step.theta.cpu().numpy(), theta, tol=1e-12, what=f"fine state after draw {t}")
-    assert seen == {0, 1}
+    if name == "quartic":  # (for the HO the Gaussian fill-in is exact and these proposals are all accepted)
+        assert seen == {0, 1}
 
 
 def test_twolevel_step_errors(gpu_ops):
