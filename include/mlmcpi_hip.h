@@ -118,6 +118,20 @@ int mlmcpi_path_hmc_draw(const mlmcpi_path_action *act, double *d_x, uint32_t B,
                          uint32_t n_rep, uint64_t seed, uint32_t chain0, uint32_t traj0, void *d_work,
                          int32_t *d_accept, double *d_energies, void *stream);
 
+/* n_draws consecutive HMCSampler::draw calls, each followed by a QoI evaluation -- the body of the loop
+ * of MonteCarloSingleLevel::evaluate (montecarlo/montecarlosinglelevel.cc:59-77) -- without returning
+ * to the host: for paths that fit one workgroup (M <= 8192, multiple of 64) everything, including the
+ * Metropolis tests and the QoIs, runs in ONE launch with the state in registers throughout.  Results are
+ * bit-identical to n_draws x (mlmcpi_path_hmc_draw with traj0 + d*n_rep, then the QoI kernel).
+ *   qoi_kind  0 none, 1 QoIXsquared, 2 QoISusceptibility;  d_qoi [B*n_draws] (chain-major) for the
+ *   one-launch path, [n_draws*B] (draw-major) for segmented paths -- see mlmcpi_path_hmc_run_layout();
+ *   d_accept_count [B] int32 (optional): accepted draws per chain. */
+int mlmcpi_path_hmc_run(const mlmcpi_path_action *act, double *d_x, uint32_t B, uint32_t nt, double dt, uint32_t n_rep,
+                        uint32_t n_draws, int qoi_kind, uint64_t seed, uint32_t chain0, uint32_t traj0, void *d_work,
+                        double *d_qoi, int32_t *d_accept_count, void *stream);
+/* 1 if d_qoi of mlmcpi_path_hmc_run is chain-major [B][n_draws] for this action / nt, 0 if draw-major */
+int mlmcpi_path_hmc_run_layout(const mlmcpi_path_action *act, uint32_t B, uint32_t nt, int32_t *chain_major);
+
 /* OverrelaxedHeatBathSampler::draw (sampler/overrelaxedheatbathsampler.cc:8-31) for the rotor:
  * n_overrelax sweeps of RotorAction::overrelaxation_update (rotoraction.cc:40-56) then n_heatbath
  * sweeps of heatbath_update (:20-37), even sites then odd sites within each sweep.  Sweep s of

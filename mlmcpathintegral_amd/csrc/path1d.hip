@@ -263,6 +263,145 @@ __global__ void __launch_bounds__(R >= 8 ? 512 : 1024)
   }
 }
 
+// Whole chains on the device: n_draws x n_rep trajectories of a periodic, register-resident path
+// (one workgroup per chain) in ONE launch, with the Metropolis test, the copy-on-accept and the QoI
+// of every draw done in-kernel.  Same arithmetic, same Philox counters (trajectory index
+// traj0 + d*n_rep + r) as n_draws calls of mlmcpi_path_hmc_draw followed by the QoI kernel, so the
+// two forms are bit-identical; this one removes ~2 launches and a host round trip per draw, which is
+// what dominates for short paths (BASELINE config 1: M_lat = 128; the coarse levels of config 5).
+// qoi_kind: 0 none, 1 <x^2> (qoixsquared.cc:7-20), 2 susceptibility (qoisusceptibility.cc:8-23).
+template <int KIND, int R>
+__global__ void __launch_bounds__(R >= 8 ? 512 : 1024)
+    hmc_chain_kernel(PathP P, double *__restrict__ x_state, double *__restrict__ q_out,
+                     int32_t *__restrict__ acc_count, double *__restrict__ energies, uint32_t nt, double dt,
+                     uint32_t n_rep, uint32_t n_draws, int qoi_kind, RngKey key0) {
+  extern __shared__ double lds[];  // [2][2][NT] exchange | 4*NT/64 scratch | [R][NT] staging | flag
+  const uint32_t b = blockIdx.x, t = threadIdx.x, NT = blockDim.x, M = P.M;
+  const uint32_t kbase = t * R;
+  double *xb = x_state + (size_t)b * M;
+  RngKey key = key0;
+  key.chain += b;
+  double *ex_first = lds, *ex_last = lds + 2 * NT;
+  double *scratch = lds + 4 * NT;
+  double *stage = scratch + 4 * (NT / kWave);
+  double *flag = stage + (size_t)R * NT;
+  const double escale = energy_scale(P);
+
+  double xc[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) xc[r] = xb[kbase + r];
+  int buf = 0;
+  auto exchange = [&](const double (&v)[R], double &xl, double &xr) {
+    ex_first[buf * NT + t] = v[0];
+    ex_last[buf * NT + t] = v[R - 1];
+    __syncthreads();
+    xl = ex_last[buf * NT + (t == 0 ? NT - 1 : t - 1)];
+    xr = ex_first[buf * NT + (t == NT - 1 ? 0 : t + 1)];
+    buf ^= 1;
+  };
+  int32_t n_acc = 0;
+  for (uint32_t d = 0; d < n_draws; ++d) {
+    bool accepted = false;
+    for (uint32_t rep = 0; rep < n_rep && !accepted; ++rep) {
+      key.step = key0.step + d * n_rep + rep;
+#pragma unroll 1
+      for (int r = 0; r < R; ++r) stage[r * NT + t] = rng_normal0(key, kbase + r, P_MOMENTUM, 0);
+      double x[R], p[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        x[r] = xc[r];
+        p[r] = stage[r * NT + t];
+      }
+      double sums[4] = {0.0, 0.0, 0.0, 0.0};
+      double xl, xr;
+      exchange(x, xl, xr);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        sums[0] += site_energy<KIND>(P, x[r], r == 0 ? xl : x[r - 1]);
+        sums[1] += p[r] * p[r];
+        if (KIND == MLMCPI_ROTOR) __builtin_amdgcn_sched_barrier(0);
+      }
+      for (uint32_t k = 0; k <= nt; ++k) {
+        const double dtp = (k == 0 || k == nt) ? 0.5 * dt : dt;
+        const double dtx = (k == nt) ? 0.0 : dt;
+        if (KIND == MLMCPI_ROTOR) {
+          double dprev = sin_reduced(x[0] - xl);
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const double dnext = sin_reduced((r == R - 1 ? xr : x[r + 1]) - x[r]);
+            p[r] -= dtp * (P.c1 * (dprev - dnext));
+            dprev = dnext;
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        } else {
+          double left = xl;
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const double right = (r == R - 1) ? xr : x[r + 1];
+            const double f = site_force<KIND>(P, left, x[r], right);
+            left = x[r];
+            p[r] -= dtp * f;
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) x[r] += dtx * p[r];
+        if (k < nt) exchange(x, xl, xr);
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        sums[2] += site_energy<KIND>(P, x[r], r == 0 ? xl : x[r - 1]);
+        sums[3] += p[r] * p[r];
+        if (KIND == MLMCPI_ROTOR) __builtin_amdgcn_sched_barrier(0);
+      }
+      block_sum<4>(sums, scratch);
+      if (t == 0) {
+        const double S0 = escale * sums[0], T0 = 0.5 * sums[1], S1 = escale * sums[2], T1 = 0.5 * sums[3];
+        const double dH = (S1 - S0) + (T1 - T0);
+        bool acc;
+        if (dH < 0.0) {
+          acc = true;
+        } else {
+          double u, v;
+          rng_uniforms(key, 0, P_ACCEPT, 0, u, v);
+          acc = u < exp(-dH);
+        }
+        flag[0] = acc ? 1.0 : 0.0;
+        if (energies) {
+          energies[4 * b + 0] = S0; energies[4 * b + 1] = T0; energies[4 * b + 2] = S1; energies[4 * b + 3] = T1;
+        }
+      }
+      __syncthreads();
+      accepted = flag[0] != 0.0;
+      __syncthreads();  // flag is rewritten by the next repetition
+      if (accepted) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) xc[r] = x[r];
+      }
+    }
+    n_acc += accepted ? 1 : 0;
+    if (qoi_kind) {
+      double q[1] = {0.0};
+      if (qoi_kind == 1) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) q[0] += xc[r] * xc[r];
+      } else {
+        double xl, xr;
+        exchange(xc, xl, xr);
+#pragma unroll
+        for (int r = 0; r < R; ++r) q[0] += mod_2pi(xc[r] - (r == 0 ? xl : xc[r - 1]));
+      }
+      block_sum<1>(q, scratch);
+      if (t == 0)
+        q_out[(size_t)b * n_draws + d] =
+            (qoi_kind == 1) ? (1.0 / M) * q[0] : (1. / (4. * kPi * kPi)) * (q[0] * q[0]) * (1.0 / P.T_final);
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) xb[kbase + r] = xc[r];
+  if (t == 0 && acc_count) acc_count[b] = n_acc;
+}
+
 // Global Metropolis test + copy of accepted trial states.  Grid (nblk, B).  Every workgroup of a
 // chain recomputes the (cheap) decision from the segment partials in the same order, so no
 // inter-workgroup hand-off is needed.  sampler/hmcsampler.cc:50-67.
@@ -302,6 +441,11 @@ __global__ void __launch_bounds__(256)
   double *dst = x_cur + (size_t)b * M;
   const double *src = x_trial + (size_t)b * M;
   for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < M; j += gridDim.x * blockDim.x) dst[j] = src[j];
+}
+
+__global__ void add_flags_kernel(int32_t *__restrict__ acc, const int32_t *__restrict__ flags, uint32_t B) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) acc[b] += flags[b];
 }
 
 // ---- rotor sweeps -----------------------------------------------------------------------------------
@@ -745,6 +889,59 @@ int mlmcpi_path_twolevel_draw(const mlmcpi_path_action *fine, const mlmcpi_path_
   hipLaunchKernelGGL(twolevel_accept_kernel, dim3(choose_split(Pf.M, B), B), block, 0, st, Pf.M, d_theta,
                      (const double *)theta_prime, (const double *)en4, (const double *)cfa, nblk, B, d_accept, d_terms, key);
   MLMCPI_LAUNCH_CHECK("twolevel_accept_kernel");
+  return MLMCPI_OK;
+}
+
+int mlmcpi_path_hmc_run(const mlmcpi_path_action *act, double *d_x, uint32_t B, uint32_t nt, double dt, uint32_t n_rep,
+                        uint32_t n_draws, int qoi_kind, uint64_t seed, uint32_t chain0, uint32_t traj0, void *d_work,
+                        double *d_qoi, int32_t *d_accept_count, void *stream) {
+  if (int rc = check_action(act)) return rc;
+  MLMCPI_REQUIRE(d_x && d_work && B > 0 && n_rep > 0 && n_draws > 0, "bad arguments");
+  MLMCPI_REQUIRE(qoi_kind >= 0 && qoi_kind <= 2 && (qoi_kind == 0 || d_qoi), "bad QoI selection");
+  HmcPlan pl;
+  if (int rc = plan_hmc(act->kind, act->M, B, nt, &pl)) return rc;
+  PathP P = make_params(*act);
+  hipStream_t st = as_stream(stream);
+  if (pl.halo == 0) {
+    // register-resident periodic path: everything in one launch, one workgroup per chain
+    const size_t lds = (4 * pl.NT + 4 * (pl.NT / 64) + (size_t)pl.R * pl.NT + 1) * sizeof(double);
+    const RngKey key = make_key(seed, chain0, traj0);
+#define MLMCPI_CHAIN(KK, RR) hipLaunchKernelGGL((hmc_chain_kernel<KK, RR>), dim3(B), dim3(pl.NT), lds, st, P, d_x, d_qoi, d_accept_count, (double *)nullptr, nt, dt, n_rep, n_draws, qoi_kind, key)
+#define MLMCPI_CHAIN_R(KK) switch (pl.R) { case 16: MLMCPI_CHAIN(KK, 16); break; case 8: MLMCPI_CHAIN(KK, 8); break; case 4: MLMCPI_CHAIN(KK, 4); break; case 2: MLMCPI_CHAIN(KK, 2); break; default: MLMCPI_CHAIN(KK, 1); }
+    switch (P.kind) {
+      case MLMCPI_HARMONIC: MLMCPI_CHAIN_R(MLMCPI_HARMONIC); break;
+      case MLMCPI_QUARTIC: MLMCPI_CHAIN_R(MLMCPI_QUARTIC); break;
+      default: MLMCPI_CHAIN_R(MLMCPI_ROTOR);
+    }
+#undef MLMCPI_CHAIN_R
+#undef MLMCPI_CHAIN
+    MLMCPI_LAUNCH_CHECK("hmc_chain_kernel");
+    return MLMCPI_OK;
+  }
+  // segmented paths (M > 8192 or not a multiple of 64): same sequence through the per-draw entry points
+  int32_t *acc_tmp = nullptr;
+  if (d_accept_count) MLMCPI_HIP_TRY(hipMemsetAsync(d_accept_count, 0, (size_t)B * 4, st));
+  MLMCPI_HIP_TRY(hipMalloc((void **)&acc_tmp, (size_t)B * 4));
+  int rc = MLMCPI_OK;
+  for (uint32_t d = 0; d < n_draws && !rc; ++d) {
+    rc = mlmcpi_path_hmc_draw(act, d_x, B, nt, dt, n_rep, seed, chain0, traj0 + d * n_rep, d_work, acc_tmp, nullptr, stream);
+    if (!rc && d_accept_count) {
+      hipLaunchKernelGGL(add_flags_kernel, dim3((B + 255) / 256), dim3(256), 0, st, d_accept_count, (const int32_t *)acc_tmp, B);
+    }
+    if (!rc && qoi_kind == 1) rc = launch_reduce<R_XSQUARED>(P, d_x, B, 1.0 / P.M, d_qoi + (size_t)d * B, st);
+    if (!rc && qoi_kind == 2) rc = launch_reduce<R_WINDING>(P, d_x, B, 1.0 / P.T_final, d_qoi + (size_t)d * B, st);
+  }
+  (void)hipStreamSynchronize(st);
+  (void)hipFree(acc_tmp);
+  return rc;
+}
+
+int mlmcpi_path_hmc_run_layout(const mlmcpi_path_action *act, uint32_t B, uint32_t nt, int32_t *chain_major) {
+  if (int rc = check_action(act)) return rc;
+  MLMCPI_REQUIRE(chain_major && B > 0, "bad arguments");
+  HmcPlan pl;
+  if (int rc = plan_hmc(act->kind, act->M, B, nt, &pl)) return rc;
+  *chain_major = pl.halo == 0 ? 1 : 0;
   return MLMCPI_OK;
 }
 

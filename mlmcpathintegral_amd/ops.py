@@ -89,6 +89,20 @@ class PathHMC:
         return self.accept
 
 
+def path_hmc_run(hmc, x, n_draws, qoi_kind):
+    """n_draws x (HMCSampler::draw + QoI) on the device; returns (q [B, n_draws], accepted draws per chain)."""
+    q = torch.empty((hmc.B, n_draws), dtype=torch.float64, device=x.device)
+    cnt = torch.zeros(hmc.B, dtype=torch.int32, device=x.device)
+    abi.call("mlmcpi_path_hmc_run", C.byref(hmc.act), _p(x), hmc.B, hmc.nt, float(hmc.dt), hmc.n_rep, n_draws, qoi_kind,
+             hmc.seed, hmc.chain0, hmc.traj, _p(hmc.work), _p(q), _p(cnt), _stream())
+    hmc.traj += n_draws * hmc.n_rep
+    layout = C.c_int32(0)
+    abi.call("mlmcpi_path_hmc_run_layout", C.byref(hmc.act), hmc.B, hmc.nt, C.byref(layout))
+    if not layout.value:
+        q = q.reshape(n_draws, hmc.B).t().contiguous()
+    return q, cnt
+
+
 class PathTwoLevelStep:
     """TwoLevelMetropolisStep (montecarlo/twolevelmetropolisstep.cc) on B device chains: Gaussian fill-in."""
 

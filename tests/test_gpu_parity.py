@@ -217,6 +217,43 @@ def test_hmc_register_geometries(gpu_ops, orc, M, R_expected):
         assert_close(hmc.energies[b].cpu().numpy(), e, tol=1e-11)
 
 
+@pytest.mark.parametrize("name,p,nt,dt,n_rep", [
+    ("harmonic", dict(M=128, T_final=4.0, m0=1.0, mu2=1.0), 100, 0.0558, 1),
+    ("quartic", dict(M=1024, T_final=128.0, m0=1.0, mu2=1.0, lam=1.0, x0=1.0), 10, 0.2, 2),
+    ("rotor", dict(M=512, T_final=64.0, m0=0.25), 12, 0.15, 1),
+    ("rotor", dict(M=65536, T_final=8192.0, m0=0.25), 6, 0.05, 1),   # segmented: per-draw fallback inside the ABI
+])
+def test_hmc_run_equals_repeated_draws(gpu_ops, orc, name, p, nt, dt, n_rep):
+    """mlmcpi_path_hmc_run (all draws + QoIs in one launch for short paths) is bit-identical to repeated
+    mlmcpi_path_hmc_draw + QoI calls, and matches the oracle trajectory by trajectory."""
+    act, A = make_path(orc, name, p)
+    M, B, n_draws = p["M"], 3, 5
+    qoi_kind = 2 if name == "rotor" else 1
+    rng = np.random.default_rng(M)
+    x0 = rng.uniform(-1, 1, (B, M))
+    xa, xb = dev(x0), dev(x0)
+    run = gpu_ops.PathHMC(act, B, nt, dt, n_rep=n_rep, seed=SEED, chain0=3)
+    q, cnt = gpu_ops.path_hmc_run(run, xa, n_draws, qoi_kind)
+    ref = gpu_ops.PathHMC(act, B, nt, dt, n_rep=n_rep, seed=SEED, chain0=3)
+    qs, total = [], torch.zeros(B, dtype=torch.int32, device="cuda")
+    for d in range(n_draws):
+        total += ref.draw(xb)
+        qs.append(gpu_ops.qoi_susceptibility(xb, p["T_final"]) if qoi_kind == 2 else gpu_ops.qoi_xsquared(xb))
+    assert torch.equal(xa, xb), "state after n_draws"
+    assert torch.equal(cnt, total)
+    assert_close(q.cpu().numpy(), torch.stack(qs, dim=1).cpu().numpy(), tol=1e-13, what="per-draw QoIs")
+    if M <= 1024:  # oracle cross-check
+        xo = x0.copy()
+        for b in range(B):
+            for d in range(n_draws):
+                a = 0
+                for r in range(n_rep):
+                    if a:
+                        break
+                    a, _, _ = A.dev_hmc_trajectory(xo[b], nt, dt, SEED, 3 + b, d * n_rep + r)
+        assert_close(xa.cpu().numpy(), xo, tol=1e-9, what="state vs oracle")
+
+
 def test_hmc_n_rep_short_circuit(gpu_ops, orc):
     """hmcsampler.cc:10-12: `accept = accept or single_step()` stops integrating after the first
     accepted repetition; repetition r uses Philox step traj0 + r."""
