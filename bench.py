@@ -30,7 +30,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="schwinger", choices=["schwinger", "gff", "rotor_hmc", "quartic_hmc"])
+    ap.add_argument("--workload", default="schwinger", choices=["schwinger", "gff", "rotor_hmc", "quartic_hmc", "ho_hmc"])
     ap.add_argument("--size", type=int, default=0, help="lattice extent (default: BASELINE size of the workload)")
     ap.add_argument("--chains", type=int, default=0, help="independent chains per GPU (default per workload)")
     ap.add_argument("--fuse", type=int, default=0, help="sweeps fused per launch (0 = library default)")
@@ -46,9 +46,9 @@ def parse():
 
 def cpu_baseline(a, size):
     """Reference-order oracle on the host cores; run BEFORE this process touches the GPU."""
-    wl = {"schwinger": "schwinger", "gff": "gff", "rotor_hmc": "rotor", "quartic_hmc": "quartic"}[a.workload]
-    draws = a.cpu_draws or {"schwinger": 5, "gff": 40, "rotor": 30, "quartic": 200}[wl]
-    dt = a.dt or (0.05 if wl == "rotor" else 0.02)
+    wl = {"schwinger": "schwinger", "gff": "gff", "rotor_hmc": "rotor", "quartic_hmc": "quartic", "ho_hmc": "harmonic"}[a.workload]
+    draws = a.cpu_draws or {"schwinger": 5, "gff": 40, "rotor": 30, "quartic": 200, "harmonic": 100000}[wl]
+    dt = a.dt or {"rotor": 0.05, "harmonic": 0.0558}.get(wl, 0.02)
     cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--workload", wl, "--size", str(size),
            "--draws", str(draws), "--n-overrelax", str(a.n_overrelax), "--n-heatbath", str(a.n_heatbath),
            "--nt", str(a.nt), "--dt", str(dt)]
@@ -65,8 +65,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    size = a.size or {"schwinger": 1024, "gff": 512, "rotor_hmc": 65536, "quartic_hmc": 32768}[a.workload]
-    B = a.chains or {"schwinger": 32, "gff": 1024, "rotor_hmc": 1024, "quartic_hmc": 2048}[a.workload]
+    size = a.size or {"schwinger": 1024, "gff": 512, "rotor_hmc": 65536, "quartic_hmc": 32768, "ho_hmc": 128}[a.workload]
+    B = a.chains or {"schwinger": 32, "gff": 1024, "rotor_hmc": 1024, "quartic_hmc": 2048, "ho_hmc": 8192}[a.workload]
 
     cpu = None
     if world == 1 and a.gpus == 1 and not a.no_cpu_baseline:
@@ -133,11 +133,13 @@ def main():
             return ops.qoi_phi_squared(state["x"])
         bytes_per_unit = 16.0  # each entry read once and written once per sweep
     else:
-        kind = abi.ROTOR if a.workload == "rotor_hmc" else abi.QUARTIC
-        T_final = size / 8.0  # a = 0.125
+        kind = {"rotor_hmc": abi.ROTOR, "quartic_hmc": abi.QUARTIC, "ho_hmc": abi.HARMONIC}[a.workload]
+        # a = 0.125 at the BASELINE sizes; config 1 (HO, M_lat = 128) keeps T_final = 4
+        T_final = 4.0 if a.workload == "ho_hmc" else size / 8.0
         act = abi.path_action(kind, size, T_final, 0.25 if kind == abi.ROTOR else 1.0, 1.0, 1.0, 1.0)
         x = ops.path_initialise(act, B, a.seed, chain0)
-        dt = a.dt or (0.05 if kind == abi.ROTOR else 0.02)
+        dt = a.dt or {abi.ROTOR: 0.05, abi.HARMONIC: 0.0558}.get(kind, 0.02)
+        draws_per_step = 10 if a.workload == "ho_hmc" else 1  # short paths: several draws per launch
         hmc = ops.PathHMC(act, B, a.nt, dt, seed=a.seed, chain0=chain0)
         # untimed thermalisation from the reference's cold / random start with small steps, so that the
         # timed trajectories run at a realistic acceptance rate (reported as p_accept)
@@ -145,14 +147,19 @@ def main():
             hmc.dt = dt * (0.2 if k < 16 else 0.5)
             hmc.draw(x, count_stats=False)
         hmc.dt = dt
-        units_per_step = size * (a.nt + 1) * B  # site-steps: one site x one force evaluation
+        units_per_step = size * (a.nt + 1) * B * draws_per_step  # site-steps: one site x one force evaluation
         fuse = 1
 
         def step(record):
             if record:
                 e0, e1 = ev(), ev()
                 e0.record()
-            hmc.draw(x)
+            if draws_per_step > 1:
+                q, cnt = ops.path_hmc_run(hmc, x, draws_per_step, 1)  # draws + QoIs in one launch
+                hmc.n_total += draws_per_step
+                hmc.n_accepted += cnt
+            else:
+                hmc.draw(x)
             if record:
                 e1.record()
                 or_events.append((e0, e1))

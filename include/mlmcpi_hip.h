@@ -121,8 +121,8 @@ int mlmcpi_path_hmc_draw(const mlmcpi_path_action *act, double *d_x, uint32_t B,
 /* n_draws consecutive HMCSampler::draw calls, each followed by a QoI evaluation -- the body of the loop
  * of MonteCarloSingleLevel::evaluate (montecarlo/montecarlosinglelevel.cc:59-77) -- without returning
  * to the host: for paths that fit one workgroup (M <= 8192, multiple of 64) everything, including the
- * Metropolis tests and the QoIs, runs in ONE launch with the state in registers throughout.  Results are
- * bit-identical to n_draws x (mlmcpi_path_hmc_draw with traj0 + d*n_rep, then the QoI kernel).
+ * Metropolis tests and the QoIs, runs in ONE launch with the state in registers throughout.  Results equal
+ * n_draws x (mlmcpi_path_hmc_draw with traj0 + d*n_rep, then the QoI kernel) up to fp contraction.
  *   qoi_kind  0 none, 1 QoIXsquared, 2 QoISusceptibility;  d_qoi [B*n_draws] (chain-major) for the
  *   one-launch path, [n_draws*B] (draw-major) for segmented paths -- see mlmcpi_path_hmc_run_layout();
  *   d_accept_count [B] int32 (optional): accepted draws per chain. */

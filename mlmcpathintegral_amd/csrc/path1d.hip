@@ -267,7 +267,7 @@ __global__ void __launch_bounds__(R >= 8 ? 512 : 1024)
 // (one workgroup per chain) in ONE launch, with the Metropolis test, the copy-on-accept and the QoI
 // of every draw done in-kernel.  Same arithmetic, same Philox counters (trajectory index
 // traj0 + d*n_rep + r) as n_draws calls of mlmcpi_path_hmc_draw followed by the QoI kernel, so the
-// two forms are bit-identical; this one removes ~2 launches and a host round trip per draw, which is
+// two forms agree to rounding; this one removes ~2 launches and a host round trip per draw, which is
 // what dominates for short paths (BASELINE config 1: M_lat = 128; the coarse levels of config 5).
 // qoi_kind: 0 none, 1 <x^2> (qoixsquared.cc:7-20), 2 susceptibility (qoisusceptibility.cc:8-23).
 template <int KIND, int R>

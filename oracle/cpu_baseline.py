@@ -32,6 +32,8 @@ def _worker(args):
     else:  # HMC, fixed dt (no auto-tune)
         if workload == "quartic":
             A = O.Action(O.QUARTIC, M=size, T_final=size / 8.0, m0=1.0, mu2=1.0, lam=1.0, x0=1.0)
+        elif workload == "harmonic":
+            A = O.Action(O.HARMONIC, M=size, T_final=4.0, m0=1.0, mu2=1.0)
         else:
             A = O.Action(O.ROTOR, M=size, T_final=size / 8.0, m0=0.25)
         units = size * (nt + 1)
