@@ -332,12 +332,13 @@ __global__ void __launch_bounds__(NT)
   const uint32_t ow = min(tg.TW, Mt - i0), oh = min(tg.TH, Mx - j0);
   const uint32_t bw = ow + 2 * H, bh = oh + 2 * H;
   double *phi = lds;
+  double *nrm = lds + (size_t)bw * bh;  // HEAT only: the second normal of each Box-Muller pair, by cell
   const uint32_t sc = (uint32_t)(((uint64_t)i0 + Mt - (H % Mt)) % Mt);
   const uint32_t sr = (uint32_t)(((uint64_t)j0 + Mx - (H % Mx)) % Mx);
   const double *src = in + (size_t)b * Mt * Mx;
   RngKey key = key0;
   key.chain += b;
-  const double kappa = 4. + mu2, sigma = 1. / sqrt(4. + mu2);
+  const double inv_kappa = 1. / (4. + mu2), two_over_kappa = 2. / (4. + mu2), sigma = 1. / sqrt(4. + mu2);
 
   stage_region<NT, (NT >= 1024 ? 3 : 5), double>(
       bh, bw, [&](uint32_t r, uint32_t c) { return src[(size_t)wrap_add(sr, r, Mx) * Mt + wrap_add(sc, c, Mt)]; },
@@ -360,12 +361,24 @@ __global__ void __launch_bounds__(NT)
         Delta += phi[o - bw];
         double v;
         if (heat) {
+          // One Philox call + one Box-Muller per vertex PAIR (l >> 1): the two vertices of a pair are
+          // horizontal neighbours (c, c ^ 1), hence of opposite colour.  The colour-0 phase draws the pair
+          // and parks the partner's normal in LDS; the colour-1 phase picks it up.  Only partners in the
+          // outermost buffer columns (never updated in the first phase) draw the pair themselves.
           const uint32_t ell = wrap_add(sr, r, Mx) * Mt + wrap_add(sc, c, Mt);
-          double n0, n1;
-          rng_normals(skey, ell >> 1, P_GFF_NORMAL, 0, n0, n1);
-          v = sigma * ((ell & 1u) ? n1 : n0) + Delta / kappa;
+          const uint32_t cpart = c ^ 1u;
+          double mine;
+          if (colour == 0 || cpart == 0 || cpart == bw - 1) {
+            double n0, n1;
+            rng_normals(skey, ell >> 1, P_GFF_NORMAL, 0, n0, n1);
+            mine = (ell & 1u) ? n1 : n0;
+            if (colour == 0) nrm[r * bw + cpart] = (ell & 1u) ? n0 : n1;
+          } else {
+            mine = nrm[o];
+          }
+          v = fma(Delta, inv_kappa, sigma * mine);
         } else {
-          v = 2. * Delta / kappa - phi[o];
+          v = fma(two_over_kappa, Delta, -phi[o]);  // 2 Delta / kappa - phi without the fp64 division
         }
         phi[o] = v;
       });
@@ -375,6 +388,63 @@ __global__ void __launch_bounds__(NT)
 
   double *dst = out + (size_t)b * Mt * Mx;
   for_region<NT>(oh, ow, [&](uint32_t r, uint32_t c) { dst[(size_t)(j0 + r) * Mt + (i0 + c)] = phi[(r + H) * bw + (c + H)]; });
+}
+
+// ---- GFF overrelaxation, specialised --------------------------------------------------------------------
+// Compile-time tile geometry, per-thread cell offsets computed once, immediate neighbour offsets:
+// bit-identical to gff_sweep_kernel<false, 256> (same colour order and update regions).  The update is
+// 4 adds and one fused multiply-add, so anything per-update besides the LDS traffic matters.
+template <int TW, int TH, int K, int NT>
+__global__ void __launch_bounds__(NT)
+    gff_or_kernel(uint32_t Mt, uint32_t Mx, double mu2, const double *__restrict__ in, double *__restrict__ out,
+                  uint32_t tiles_x) {
+  constexpr int H = 2 * K, BW = TW + 2 * H, BH = TH + 2 * H, P = BW + 1;
+  constexpr int NRR = BH - 2, NCC = (BW - 2) / 2, T = NRR * NCC, M = (T + NT - 1) / NT;
+  extern __shared__ double lds[];
+  double *phi = lds;
+  const uint32_t tile = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
+  const uint32_t i0 = tx * TW, j0 = ty * TH;
+  const uint32_t sc = (uint32_t)(((uint64_t)i0 + Mt - (H % Mt)) % Mt);
+  const uint32_t sr = (uint32_t)(((uint64_t)j0 + Mx - (H % Mx)) % Mx);
+  const double *src = in + (size_t)b * Mt * Mx;
+  const double two_over_kappa = 2. / (4. + mu2);
+
+  stage_region<NT, 5, double>(
+      BH, BW, [&](uint32_t r, uint32_t c) { return src[(size_t)wrap_add(sr, r, Mx) * Mt + wrap_add(sc, c, Mt)]; },
+      [&](uint32_t r, uint32_t c, double v) { phi[r * P + c] = v; });
+
+  // cell (r, c) of colour 0: r = 1 + ri, c = 1 + ((r + 1) & 1) + 2 ci; colour 1: the other cell of the pair
+  int o0[M], o1[M];
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    const int idx = tid + NT * m, ri = idx / NCC, ci = idx - ri * NCC, r = 1 + ri;
+    o0[m] = r * P + 1 + ((r + 1) & 1) + 2 * ci;
+    o1[m] = r * P + 1 + (r & 1) + 2 * ci;
+  }
+  __syncthreads();
+
+  for (int s = 0; s < K; ++s) {
+#pragma unroll
+    for (int colour = 0; colour < 2; ++colour) {
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        if ((m + 1) * NT <= T || (int)tid + NT * m < T) {
+          double *q = phi + (colour ? o1[m] : o0[m]);
+          double Delta = 0.0;
+          Delta += q[1];
+          Delta += q[-1];
+          Delta += q[P];
+          Delta += q[-P];
+          q[0] = fma(two_over_kappa, Delta, -q[0]);  // 2 Delta / kappa - phi, without the fp64 division
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  double *dst = out + (size_t)b * Mt * Mx;
+  for_region<NT>(TH, TW, [&](uint32_t r, uint32_t c) { dst[(size_t)(j0 + r) * Mt + (i0 + c)] = phi[(r + H) * P + (c + H)]; });
 }
 
 // ---- streaming kernels: evaluate, force, QoI ----------------------------------------------------------
@@ -556,7 +626,7 @@ struct SweepGeom {
 // Tile shape and workgroup size for a launch of `nsweeps` fused sweeps.  Default: 64 x 32 owned sites,
 // 256 threads (4 workgroups per CU at one sweep).  MLMCPI_SWEEP_TILE=TWxTHxNT overrides (tuning knob;
 // results never depend on it).
-static SweepGeom choose_geometry(uint32_t Mt, uint32_t Mx, uint32_t nsweeps, bool schw) {
+static SweepGeom choose_geometry(uint32_t Mt, uint32_t Mx, uint32_t nsweeps, uint32_t bytes_per_cell) {
   uint32_t TW = 64, TH = 32, NT = 256;
   bool overridden = false;
   if (const char *e = getenv("MLMCPI_SWEEP_TILE")) {
@@ -574,7 +644,7 @@ static SweepGeom choose_geometry(uint32_t Mt, uint32_t Mx, uint32_t nsweeps, boo
   g.tg.tiles_x = (Mt + g.tg.TW - 1) / g.tg.TW;
   g.tiles_y = (Mx + g.tg.TH - 1) / g.tg.TH;
   g.NT = NT;
-  g.lds_bytes = (size_t)(g.tg.TW + 4 * nsweeps) * (g.tg.TH + 4 * nsweeps) * (schw ? 16 : 8);
+  g.lds_bytes = (size_t)(g.tg.TW + 4 * nsweeps) * (g.tg.TH + 4 * nsweeps) * bytes_per_cell;
   return g;
 }
 
@@ -691,14 +761,16 @@ static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, doub
   while (s < total) {
     uint32_t n = total - s < fuse ? total - s : fuse;
     SweepGeom g;
+    uint32_t kinds = 0;
     for (;;) {  // shrink the fused count until the tile + halo fits in LDS
-      g = choose_geometry(act->Mt, act->Mx, n, schw);
+      kinds = 0;
+      for (uint32_t q = 0; q < n; ++q)
+        if (s + q >= n_overrelax) kinds |= 1u << q;
+      // Schwinger: two link angles per site; GFF heat bath: field + parked normal per site
+      g = choose_geometry(act->Mt, act->Mx, n, (schw || kinds) ? 16 : 8);
       if (g.lds_bytes <= 160 * 1024 || n == 1) break;
       --n;
     }
-    uint32_t kinds = 0;
-    for (uint32_t q = 0; q < n; ++q)
-      if (s + q >= n_overrelax) kinds |= 1u << q;
     const RngKey key = make_key(seed, chain0, sweep0 + s);
     dim3 grid(g.tg.tiles_x * g.tiles_y, B);
     int rc;
@@ -723,6 +795,18 @@ static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, doub
 #undef MLMCPI_OR_K
 #undef MLMCPI_OR
       MLMCPI_LAUNCH_CHECK("schwinger_or_kernel");
+      rc = MLMCPI_OK;
+    } else if (!schw && !kinds && !g.overridden && act->Mt % 64 == 0 && act->Mx % 32 == 0 && n <= 4) {
+      const size_t lds = (size_t)(32 + 4 * n) * (64 + 4 * n + 1) * sizeof(double);
+      dim3 sgrid((act->Mt / 64) * (act->Mx / 32), B);
+      const double mu2 = gff_mu2(*act);
+      switch (n) {
+        case 1: hipLaunchKernelGGL((gff_or_kernel<64, 32, 1, 256>), sgrid, dim3(256), lds, st, act->Mt, act->Mx, mu2, (const double *)src, dst, act->Mt / 64); break;
+        case 2: hipLaunchKernelGGL((gff_or_kernel<64, 32, 2, 256>), sgrid, dim3(256), lds, st, act->Mt, act->Mx, mu2, (const double *)src, dst, act->Mt / 64); break;
+        case 3: hipLaunchKernelGGL((gff_or_kernel<64, 32, 3, 256>), sgrid, dim3(256), lds, st, act->Mt, act->Mx, mu2, (const double *)src, dst, act->Mt / 64); break;
+        default: hipLaunchKernelGGL((gff_or_kernel<64, 32, 4, 256>), sgrid, dim3(256), lds, st, act->Mt, act->Mx, mu2, (const double *)src, dst, act->Mt / 64);
+      }
+      MLMCPI_LAUNCH_CHECK("gff_or_kernel");
       rc = MLMCPI_OK;
     } else
     // launches without a heat-bath sweep use the lean instantiation (no sampler code, fewer VGPRs)

@@ -415,7 +415,8 @@ SWEEP_CASES = [
     # several tiles with ragged edges, rectangular Schwinger lattices
     ("gff", 4, 4, dict(mass=10.0), 2),
     ("gff", 16, 16, dict(mass=10.0), 3),
-    ("gff", 64, 64, dict(mass=10.0), 2),
+    ("gff", 64, 64, dict(mass=10.0), 2),   # specialised overrelaxation kernel, 1 x 2 tiles
+    ("gff", 128, 128, dict(mass=3.0), 1),  # 2 x 4 tiles
     ("gff", 130, 130, dict(mass=10.0), 1),
     ("schwinger", 4, 4, dict(beta=1.0), 2),
     ("schwinger", 16, 16, dict(beta=1.0), 3),
@@ -544,6 +545,13 @@ def test_rotor_65536_and_gff_512_properties(gpu_ops):
     gpu_ops.lattice_sweep_draw(act, a, scratch, 6, 1, SEED, 0, 0, fuse=1)
     gpu_ops.lattice_sweep_draw(act, b, scratch, 6, 1, SEED, 0, 0, fuse=4)
     assert torch.equal(a, b)
+    os.environ["MLMCPI_SWEEP_TILE"] = "64x32x256"  # generic kernels
+    try:
+        gen = phi.clone()
+        gpu_ops.lattice_sweep_draw(act, gen, scratch, 6, 1, SEED, 0, 0, fuse=2)
+    finally:
+        del os.environ["MLMCPI_SWEEP_TILE"]
+    assert torch.equal(a, gen), "specialised and generic GFF kernels must agree bit for bit"
     c = phi.clone()
     gpu_ops.lattice_sweep_draw(act, c, scratch, 6, 0, SEED, 0, 0, fuse=3)
     assert_close(gpu_ops.lattice_evaluate(act, c).cpu().numpy(), S0, tol=1e-11, what="GFF OR conserves S")
