@@ -70,11 +70,11 @@ __device__ __forceinline__ void stage_region(uint32_t nr, uint32_t nc, Load load
 }
 
 // Heat-bath colour phase as a per-lane work queue.  Each thread owns up to S cells of the region
-// (linear index tid + 256 m).  Their conditional parameters are set up first (no divergence), then
-// every lane runs rejection attempts on its CURRENT cell and moves on to its next cell as soon as one
-// is accepted, so a wave iterates max-over-lanes(sum of attempts) times instead of
-// sum-over-cells(max-over-lanes attempts); the arccosine and the LDS write-back run once per cell
-// afterwards, again without divergence.  Which random numbers a cell consumes is fixed by
+// (linear index tid + NT m).  Their conditional parameters are set up first (no divergence), every cell
+// gets its first attempt in straight-line code, then every lane runs further rejection attempts on its
+// lowest PENDING cell and moves on as soon as one is accepted, so a wave iterates
+// max-over-lanes(sum of extra attempts) times instead of sum-over-cells(max-over-lanes attempts); the
+// arccosine and the LDS write-back run once per cell afterwards, again without divergence.  Which random numbers a cell consumes is fixed by
 // (site, attempt), so the result does not depend on this scheduling.
 template <int NT, int S, class Setup, class Commit>
 __device__ __forceinline__ void heatbath_region(uint32_t nr, uint32_t nc, const RngKey &key, Setup setup,
@@ -98,10 +98,19 @@ __device__ __forceinline__ void heatbath_region(uint32_t nr, uint32_t nc, const 
         n = m + 1;
       }
     }
-    int cur = 0;
-    uint32_t attempt = 0;
-    while (__ballot(cur < n) != 0ull) {
-      if (cur < n) {
+    // First attempt of every cell in straight-line code (about 5 in 6 proposals are accepted at once, and
+    // the S independent chains give the scheduler instruction-level parallelism) ...
+    uint32_t pending = 0;
+#pragma unroll
+    for (int m = 0; m < S; ++m) {
+      if (m < n && !vm_attempt(key, site[m], 0, kap[m], env[m], fv[m], neg[m])) pending |= 1u << m;
+    }
+    // ... then the per-lane queue over the cells still pending: every lane retries its lowest pending
+    // cell and moves on when it is accepted.
+    uint32_t attempt = 1;
+    while (__ballot(pending != 0u) != 0ull) {
+      if (pending != 0u) {
+        const int cur = __ffs(pending) - 1;
         double k_ = kap[0], r_ = env[0];
         uint32_t s_ = site[0];
 #pragma unroll
@@ -113,8 +122,8 @@ __device__ __forceinline__ void heatbath_region(uint32_t nr, uint32_t nc, const 
 #pragma unroll
           for (int m = 0; m < S; ++m)
             if (cur == m) { fv[m] = f; neg[m] = ng; }
-          ++cur;
-          attempt = 0;
+          pending &= pending - 1u;
+          attempt = 1;
         } else {
           ++attempt;
         }
@@ -144,7 +153,7 @@ __device__ __forceinline__ uint32_t wrap_add(uint32_t base, uint32_t off, uint32
 // two sites per side per sweep, so a halo of 2*nsweeps keeps the owned tile exact (tile origins are
 // even, which makes buffer parity equal lattice parity).
 template <bool HEAT, int NT>
-__global__ void __launch_bounds__(NT)
+__global__ void __launch_bounds__(NT, (HEAT && NT == 256) ? 4 : 1)
     schwinger_sweep_kernel(uint32_t Mt, uint32_t Mx, double beta, const double2 *__restrict__ in,
                            double2 *__restrict__ out, TileGeom tg, uint32_t nsweeps, uint32_t kinds, RngKey key0) {
   extern __shared__ double lds[];
