@@ -230,10 +230,15 @@ def main():
                                       "launch_ms": launch_ms, "algorithmic_bytes_per_launch": alg,
                                       "updates_per_s": sites * B * fuse / (launch_ms * 1e-3)}
             hb_ms = ms(hb_events)
+            if n_launch:
+                result["roofline"]["share_of_step"] = or_ms / a.steps / (1e3 * elapsed / a.steps)
             if a.n_heatbath:
                 result["heatbath"] = {"launch_ms": hb_ms / (a.steps * a.n_heatbath),
                                       "updates_per_s": sites * B * a.n_heatbath * a.steps / (hb_ms * 1e-3),
-                                      "note": "fp64 transcendental (VALU) bound, not HBM bound (SURVEY F9)"}
+                                      "share_of_step": hb_ms / a.steps / (1e3 * elapsed / a.steps),
+                                      "algorithmic_GBps": 16.0 * sites * B * a.n_heatbath * a.steps / (hb_ms * 1e-3) / 1e9,
+                                      "note": "fp64 VALU bound (Philox + von Mises rejection sampler), not HBM bound "
+                                              "(SURVEY F9); ~70 % VALU-active in the PMC profile"}
         else:
             launch_ms = or_ms / a.steps
             alg = bytes_per_unit * units_per_step

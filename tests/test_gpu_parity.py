@@ -413,11 +413,14 @@ def test_lattice_initialise(gpu_ops, orc):
 SWEEP_CASES = [
     # kind, Mt, Mx, params, B  -- tiny lattices (buffer wraps around the torus several times), one tile,
     # several tiles with ragged edges, rectangular Schwinger lattices
+    ("gff", 2, 2, dict(mass=1.0), 2),      # smallest lattice: every neighbour is the same vertex twice
     ("gff", 4, 4, dict(mass=10.0), 2),
     ("gff", 16, 16, dict(mass=10.0), 3),
     ("gff", 64, 64, dict(mass=10.0), 2),   # specialised overrelaxation kernel, 1 x 2 tiles
     ("gff", 128, 128, dict(mass=3.0), 1),  # 2 x 4 tiles
     ("gff", 130, 130, dict(mass=10.0), 1),
+    ("schwinger", 2, 2, dict(beta=1.0), 2),
+    ("schwinger", 2, 8, dict(beta=0.7), 1),
     ("schwinger", 4, 4, dict(beta=1.0), 2),
     ("schwinger", 16, 16, dict(beta=1.0), 3),
     ("schwinger", 6, 10, dict(beta=4.0), 2),
@@ -460,6 +463,34 @@ def test_pingpong_sweeps_equal_copy_form(gpu_ops):
             gpu_ops.lattice_sweep_draw(act, a, torch.empty_like(a), n_or, n_hb, SEED, 0, 5)
             res, other = gpu_ops.lattice_sweep_draw_pingpong(act, b, torch.empty_like(b), n_or, n_hb, SEED, 0, 5)
             assert torch.equal(res, a) and res.data_ptr() != other.data_ptr()
+
+
+def test_invalid_arguments_are_errors(gpu_ops):
+    """Bad sizes, null pointers and unsupported geometries return an error status (never a fault)."""
+    import ctypes as C
+    from mlmcpathintegral_amd import abi
+    z = C.c_void_p(0)
+    x = torch.zeros((1, 64), dtype=torch.float64, device="cuda")
+    p = C.c_void_p(x.data_ptr())
+    act = abi.path_action(1, 64, 8.0, 1.0, 1.0, 1.0, 1.0)
+    with pytest.raises(abi.MlmcpiError):
+        abi.call("mlmcpi_path_evaluate", C.byref(act), p, 0, p, z)          # B = 0
+    with pytest.raises(abi.MlmcpiError):
+        abi.call("mlmcpi_path_evaluate", C.byref(act), z, 1, p, z)          # null state
+    with pytest.raises(abi.MlmcpiError):
+        abi.call("mlmcpi_path_force", C.byref(act), p, p, 1, z)             # in-place force
+    with pytest.raises(abi.MlmcpiError):
+        abi.call("mlmcpi_path_evaluate", C.byref(abi.path_action(1, 1, 8.0)), p, 1, p, z)   # M_lat < 2
+    with pytest.raises(abi.MlmcpiError):
+        abi.call("mlmcpi_path_evaluate", C.byref(abi.path_action(1, 64, -1.0)), p, 1, p, z)  # T_final <= 0
+    with pytest.raises(abi.MlmcpiError):
+        abi.call("mlmcpi_path_evaluate", C.byref(abi.path_action(4, 64, 8.0)), p, 1, p, z)   # 2-D kind on a path call
+    with pytest.raises(abi.MlmcpiError, match="too long"):
+        gpu_ops.PathHMC(abi.path_action(2, 65536, 8192.0, 0.25), 1, 5000, 0.1)              # nt beyond the fused halo
+    with pytest.raises(abi.MlmcpiError):
+        y = torch.zeros((1, 128), dtype=torch.float64, device="cuda")
+        q = C.c_void_p(y.data_ptr())
+        abi.call("mlmcpi_lattice_sweep_draw", C.byref(abi.lattice_action(4, 8, 8, beta=1.0)), q, q, 1, 1, 0, 1, 0, 0, 0, z)  # state == scratch
 
 
 def test_sweep_rejects_odd_lattice(gpu_ops):
