@@ -313,6 +313,50 @@ def test_twolevel_step_matches_oracle(gpu_ops, orc, name, M, B):
         assert seen == {0, 1}
 
 
+def test_config5_hierarchy_matches_oracle(gpu_ops, orc):
+    """BASELINE config 5 shape: quartic double well, 5 levels, finest M_lat = 32768 (T_final = 4096, a = 0.125),
+    hierarchical sampling (sampler/hierarchicalsampler.cc:55-81): HMC on the coarsest level (M_lat = 2048), then
+    one TwoLevelMetropolisStep per finer level.  Two full hierarchical draws, chain by chain against the
+    oracle's device-order restatement of the same composition."""
+    from mlmcpathintegral_amd import abi
+    L, M0, T, B, nt, dt = 5, 32768, 4096.0, 2, 100, 0.095
+    par = dict(m0=1.0, mu2=1.0, lam=1.0, x0=1.0)
+    acts, oras = [], []
+    for ell in range(L):
+        M = M0 >> ell
+        acts.append(abi.path_action(1, M, T, 1.0, 1.0, 1.0, 1.0))
+        oras.append(orc.Action(orc.QUARTIC, M=M, T_final=T, **par))
+    rng = np.random.default_rng(5)
+    # a smooth fine-level start (coarse random walk, interpolated) so that acceptance is not degenerate
+    coarse = np.cumsum(rng.normal(0, 0.2, (B, M0 >> 6)), axis=1)
+    coarse -= np.linspace(0, 1, M0 >> 6)[None, :] * (coarse[:, -1:] - coarse[:, :1])  # periodic
+    x_fine = 1.0 + 0.3 * np.repeat(coarse, 64, axis=1) + rng.normal(0, 0.02, (B, M0))
+    hmc = gpu_ops.PathHMC(acts[-1], B, nt, dt, seed=SEED, chain0=0)
+    steps = [gpu_ops.PathTwoLevelStep(acts[ell], acts[ell + 1], B, seed=SEED + ell + 1, chain0=0) for ell in range(L - 1)]
+    state = [dev(x_fine[:, :: (1 << ell)]) for ell in range(L)]          # copy_from_fine down the hierarchy
+    host = [x_fine[:, :: (1 << ell)].copy() for ell in range(L)]
+    outcomes = []
+    for draw in range(2):
+        for ell in range(1, L):                                          # hierarchicalsampler.cc:57-60
+            state[ell].copy_(state[ell - 1][:, ::2])
+            host[ell] = host[ell - 1][:, ::2].copy()
+        acc = hmc.draw(state[L - 1]).cpu().numpy()
+        for b in range(B):
+            a, _, _ = oras[-1].dev_hmc_trajectory(host[L - 1][b], nt, dt, SEED, b, draw)
+            assert a == acc[b]
+        assert_close(state[L - 1].cpu().numpy(), host[L - 1], tol=1e-9, what="coarsest level after HMC")
+        for ell in range(L - 2, -1, -1):
+            steps[ell].set_state(state[ell])
+            acc = steps[ell].draw(state[ell + 1]).cpu().numpy()
+            state[ell].copy_(steps[ell].theta)
+            for b in range(B):
+                a, terms = oras[ell].dev_twolevel_draw(oras[ell + 1], host[ell + 1][b], host[ell][b], SEED + ell + 1, b, draw)
+                assert a == acc[b], (draw, ell, b, terms)
+                outcomes.append(a)
+            assert_close(state[ell].cpu().numpy(), host[ell], tol=1e-9, what=f"level {ell} after two-level step")
+    assert len(outcomes) == 2 * (L - 1) * B
+
+
 def test_twolevel_step_errors(gpu_ops):
     from mlmcpathintegral_amd import abi
     with pytest.raises(abi.MlmcpiError, match="not defined for the rotor"):
