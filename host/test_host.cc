@@ -97,6 +97,20 @@ int main(int argc, char **argv) {
     fill_sin(phi);
     EXPECT(close(gff->getmu2(), 6.25) && close(gff->evaluate(phi), 41.88143013055145), "gff S");
     EXPECT(close(QoI2DPhiSquared(lat).evaluate(phi), 0.49705796311310979), "phi2");
+    // coarse action of the 4 x 4 lattice has beta = 0.25; copy_from_fine of the recorded state
+    {
+      auto cact = std::dynamic_pointer_cast<QuenchedSchwingerAction>(act->coarse_action());
+      EXPECT(cact && close(cact->getbeta(), 0.25) && cact->sample_size() == 8, "coarse Schwinger action");
+      fill_sin(x);
+      x->data[0] = 0.61274301029796319; x->data[1] = -0.4828159090156936;
+      x->data[2] = -0.58943551973302177; x->data[3] = -1.1740400357754384;
+      auto xc = std::make_shared<SampleState>(8);
+      cact->copy_from_fine(x, xc);
+      const double want_c[4] = {0.023307490564941413, -1.0268370199050634, -0.30193767594434939, 0.71119185749594449};
+      for (int k = 0; k < 4; ++k) EXPECT(close(xc->data[k], want_c[k], 1e-14), "coarse link %d = %.17g", k, (double)xc->data[k]);
+      act->copy_from_coarse(xc, x);
+      EXPECT(close(x->data[0], 0.5 * want_c[0], 1e-14) && close(x->data[2], 0.5 * want_c[0], 1e-14), "copy_from_coarse halves the link");
+    }
     auto rot = std::make_shared<Lattice2D>(4, 4, CoarsenRotate)->get_coarse_lattice();
     const unsigned want_rot[8] = {4, 6, 5, 7, 1, 1, 2, 2};
     EXPECT(rot && rot->is_rotated() && rot->getNvertices() == 8, "rotated coarse lattice");

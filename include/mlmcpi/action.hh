@@ -49,6 +49,9 @@ public:
   virtual void sweep(std::shared_ptr<SampleState>, std::shared_ptr<SampleState>, unsigned, unsigned, uint32_t) {
     fatal("overrelaxation update not implemented for this action");
   }
+  /** action.hh:130-143: transfers between this level and the next coarser / finer one */
+  virtual void copy_from_coarse(const std::shared_ptr<SampleState>, std::shared_ptr<SampleState>) { fatal("cannot copy from coarse lattice."); }
+  virtual void copy_from_fine(const std::shared_ptr<SampleState>, std::shared_ptr<SampleState>) { fatal("cannot copy from fine lattice."); }
   const std::vector<unsigned int> &get_heatbath_indexset() const { return heatbath_indexset; }
   virtual int get_coarsening_level() const = 0;
   virtual std::string info_string() const = 0;
@@ -92,6 +95,15 @@ public:
   }
   void initialise_state(std::shared_ptr<SampleState> x) const override {
     check(mlmcpi_path_initialise(&abi, x->device_mutable(), x->batch(), seed, chain0, nullptr), "path_initialise");
+  }
+  /** action/qm/qmaction.cc:7-24 */
+  void copy_from_coarse(const std::shared_ptr<SampleState> x_coarse, std::shared_ptr<SampleState> x_path) override {
+    if (x_path->size() != M_lat || 2 * x_coarse->size() != M_lat) fatal("cannot copy from coarse lattice.");
+    check(mlmcpi_path_copy_from_coarse(x_coarse->device(), x_path->device_mutable(), M_lat / 2, x_path->batch(), nullptr), "path_copy_from_coarse");
+  }
+  void copy_from_fine(const std::shared_ptr<SampleState> x_fine, std::shared_ptr<SampleState> x_path) override {
+    if (x_path->size() != M_lat || x_fine->size() != 2 * M_lat) fatal("cannot copy from fine lattice.");
+    check(mlmcpi_path_copy_from_fine(x_fine->device(), x_path->device_mutable(), M_lat, x_path->batch(), nullptr), "path_copy_from_fine");
   }
   std::string info_string() const override {
     std::stringstream s;
@@ -197,6 +209,21 @@ public:
                                              n_hb, seed, chain0, sweep0, fuse, &in_scratch, nullptr), "lattice_sweep_draw");
     if (in_scratch) phi->swap_device(*scratch);  // no copy: the buffers exchange roles
   }
+  /** quenchedschwingeraction.cc:92-195, gffaction.cc:97-118: `this` is the level being written to */
+  void copy_from_coarse(const std::shared_ptr<SampleState> phi_coarse, std::shared_ptr<SampleState> phi_state) override {
+    unsigned rt = 0, rx = 0;
+    if (!factors(lattice, phi_coarse, rt, rx)) fatal("cannot copy from coarse lattice.");
+    check(mlmcpi_lattice_copy_from_coarse(&abi, rt, rx, phi_coarse->device(), phi_state->device_mutable(), phi_state->batch(), nullptr), "lattice_copy_from_coarse");
+  }
+  void copy_from_fine(const std::shared_ptr<SampleState> phi_fine, std::shared_ptr<SampleState> phi_state) override {
+    if (!fine_lattice) fatal("cannot copy from fine lattice.");
+    mlmcpi_lattice_action fine_abi = abi;
+    fine_abi.Mt = fine_lattice->getMt_lat();
+    fine_abi.Mx = fine_lattice->getMx_lat();
+    const unsigned rt = fine_abi.Mt / abi.Mt, rx = fine_abi.Mx / abi.Mx;
+    if (rt * abi.Mt != fine_abi.Mt || rx * abi.Mx != fine_abi.Mx || rt * rx < 2 || rt > 2 || rx > 2) fatal("cannot copy from fine lattice.");
+    check(mlmcpi_lattice_copy_from_fine(&fine_abi, rt, rx, phi_fine->device(), phi_state->device_mutable(), phi_state->batch(), nullptr), "lattice_copy_from_fine");
+  }
   std::string info_string() const override {
     std::stringstream s;
     s << "Mt_lat = " << abi.Mt << ", Mx_lat = " << abi.Mx;
@@ -205,6 +232,15 @@ public:
   unsigned fuse = 0;  // sweeps fused per launch (0 = library default); results do not depend on it
 
 protected:
+  /** coarsening factors between `fine` (this level's lattice) and the state of the next-coarser level */
+  bool factors(const std::shared_ptr<Lattice2D> fine, const std::shared_ptr<SampleState> coarse_state, unsigned &rt, unsigned &rx) const {
+    auto c = fine->get_coarse_lattice();
+    if (!c || c->is_rotated()) return false;
+    rt = fine->getMt_lat() / c->getMt_lat();
+    rx = fine->getMx_lat() / c->getMx_lat();
+    const unsigned per = (abi.kind == MLMCPI_SCHWINGER) ? 2u : 1u;
+    return coarse_state->size() == per * c->getMt_lat() * c->getMx_lat() && rt * rx >= 2;
+  }
   const std::shared_ptr<Lattice2D> lattice, fine_lattice;
   mlmcpi_lattice_action abi;
 };
@@ -241,6 +277,20 @@ public:
   }
   unsigned int sample_size() const override { return lattice->getNedges(); }
   double getbeta() const { return beta; }
+  /** quenchedschwingeraction.hh:147-165 with RenormalisedQuenchedSchwingerParameters::beta_coarse
+   *  (quenchedschwingerrenormalisation.hh:52-83): beta/4 when both directions are coarsened, beta/2
+   *  otherwise; the perturbative correction applies for beta > 4.  (The non-perturbative matching needs a
+   *  GSL root finder and is not reproduced.) */
+  std::shared_ptr<Action> coarse_action() override {
+    std::shared_ptr<Lattice2D> coarse_lattice = lattice->get_coarse_lattice();
+    if (!coarse_lattice)
+      fatal("cannot coarsen 2d lattice with M_{t,lat} = " + std::to_string(lattice->getMt_lat()) + " , M_{x,lat} = " + std::to_string(lattice->getMx_lat()) + ".");
+    const bool both = lattice->get_coarsening_type() == CoarsenBoth;
+    double beta_c = (both ? 0.25 : 0.5) * beta;
+    if (renormalisation == RenormalisationPerturbative && beta > 4.0) beta_c = (both ? 0.25 : 0.5) * (1. + (both ? 1.5 : 0.5) / beta) * beta;
+    if (renormalisation == RenormalisationNonperturbative && beta > 4.0) fatal("nonperturbative renormalisation of beta is not available");
+    return std::make_shared<QuenchedSchwingerAction>(coarse_lattice, lattice, renormalisation, beta_c);
+  }
   std::string info_string() const override { return QFTAction::info_string() + ", beta = " + std::to_string(beta); }
 
 private:

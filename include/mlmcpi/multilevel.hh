@@ -138,7 +138,7 @@ public:
   /** hierarchicalsampler.cc:55-81 */
   void draw(std::shared_ptr<SampleState> phi_state) override {
     accept = true;
-    for (unsigned int ell = 1; ell < n_level; ++ell) copy_from_fine(phi_sampler_state[ell - 1], phi_sampler_state[ell]);
+    for (unsigned int ell = 1; ell < n_level; ++ell) action[ell]->copy_from_fine(phi_sampler_state[ell - 1], phi_sampler_state[ell]);
     for (int ell = (int)n_level - 1; ell >= 0; --ell) {
       if (ell == (int)n_level - 1) {
         coarse_sampler->set_state(phi_sampler_state[ell]);
@@ -162,14 +162,6 @@ public:
     std::cout << "  acceptance rate = " << p_accept() << std::endl;
     for (unsigned int ell = 0; ell < n_level; ++ell)
       std::cout << "  level " << ell << " : p = " << (ell == n_level - 1 ? coarse_sampler->p_accept() : twolevel_step[ell]->p_accept()) << std::endl;
-  }
-
-  /** QMAction::copy_from_fine (action/qm/qmaction.cc:16-24): x_coarse[j] = x_fine[2j].  Host-side strided
-   *  copy through the lazy mirror (levels are small compared with a trajectory; a device kernel is next). */
-  static void copy_from_fine(const std::shared_ptr<SampleState> fine, std::shared_ptr<SampleState> coarse) {
-    const size_t Mc = coarse->size(), B = coarse->batch();
-    for (size_t b = 0; b < B; ++b)
-      for (size_t j = 0; j < Mc; ++j) coarse->data[b * Mc + j] = static_cast<const SampleState::Data &>(fine->data)[b * 2 * Mc + 2 * j];
   }
 
 private:

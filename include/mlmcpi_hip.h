@@ -155,6 +155,11 @@ int mlmcpi_path_twolevel_draw(const mlmcpi_path_action *fine, const mlmcpi_path_
                               double *d_theta, uint32_t B, uint64_t seed, uint32_t chain0, uint32_t step, void *d_work,
                               int32_t *d_accept, double *d_terms, void *stream);
 
+/* QMAction::copy_from_fine / copy_from_coarse (action/qm/qmaction.cc:7-24): coarse[j] <-> fine[2j]; the odd
+ * fine sites are left untouched.  d_fine [B*2*M_coarse], d_coarse [B*M_coarse]. */
+int mlmcpi_path_copy_from_fine(const double *d_fine, double *d_coarse, uint32_t M_coarse, uint32_t B, void *stream);
+int mlmcpi_path_copy_from_coarse(const double *d_coarse, double *d_fine, uint32_t M_coarse, uint32_t B, void *stream);
+
 /* ---- 2-D lattices --------------------------------------------------------------------------- */
 int mlmcpi_lattice_state_size(const mlmcpi_lattice_action *act, uint32_t *n); /* Action::sample_size */
 int mlmcpi_lattice_evaluate(const mlmcpi_lattice_action *act, const double *d_phi, uint32_t B, double *d_S,
@@ -181,6 +186,16 @@ int mlmcpi_lattice_sweep_draw(const mlmcpi_lattice_action *act, double *d_phi, d
 int mlmcpi_lattice_sweep_draw_pingpong(const mlmcpi_lattice_action *act, double *d_a, double *d_b, uint32_t B,
                                        uint32_t n_overrelax, uint32_t n_heatbath, uint64_t seed, uint32_t chain0,
                                        uint32_t sweep0, uint32_t fuse, int32_t *result_in_b, void *stream);
+/* Action::copy_from_fine / copy_from_coarse between a lattice and its next-coarser level, coarsening
+ * factors rt, rx in {1, 2} in the temporal / spatial direction (CoarsenBoth = 2,2; CoarsenTemporal = 2,1;
+ * CoarsenSpatial = 1,2; lattice/lattice2d.cc:24-47).  `fine` describes the FINE lattice.
+ *   Schwinger (quenchedschwingeraction.cc:92-195): coarse links = mod_2pi(sum of the fine links they span);
+ *     copy_from_coarse halves a coarse link over its two fine links and leaves the fine-only links untouched.
+ *   GFF (gffaction.cc:97-118): vertices (rt i, rx j) <-> (i, j). */
+int mlmcpi_lattice_copy_from_fine(const mlmcpi_lattice_action *fine, uint32_t rt, uint32_t rx, const double *d_fine,
+                                  double *d_coarse, uint32_t B, void *stream);
+int mlmcpi_lattice_copy_from_coarse(const mlmcpi_lattice_action *fine, uint32_t rt, uint32_t rx, const double *d_coarse,
+                                    double *d_fine, uint32_t B, void *stream);
 /* QoI2DPhiSquared (qoi/qft/qoi2dphisquared.cc:8-15), QoIAvgPlaquette (qoi/qft/qoiavgplaquette.cc:8-27),
  * QoI2DSusceptibility (qoi/qft/qoi2dsusceptibility.cc:8-27); d_out[b]. */
 int mlmcpi_qoi_phi_squared(const double *d_phi, uint32_t n_vertices, uint32_t B, double *d_out, void *stream);

@@ -589,6 +589,15 @@ __global__ void stats_accumulate_kernel(double *__restrict__ acc, const double *
 }
 
 // ---- host dispatch ----------------------------------------------------------------------------------------
+static int check_lattice_dims(const mlmcpi_lattice_action *act) {
+  if (!act) return fail(MLMCPI_ERR_INVALID, "action is NULL");
+  if (act->kind != MLMCPI_GFF && act->kind != MLMCPI_SCHWINGER)
+    return fail(MLMCPI_ERR_INVALID, "kind %d is not a 2-D lattice action", act->kind);
+  if (act->Mt < 2 || act->Mx < 2) return fail(MLMCPI_ERR_INVALID, "lattice %u x %u too small", act->Mt, act->Mx);
+  if ((uint64_t)act->Mt * act->Mx > (1ull << 30)) return fail(MLMCPI_ERR_INVALID, "lattice too large for 32-bit site indices");
+  return MLMCPI_OK;
+}
+
 static int check_lattice(const mlmcpi_lattice_action *act) {
   if (!act) return fail(MLMCPI_ERR_INVALID, "action is NULL");
   if (act->kind != MLMCPI_GFF && act->kind != MLMCPI_SCHWINGER)
@@ -1062,6 +1071,113 @@ int mlmcpi_lattice_hmc_draw(const mlmcpi_lattice_action *act, double *d_phi, uin
   }
   if (d_accept)
     MLMCPI_HIP_TRY(hipMemcpyAsync(d_accept, flags + (size_t)(n_rep & 1) * B, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
+  return MLMCPI_OK;
+}
+
+}  // extern "C"
+
+// =================================================================================================
+// Transfers between lattice levels: Action::copy_from_fine / copy_from_coarse for the 2-D actions.
+//   Schwinger  quenchedschwingeraction.cc:92-195 (three coarsening cases: both, temporal, spatial)
+//   GFF        gffaction.cc:97-118 (fine2coarse_map of lattice2d.cc:126-134; unrotated coarsenings)
+// Grid (rows, B); rt, rx in {1, 2} are the coarsening factors in the temporal / spatial direction.
+// =================================================================================================
+namespace mlmcpi {
+
+__global__ void __launch_bounds__(256)
+    schwinger_copy_from_fine_kernel(uint32_t Mt, uint32_t Mx, uint32_t rt, uint32_t rx, const double2 *__restrict__ fine_all,
+                                    double2 *__restrict__ coarse_all) {
+  const uint32_t b = blockIdx.y, Mtf = Mt * rt, Mxf = Mx * rx;  // Mt, Mx: coarse extents
+  const double2 *fine = fine_all + (size_t)b * Mtf * Mxf;
+  double2 *coarse = coarse_all + (size_t)b * Mt * Mx;
+  for (uint32_t j = blockIdx.x; j < Mx; j += gridDim.x)
+    for (uint32_t i = threadIdx.x; i < Mt; i += blockDim.x) {
+      const size_t f = (size_t)(rx * j) * Mtf + rt * i;
+      // mu = 0 links add up along the temporal direction, mu = 1 links along the spatial one
+      const double t0 = (rt == 2) ? fine[f].x + fine[f + 1].x : fine[f].x;
+      const double t1 = (rx == 2) ? fine[f].y + fine[f + Mtf].y : fine[f].y;
+      coarse[(size_t)j * Mt + i] = make_double2(mod_2pi(t0), mod_2pi(t1));
+    }
+}
+
+// writes only the links the reference writes (the others are filled by the conditioned fine action)
+__global__ void __launch_bounds__(256)
+    schwinger_copy_from_coarse_kernel(uint32_t Mt, uint32_t Mx, uint32_t rt, uint32_t rx,
+                                      const double2 *__restrict__ coarse_all, double *__restrict__ fine_all) {
+  const uint32_t b = blockIdx.y, Mtf = Mt * rt, Mxf = Mx * rx;
+  const double2 *coarse = coarse_all + (size_t)b * Mt * Mx;
+  double *fine = fine_all + (size_t)b * 2 * Mtf * Mxf;
+  for (uint32_t j = blockIdx.x; j < Mx; j += gridDim.x)
+    for (uint32_t i = threadIdx.x; i < Mt; i += blockDim.x) {
+      const double2 c = coarse[(size_t)j * Mt + i];
+      const size_t f = 2 * ((size_t)(rx * j) * Mtf + rt * i);  // link index of (rt i, rx j, 0)
+      if (rt == 2) {
+        fine[f] = 0.5 * c.x;
+        fine[f + 2] = 0.5 * c.x;
+      } else {
+        fine[f] = c.x;
+      }
+      if (rx == 2) {
+        fine[f + 1] = 0.5 * c.y;
+        fine[f + 2 * Mtf + 1] = 0.5 * c.y;
+      } else {
+        fine[f + 1] = c.y;
+      }
+    }
+}
+
+// to_coarse != 0: coarse(i,j) = fine(rt i, rx j); else fine(rt i, rx j) = coarse(i,j)
+__global__ void __launch_bounds__(256)
+    vertex_transfer_kernel(uint32_t Mt, uint32_t Mx, uint32_t rt, uint32_t rx, double *__restrict__ fine_all,
+                           double *__restrict__ coarse_all, int to_coarse) {
+  const uint32_t b = blockIdx.y, Mtf = Mt * rt, Mxf = Mx * rx;
+  double *fine = fine_all + (size_t)b * Mtf * Mxf, *coarse = coarse_all + (size_t)b * Mt * Mx;
+  for (uint32_t j = blockIdx.x; j < Mx; j += gridDim.x)
+    for (uint32_t i = threadIdx.x; i < Mt; i += blockDim.x) {
+      const size_t f = (size_t)(rx * j) * Mtf + rt * i, c = (size_t)j * Mt + i;
+      if (to_coarse) coarse[c] = fine[f]; else fine[f] = coarse[c];
+    }
+}
+
+}  // namespace mlmcpi
+
+extern "C" {
+
+static int check_levels(const mlmcpi_lattice_action *fine, uint32_t rt, uint32_t rx) {
+  if (int rc = check_lattice_dims(fine)) return rc;
+  if (!((rt == 1 || rt == 2) && (rx == 1 || rx == 2) && rt * rx > 1))
+    return fail(MLMCPI_ERR_INVALID, "cannot copy between these lattices (coarsening factors %u x %u)", rt, rx);
+  if (fine->Mt % rt || fine->Mx % rx) return fail(MLMCPI_ERR_INVALID, "fine lattice %u x %u cannot be coarsened by %u x %u", fine->Mt, fine->Mx, rt, rx);
+  return MLMCPI_OK;
+}
+
+int mlmcpi_lattice_copy_from_fine(const mlmcpi_lattice_action *fine, uint32_t rt, uint32_t rx, const double *d_fine,
+                                  double *d_coarse, uint32_t B, void *stream) {
+  if (int rc = check_levels(fine, rt, rx)) return rc;
+  MLMCPI_REQUIRE(d_fine && d_coarse && B > 0, "bad arguments");
+  const uint32_t Mt = fine->Mt / rt, Mx = fine->Mx / rx;
+  dim3 grid(row_blocks(Mx, B), B), block(256);
+  if (fine->kind == MLMCPI_SCHWINGER)
+    hipLaunchKernelGGL(schwinger_copy_from_fine_kernel, grid, block, 0, as_stream(stream), Mt, Mx, rt, rx,
+                       (const double2 *)d_fine, (double2 *)d_coarse);
+  else
+    hipLaunchKernelGGL(vertex_transfer_kernel, grid, block, 0, as_stream(stream), Mt, Mx, rt, rx, (double *)d_fine, d_coarse, 1);
+  MLMCPI_LAUNCH_CHECK("copy_from_fine kernel");
+  return MLMCPI_OK;
+}
+
+int mlmcpi_lattice_copy_from_coarse(const mlmcpi_lattice_action *fine, uint32_t rt, uint32_t rx, const double *d_coarse,
+                                    double *d_fine, uint32_t B, void *stream) {
+  if (int rc = check_levels(fine, rt, rx)) return rc;
+  MLMCPI_REQUIRE(d_fine && d_coarse && B > 0, "bad arguments");
+  const uint32_t Mt = fine->Mt / rt, Mx = fine->Mx / rx;
+  dim3 grid(row_blocks(Mx, B), B), block(256);
+  if (fine->kind == MLMCPI_SCHWINGER)
+    hipLaunchKernelGGL(schwinger_copy_from_coarse_kernel, grid, block, 0, as_stream(stream), Mt, Mx, rt, rx,
+                       (const double2 *)d_coarse, d_fine);
+  else
+    hipLaunchKernelGGL(vertex_transfer_kernel, grid, block, 0, as_stream(stream), Mt, Mx, rt, rx, d_fine, (double *)d_coarse, 0);
+  MLMCPI_LAUNCH_CHECK("copy_from_coarse kernel");
   return MLMCPI_OK;
 }
 

@@ -448,6 +448,16 @@ __global__ void add_flags_kernel(int32_t *__restrict__ acc, const int32_t *__res
   if (b < B) acc[b] += flags[b];
 }
 
+// QMAction::copy_from_fine / copy_from_coarse (action/qm/qmaction.cc:7-24): even sites of the fine path
+__global__ void __launch_bounds__(256) path_transfer_kernel(uint32_t Mc, double *__restrict__ fine_all,
+                                                            double *__restrict__ coarse_all, int to_coarse) {
+  const uint32_t b = blockIdx.y;
+  double *fine = fine_all + (size_t)b * 2 * Mc, *coarse = coarse_all + (size_t)b * Mc;
+  for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < Mc; j += gridDim.x * blockDim.x) {
+    if (to_coarse) coarse[j] = fine[2 * j]; else fine[2 * j] = coarse[j];
+  }
+}
+
 // ---- rotor sweeps -----------------------------------------------------------------------------------
 // Grid (nseg, B), 256 threads.  The segment plus a halo of 2 sites per fused sweep lives in LDS;
 // every site whose two neighbours are inside the buffer is updated, so stale values creep inwards
@@ -942,6 +952,22 @@ int mlmcpi_path_hmc_run_layout(const mlmcpi_path_action *act, uint32_t B, uint32
   HmcPlan pl;
   if (int rc = plan_hmc(act->kind, act->M, B, nt, &pl)) return rc;
   *chain_major = pl.halo == 0 ? 1 : 0;
+  return MLMCPI_OK;
+}
+
+int mlmcpi_path_copy_from_fine(const double *d_fine, double *d_coarse, uint32_t M_coarse, uint32_t B, void *stream) {
+  MLMCPI_REQUIRE(d_fine && d_coarse && M_coarse > 0 && B > 0, "bad arguments");
+  hipLaunchKernelGGL(path_transfer_kernel, dim3(choose_split(M_coarse, B), B), dim3(256), 0, as_stream(stream), M_coarse,
+                     (double *)d_fine, d_coarse, 1);
+  MLMCPI_LAUNCH_CHECK("path_transfer_kernel");
+  return MLMCPI_OK;
+}
+
+int mlmcpi_path_copy_from_coarse(const double *d_coarse, double *d_fine, uint32_t M_coarse, uint32_t B, void *stream) {
+  MLMCPI_REQUIRE(d_fine && d_coarse && M_coarse > 0 && B > 0, "bad arguments");
+  hipLaunchKernelGGL(path_transfer_kernel, dim3(choose_split(M_coarse, B), B), dim3(256), 0, as_stream(stream), M_coarse,
+                     d_fine, (double *)d_coarse, 0);
+  MLMCPI_LAUNCH_CHECK("path_transfer_kernel");
   return MLMCPI_OK;
 }
 

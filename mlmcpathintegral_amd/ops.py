@@ -173,6 +173,29 @@ def lattice_sweep_draw_pingpong(act, a, b, n_overrelax, n_heatbath, seed, chain0
     return (b, a) if flag.value else (a, b)
 
 
+def lattice_copy_from_fine(fine_act, rt, rx, fine):
+    """Action::copy_from_fine on the device; returns the coarse-level state [B, n_coarse]."""
+    n = lattice_size(fine_act) // (rt * rx)
+    coarse = torch.empty((fine.shape[0], n), dtype=torch.float64, device=fine.device)
+    abi.call("mlmcpi_lattice_copy_from_fine", C.byref(fine_act), rt, rx, _p(fine), _p(coarse), fine.shape[0], _stream())
+    return coarse
+
+
+def lattice_copy_from_coarse(fine_act, rt, rx, coarse, fine):
+    """Action::copy_from_coarse on the device: updates the coarse-level entries of `fine` in place."""
+    abi.call("mlmcpi_lattice_copy_from_coarse", C.byref(fine_act), rt, rx, _p(coarse), _p(fine), fine.shape[0], _stream())
+
+
+def path_copy_from_fine(fine):
+    coarse = torch.empty((fine.shape[0], fine.shape[1] // 2), dtype=torch.float64, device=fine.device)
+    abi.call("mlmcpi_path_copy_from_fine", _p(fine), _p(coarse), coarse.shape[1], fine.shape[0], _stream())
+    return coarse
+
+
+def path_copy_from_coarse(coarse, fine):
+    abi.call("mlmcpi_path_copy_from_coarse", _p(coarse), _p(fine), coarse.shape[1], fine.shape[0], _stream())
+
+
 def qoi_phi_squared(phi):
     out = torch.empty(phi.shape[0], dtype=torch.float64, device=phi.device)
     abi.call("mlmcpi_qoi_phi_squared", _p(phi), phi.shape[1], phi.shape[0], _p(out), _stream())

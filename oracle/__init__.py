@@ -77,6 +77,9 @@ _SIGS = {
     "orc_dev_hmc_trajectory": (_i, [_vp, _dp, _u32, _d, _u64, _u32, _u32, _dp, _dp]),
     "orc_dev_initialise": (None, [_vp, _dp, _u64, _u32]),
     "orc_dev_twolevel_draw": (_i, [_vp, _vp, _dp, _dp, _u64, _u32, _u32, _dp]),
+    "orc_schwinger_copy_from_fine": (None, [_i, _i, _i, _i, _dp, _dp]),
+    "orc_schwinger_copy_from_coarse": (None, [_i, _i, _i, _i, _dp, _dp]),
+    "orc_gff_transfer": (None, [_i, _i, _i, _i, _dp, _dp, _i]),
     "orc_stats_new": (_vp, [_u32]),
     "orc_stats_free": (None, [_vp]),
     "orc_stats_record": (None, [_vp, _dp, _u32]),

@@ -1003,6 +1003,50 @@ int orc_dev_twolevel_draw(void *fine, void *coarse, const double *x_coarse, doub
   return dev_twolevel_draw(*(ActionO *)fine, *(ActionO *)coarse, x_coarse, theta, r, terms);
 }
 
+// ---- transfers between lattice levels ------------------------------------------------------------------
+// quenchedschwingeraction.cc:147-195 (copy_from_fine: three coarsening cases); Mt, Mx = COARSE extents
+void orc_schwinger_copy_from_fine(int Mt, int Mx, int rt, int rx, const double *fine, double *coarse) {
+  Grid2 gc{Mt, Mx, false}, gf{Mt * rt, Mx * rx, false};
+  for (int i = 0; i < Mt; ++i)
+    for (int j = 0; j < Mx; ++j) {
+      double t0 = fine[gf.link(rt * i, rx * j, 0)];
+      if (rt == 2) t0 += fine[gf.link(2 * i + 1, rx * j, 0)];
+      double t1 = fine[gf.link(rt * i, rx * j, 1)];
+      if (rx == 2) t1 += fine[gf.link(rt * i, 2 * j + 1, 1)];
+      coarse[gc.link(i, j, 0)] = wrap_2pi(t0);
+      coarse[gc.link(i, j, 1)] = wrap_2pi(t1);
+    }
+}
+// quenchedschwingeraction.cc:92-144 (copy_from_coarse)
+void orc_schwinger_copy_from_coarse(int Mt, int Mx, int rt, int rx, const double *coarse, double *fine) {
+  Grid2 gc{Mt, Mx, false}, gf{Mt * rt, Mx * rx, false};
+  for (int i = 0; i < Mt; ++i)
+    for (int j = 0; j < Mx; ++j) {
+      double c0 = coarse[gc.link(i, j, 0)], c1 = coarse[gc.link(i, j, 1)];
+      if (rt == 2) {
+        fine[gf.link(2 * i, rx * j, 0)] = 0.5 * c0;
+        fine[gf.link(2 * i + 1, rx * j, 0)] = 0.5 * c0;
+      } else {
+        fine[gf.link(i, rx * j, 0)] = c0;
+      }
+      if (rx == 2) {
+        fine[gf.link(rt * i, 2 * j, 1)] = 0.5 * c1;
+        fine[gf.link(rt * i, 2 * j + 1, 1)] = 0.5 * c1;
+      } else {
+        fine[gf.link(rt * i, j, 1)] = c1;
+      }
+    }
+}
+// gffaction.cc:97-118 with the fine2coarse_map of lattice2d.cc:126-134 (unrotated): vertex (rt i, rx j) <-> (i, j)
+void orc_gff_transfer(int Mt, int Mx, int rt, int rx, double *fine, double *coarse, int to_coarse) {
+  Grid2 gc{Mt, Mx, false}, gf{Mt * rt, Mx * rx, false};
+  for (int i = 0; i < Mt; ++i)
+    for (int j = 0; j < Mx; ++j) {
+      if (to_coarse) coarse[gc.vertex(i, j)] = fine[gf.vertex(rt * i, rx * j)];
+      else fine[gf.vertex(rt * i, rx * j)] = coarse[gc.vertex(i, j)];
+    }
+}
+
 // ---- statistics ------------------------------------------------------------------------------------
 void *orc_stats_new(unsigned k_max) { return new StatsO(k_max); }
 void orc_stats_free(void *h) { delete (StatsO *)h; }

@@ -498,6 +498,56 @@ def test_lattice_sweeps_match_oracle(gpu_ops, orc, kind, Mt, Mx, kw, B, fuse):
             assert_close(got, xo, tol=1e-11, what=f"sweeps ({n_or},{n_hb}) fuse={fuse}")
 
 
+@pytest.mark.parametrize("rt,rx", [(2, 2), (2, 1), (1, 2)])
+def test_level_transfers_match_oracle(gpu_ops, orc, golden, rt, rx):
+    """Action::copy_from_fine / copy_from_coarse (Schwinger, GFF, 1-D paths) against the oracle, plus the
+    survey's recorded coarse links of the 4 x 4 Schwinger state."""
+    from mlmcpathintegral_amd import abi
+    L = orc.lib()
+    Mt, Mx, B = 12 * rt, 10 * rx, 2          # fine extents
+    rng = np.random.default_rng(rt * 10 + rx)
+    fine_act = abi.lattice_action(4, Mt, Mx, beta=1.0)
+    fine = rng.uniform(-np.pi, np.pi, (B, 2 * Mt * Mx))
+    got = gpu_ops.lattice_copy_from_fine(fine_act, rt, rx, dev(fine)).cpu().numpy()
+    for b in range(B):
+        want = np.zeros(2 * (Mt // rt) * (Mx // rx))
+        L.orc_schwinger_copy_from_fine(Mt // rt, Mx // rx, rt, rx, fine[b], want)
+        assert_angles_close(got[b], want, tol=1e-15, what="Schwinger copy_from_fine")
+    coarse = rng.uniform(-np.pi, np.pi, got.shape)
+    fd = dev(fine)
+    gpu_ops.lattice_copy_from_coarse(fine_act, rt, rx, dev(coarse), fd)
+    for b in range(B):
+        want = fine[b].copy()
+        L.orc_schwinger_copy_from_coarse(Mt // rt, Mx // rx, rt, rx, coarse[b], want)
+        assert (fd[b].cpu().numpy() == want).all(), "Schwinger copy_from_coarse (untouched links must stay)"
+    gff = abi.lattice_action(3, Mt, Mx, mass=1.0)
+    phi = rng.normal(size=(B, Mt * Mx))
+    gotc = gpu_ops.lattice_copy_from_fine(gff, rt, rx, dev(phi)).cpu().numpy()
+    pd = dev(phi)
+    cnew = rng.normal(size=gotc.shape)
+    gpu_ops.lattice_copy_from_coarse(gff, rt, rx, dev(cnew), pd)
+    for b in range(B):
+        want = np.zeros(gotc.shape[1]); f = phi[b].copy()
+        L.orc_gff_transfer(Mt // rt, Mx // rx, rt, rx, f, want, 1)
+        assert (gotc[b] == want).all()
+        L.orc_gff_transfer(Mt // rt, Mx // rx, rt, rx, f, cnew[b].copy(), 0)
+        assert (pd[b].cpu().numpy() == f).all()
+    if (rt, rx) == (2, 2):
+        g = golden["schwinger_4x4"]
+        x = seq(32)
+        x[0:2] = g["after_overrelax_0_then_1"]
+        x[2:4] = g["after_heatbath_2_then_3"]
+        c = gpu_ops.lattice_copy_from_fine(abi.lattice_action(4, 4, 4, beta=1.0), 2, 2, dev(x[None, :])).cpu().numpy()[0]
+        assert_close(c[:4], g["copy_from_fine_first_four_coarse_links"], tol=1e-15)
+        xf = rng.normal(size=(B, 64))
+        assert (gpu_ops.path_copy_from_fine(dev(xf)).cpu().numpy() == xf[:, ::2]).all()
+        tgt = dev(xf)
+        newc = rng.normal(size=(B, 32))
+        gpu_ops.path_copy_from_coarse(dev(newc), tgt)
+        want = xf.copy(); want[:, ::2] = newc
+        assert (tgt.cpu().numpy() == want).all()
+
+
 def test_pingpong_sweeps_equal_copy_form(gpu_ops):
     from mlmcpathintegral_amd import abi
     for act, n in ((abi.lattice_action(4, 64, 32, beta=1.0), 2 * 64 * 32), (abi.lattice_action(3, 32, 32, mass=5.0), 32 * 32)):

@@ -63,6 +63,18 @@ def test_schwinger_known_answers(orc, golden):
     assert list(x[2:4]) == g["after_heatbath_2_then_3"]
 
 
+def test_schwinger_copy_from_fine_known_answers(orc, golden):
+    """coarse_action()->copy_from_fine on the 4 x 4 state after the recorded updates; the coarse
+    links are mod_2pi sums of the fine links they span (quenchedschwingeraction.cc:147-162)."""
+    g = golden["schwinger_4x4"]
+    x = seq(32)
+    x[0:2] = g["after_overrelax_0_then_1"]
+    x[2:4] = g["after_heatbath_2_then_3"]
+    coarse = np.zeros(8)
+    orc.lib().orc_schwinger_copy_from_fine(2, 2, 2, 2, x, coarse)
+    assert np.max(np.abs(coarse[:4] - np.array(g["copy_from_fine_first_four_coarse_links"]))) < 1e-15
+
+
 def test_gff_known_answers(orc, golden):
     g = golden["gff_4x4"]
     A = orc.Action(orc.GFF, **g["params"])
