@@ -520,19 +520,21 @@ def test_level_transfers_match_oracle(gpu_ops, orc, golden, rt, rx):
         want = fine[b].copy()
         L.orc_schwinger_copy_from_coarse(Mt // rt, Mx // rx, rt, rx, coarse[b], want)
         assert (fd[b].cpu().numpy() == want).all(), "Schwinger copy_from_coarse (untouched links must stay)"
-    gff = abi.lattice_action(3, Mt, Mx, mass=1.0)
-    phi = rng.normal(size=(B, Mt * Mx))
-    gotc = gpu_ops.lattice_copy_from_fine(gff, rt, rx, dev(phi)).cpu().numpy()
-    pd = dev(phi)
-    cnew = rng.normal(size=gotc.shape)
-    gpu_ops.lattice_copy_from_coarse(gff, rt, rx, dev(cnew), pd)
-    for b in range(B):
-        want = np.zeros(gotc.shape[1]); f = phi[b].copy()
-        L.orc_gff_transfer(Mt // rt, Mx // rx, rt, rx, f, want, 1)
-        assert (gotc[b] == want).all()
-        L.orc_gff_transfer(Mt // rt, Mx // rx, rt, rx, f, cnew[b].copy(), 0)
-        assert (pd[b].cpu().numpy() == f).all()
     if (rt, rx) == (2, 2):
+        # GFF lives on square lattices only (gffaction.hh:169-173), i.e. CoarsenBoth hierarchies
+        Mg = 24
+        gff = abi.lattice_action(3, Mg, Mg, mass=1.0)
+        phi = rng.normal(size=(B, Mg * Mg))
+        gotc = gpu_ops.lattice_copy_from_fine(gff, 2, 2, dev(phi)).cpu().numpy()
+        pd = dev(phi)
+        cnew = rng.normal(size=gotc.shape)
+        gpu_ops.lattice_copy_from_coarse(gff, 2, 2, dev(cnew), pd)
+        for b in range(B):
+            want = np.zeros(gotc.shape[1]); f = phi[b].copy()
+            L.orc_gff_transfer(Mg // 2, Mg // 2, 2, 2, f, want, 1)
+            assert (gotc[b] == want).all()
+            L.orc_gff_transfer(Mg // 2, Mg // 2, 2, 2, f, cnew[b].copy(), 0)
+            assert (pd[b].cpu().numpy() == f).all()
         g = golden["schwinger_4x4"]
         x = seq(32)
         x[0:2] = g["after_overrelax_0_then_1"]
