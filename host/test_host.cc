@@ -174,6 +174,17 @@ int main(int argc, char **argv) {
                   st->error(), act->Xsquared_analytical(), mc.get_sampler()->p_accept());
       EXPECT(std::fabs(st->average() - act->Xsquared_analytical()) < 5 * st->error(), "hierarchical sampler <x^2>");
     }
+    {  // sampler/multilevelsampler.cc: independent samples handed up the hierarchy
+      MultilevelSampler ms(act, std::make_shared<QoIXsquaredFactory>(), std::make_shared<HMCSamplerFactory>(hp), cfa, 20, hier);
+      auto st = std::make_shared<SampleState>(64);
+      Statistics q("Q", 20);
+      for (int k = 0; k < 1500; ++k) {
+        ms.draw(st);
+        if (k >= 200) q.record_sample(QoIXsquared(lat).evaluate(st));
+      }
+      std::printf(" multilevel sampler: <x^2> = %.6f +- %.6f (analytic %.6f)\n", q.average(), q.error(), act->Xsquared_analytical());
+      EXPECT(std::fabs(q.average() - act->Xsquared_analytical()) < 5 * q.error(), "multilevel sampler <x^2>");
+    }
     MultiLevelMCParameters mlp;
     mlp.n_level = 3; mlp.n_burnin = 100; mlp.epsilon = 2.5e-2; mlp.n_min_samples_qoi = 200; mlp.n_meas = 50;
     std::printf(" constructing the multilevel estimator ...\n"); std::fflush(stdout);

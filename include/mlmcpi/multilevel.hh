@@ -186,6 +186,82 @@ private:
   const HierarchicalParameters param;
 };
 
+/** sampler/multilevelsampler.{hh,cc}: independent samples are passed up the hierarchy -- a level only hands
+ *  its state to the next finer two-level step once ceil(tau_int) draws have been made on it since the last
+ *  hand-over (multilevelsampler.cc:71-113). */
+class MultilevelSampler : public Sampler {
+public:
+  MultilevelSampler(const std::shared_ptr<Action> fine_action, const std::shared_ptr<QoIFactory> qoi_factory,
+                    const std::shared_ptr<SamplerFactory> coarse_sampler_factory,
+                    const std::shared_ptr<ConditionedFineActionFactory> cfa_factory, unsigned int n_autocorr_window,
+                    const HierarchicalParameters p)
+      : Sampler(), n_level(p.n_max_level - fine_action->get_coarsening_level()), t_indep(n_level, 0.0),
+        n_indep(n_level, 0), t_sampler(n_level, 0), cost_per_sample_(0.0) {
+    if (n_level < 1) fatal("multilevel sampler needs at least one level");
+    action.push_back(fine_action);
+    for (unsigned int ell = 0; ell + 1 < n_level; ++ell) {
+      std::shared_ptr<Action> c = action[ell]->coarse_action();
+      c->set_seed(fine_action->get_seed() + 104729 * (ell + 1), fine_action->get_chain0());
+      action.push_back(c);
+      twolevel_step.push_back(std::make_shared<TwoLevelMetropolisStep>(c, action[ell], cfa_factory->get(action[ell]), 1, p.n_meas));
+    }
+    for (unsigned int ell = 0; ell < n_level; ++ell) {
+      qoi.push_back(qoi_factory->get(action[ell]));
+      phi_sampler_state.push_back(std::make_shared<SampleState>(action[ell]->sample_size()));
+      stats_sampler.push_back(std::make_shared<Statistics>("   Q_{sampler}[" + std::to_string(ell) + "]", n_autocorr_window));
+    }
+    coarse_sampler = coarse_sampler_factory->get(action[n_level - 1]);
+    auto meas_state = std::make_shared<SampleState>(fine_action->sample_size());
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned int k = 0; k < p.n_meas; ++k) draw(meas_state);
+    check(mlmcpi_stream_synchronize(nullptr), "synchronize");
+    cost_per_sample_ = 1.E6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / (p.n_meas ? p.n_meas : 1);
+  }
+
+  void draw(std::shared_ptr<SampleState> phi_state) override {
+    accept = true;
+    int level = (int)n_level - 1;
+    do {
+      if (level == (int)n_level - 1) coarse_sampler->draw(phi_sampler_state[level]);
+      else twolevel_step[level]->draw(phi_sampler_state[level + 1], phi_sampler_state[level]);
+      stats_sampler[level]->record_sample(qoi[level]->evaluate(phi_sampler_state[level]));
+      t_sampler[level]++;
+      double tau = std::ceil(stats_sampler[level]->tau_int());
+      if (!(tau <= 1. + 2. * stats_sampler[level]->autocorr_window())) tau = 1. + 2. * stats_sampler[level]->autocorr_window();
+      if (t_sampler[level] >= tau) {
+        t_indep[level] = (n_indep[level] * t_indep[level] + t_sampler[level]) / (1.0 + n_indep[level]);
+        n_indep[level]++;
+        t_sampler[level] = 0;
+        level--;  // a new independent sample: hand it to the next finer level
+      } else {
+        level = (int)n_level - 1;
+      }
+    } while (level >= 0);
+    n_total_samples++;
+    n_accepted_samples++;
+    phi_state->data = phi_sampler_state[0]->data;
+  }
+  void set_state(std::shared_ptr<SampleState> phi_state) override { phi_sampler_state[0]->data = phi_state->data; }
+  double cost_per_sample() override { return cost_per_sample_; }
+  void show_stats() override {
+    std::cout << std::setprecision(3) << std::fixed << "  cost per sample = " << cost_per_sample() << " mu s" << std::endl;
+    for (unsigned int ell = 0; ell < n_level; ++ell)
+      std::cout << " level " << ell << " : average spacing between samples " << t_indep[ell] << std::endl << *stats_sampler[ell];
+  }
+
+private:
+  const unsigned int n_level;
+  std::vector<std::shared_ptr<Action>> action;
+  std::vector<std::shared_ptr<TwoLevelMetropolisStep>> twolevel_step;
+  std::vector<std::shared_ptr<QoI>> qoi;
+  std::vector<std::shared_ptr<SampleState>> phi_sampler_state;
+  std::vector<std::shared_ptr<Statistics>> stats_sampler;
+  std::shared_ptr<Sampler> coarse_sampler;
+  std::vector<double> t_indep;
+  std::vector<unsigned int> n_indep, t_sampler;
+  double cost_per_sample_;
+};
+
 /** montecarlo/montecarlomultilevel.hh: parameters */
 struct MultiLevelMCParameters {
   unsigned int n_level = 3;
