@@ -294,11 +294,15 @@ __global__ void __launch_bounds__(NT)
 #pragma unroll
       for (int m = 0; m < M0; ++m) {
         if ((m + 1) * NT <= T0 || (int)tid + NT * m < T0) {
-          const double *q0 = th0 + (o0[m] - par * P);
-          const double *q1 = th1 + (o0[m] - par * P);
-          const double tp = mod_2pi_fast(q0[P] + q1[0] - q1[1]);
-          const double tm = mod_2pi_fast(q0[-P] + q1[1 - P] - q1[-P]);
-          th0[o0[m] - par * P] = mod_2pi_fast((tp + tm) - q0[0]);
+          const int o = o0[m] - par * P;
+          const uint32_t a0 = (uint32_t)(o - P) * 8u, a1 = a0 + (uint32_t)(BH * P) * 8u;  // th0 / th1 at (r-1, c)
+          double t0_up = lds_read_f64<2 * P * 8>(a0), t0_dn = lds_read_f64<0>(a0), t0_own = lds_read_f64<P * 8>(a0);
+          double t1_c = lds_read_f64<P * 8>(a1), t1_r = lds_read_f64<P * 8 + 8>(a1);
+          double t1_dc = lds_read_f64<0>(a1), t1_dr = lds_read_f64<8>(a1);
+          lds_wait7(t0_up, t0_dn, t0_own, t1_c, t1_r, t1_dc, t1_dr);
+          const double tp = mod_2pi_fast(t0_up + t1_c - t1_r);
+          const double tm = mod_2pi_fast(t0_dn + t1_dr - t1_dc);
+          th0[o] = mod_2pi_fast((tp + tm) - t0_own);
         }
       }
       __syncthreads();
@@ -308,11 +312,15 @@ __global__ void __launch_bounds__(NT)
 #pragma unroll
       for (int m = 0; m < M1; ++m) {
         if ((m + 1) * NT <= T1 || (int)tid + NT * m < T1) {
-          const double *q0 = th0 + (o1[m] - par);
-          const double *q1 = th1 + (o1[m] - par);
-          const double tp = mod_2pi_fast(q0[0] + q1[1] - q0[P]);
-          const double tm = mod_2pi_fast(q0[P - 1] + q1[-1] - q0[-1]);
-          th1[o1[m] - par] = mod_2pi_fast((tp + tm) - q1[0]);
+          const int o = o1[m] - par;
+          const uint32_t a0 = (uint32_t)(o - 1) * 8u, a1 = a0 + (uint32_t)(BH * P) * 8u;  // th0 / th1 at (r, c-1)
+          double t0_c = lds_read_f64<8>(a0), t0_u = lds_read_f64<P * 8 + 8>(a0);
+          double t0_lu = lds_read_f64<P * 8>(a0), t0_l = lds_read_f64<0>(a0);
+          double t1_r = lds_read_f64<16>(a1), t1_l = lds_read_f64<0>(a1), t1_own = lds_read_f64<8>(a1);
+          lds_wait7(t0_c, t0_u, t0_lu, t0_l, t1_r, t1_l, t1_own);
+          const double tp = mod_2pi_fast(t0_c + t1_r - t0_u);
+          const double tm = mod_2pi_fast(t0_lu + t1_l - t0_l);
+          th1[o] = mod_2pi_fast((tp + tm) - t1_own);
         }
       }
       __syncthreads();
@@ -439,13 +447,17 @@ __global__ void __launch_bounds__(NT)
 #pragma unroll
       for (int m = 0; m < M; ++m) {
         if ((m + 1) * NT <= T || (int)tid + NT * m < T) {
-          double *q = phi + (colour ? o1[m] : o0[m]);
+          const int o = colour ? o1[m] : o0[m];
+          const uint32_t a = (uint32_t)(o - P) * 8u;  // LDS byte address of the cell below
+          double dn = lds_read_f64<0>(a), lf = lds_read_f64<(P - 1) * 8>(a), own = lds_read_f64<P * 8>(a);
+          double rt = lds_read_f64<(P + 1) * 8>(a), up = lds_read_f64<2 * P * 8>(a), pad0 = 0.0, pad1 = 0.0;
+          lds_wait7(dn, lf, own, rt, up, pad0, pad1);
           double Delta = 0.0;
-          Delta += q[1];
-          Delta += q[-1];
-          Delta += q[P];
-          Delta += q[-P];
-          q[0] = fma(two_over_kappa, Delta, -q[0]);  // 2 Delta / kappa - phi, without the fp64 division
+          Delta += rt;
+          Delta += lf;
+          Delta += up;
+          Delta += dn;
+          phi[o] = fma(two_over_kappa, Delta, -own);  // 2 Delta / kappa - phi, without the fp64 division
         }
       }
       __syncthreads();
