@@ -77,9 +77,7 @@ __device__ __forceinline__ void stage_region(uint32_t nr, uint32_t nc, Load load
 // arccosine and the LDS write-back run once per cell afterwards, again without divergence.  Which random numbers a cell consumes is fixed by
 // (site, attempt), so the result does not depend on this scheduling.
 template <int NT, int S, class Setup, class Commit>
-__device__ __forceinline__ void heatbath_region(uint32_t nr, uint32_t nc, const RngKey &key, Setup setup,
-                                                Commit commit) {
-  const uint32_t total = nr * nc;
+__device__ __forceinline__ void heatbath_cells(uint32_t total, const RngKey &key, Setup setup, Commit commit) {
   for (uint32_t b0 = 0; b0 < total; b0 += S * NT) {  // uniform trip count: the vote below needs every lane
     double kap[S], env[S], cen[S], fv[S];
     uint32_t site[S], off[S];
@@ -90,9 +88,8 @@ __device__ __forceinline__ void heatbath_region(uint32_t nr, uint32_t nc, const 
       const uint32_t idx = b0 + m * NT + threadIdx.x;
       kap[m] = 1.0; env[m] = 1.0; cen[m] = 0.0; fv[m] = 1.0; site[m] = 0; off[m] = 0; neg[m] = false;
       if (idx < total) {
-        const uint32_t ri = idx / nc, ci = idx - ri * nc;
         double tau;
-        setup(ri, ci, tau, cen[m], site[m], off[m]);
+        setup(idx, tau, cen[m], site[m], off[m]);
         kap[m] = vm_clamp(tau);
         env[m] = vm_envelope(kap[m]);
         n = m + 1;
@@ -133,6 +130,18 @@ __device__ __forceinline__ void heatbath_region(uint32_t nr, uint32_t nc, const 
     for (int m = 0; m < S; ++m)
       if (m < n) commit(off[m], mod_2pi_fast(vm_angle(fv[m], neg[m]) + cen[m]));
   }
+}
+
+// region given as nr x nc with a runtime nc (generic kernels)
+template <int NT, int S, class Setup, class Commit>
+__device__ __forceinline__ void heatbath_region(uint32_t nr, uint32_t nc, const RngKey &key, Setup setup,
+                                                Commit commit) {
+  heatbath_cells<NT, S>(nr * nc, key,
+                        [&](uint32_t idx, double &tau, double &centre, uint32_t &site, uint32_t &o) {
+                          const uint32_t ri = idx / nc, ci = idx - ri * nc;
+                          setup(ri, ci, tau, centre, site, o);
+                        },
+                        commit);
 }
 
 struct TileGeom {
