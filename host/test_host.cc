@@ -198,6 +198,33 @@ int main(int argc, char **argv) {
     EXPECT(std::fabs(mlmc.numerical_result() - exact) < 5 * mlmc.statistical_error(), "MLMC estimate");
     EXPECT(mlmc.level_statistics(0)->variance() < mlmc.level_statistics(2)->variance(), "variance decays towards fine levels");
   }
+  // ---- rotor: hierarchical sampler (heat bath on the coarsest level, ExpSin2 fill-in) vs the direct sampler ---
+  {
+    auto lat = std::make_shared<Lattice1D>(32, 4.0);
+    auto act = std::make_shared<RotorAction>(lat, RenormalisationPerturbative, 0.25);
+    auto coarse = std::dynamic_pointer_cast<RotorAction>(act->coarse_action());
+    std::printf(" rotor: m0 %.6f -> coarse %.6f; chi_t perturbative %.6f, continuum %.6f\n", act->getm0(), coarse->getm0(),
+                act->chit_perturbative(), act->chit_continuum());
+    EXPECT(coarse->getm0() > act->getm0() && coarse->getm0() < 1.5 * act->getm0(), "perturbative m0 renormalisation");
+    OverrelaxedHeatBathParameters op;
+    op.n_sweep_overrelax = 1; op.n_sweep_heatbath = 1; op.n_burnin = 100;
+    HierarchicalParameters hier;
+    hier.n_max_level = 3; hier.n_meas = 20;
+    auto hfac = std::make_shared<HierarchicalSamplerFactory>(std::make_shared<OverrelaxedHeatBathSamplerFactory>(op),
+                                                             std::make_shared<RotorConditionedFineActionFactory>(), hier);
+    SingleLevelMCParameters mp;
+    mp.n_burnin = 300; mp.n_samples = 20000;
+    MonteCarloSingleLevel mc(act, std::make_shared<QoISusceptibility>(lat), hfac, mp);
+    mc.evaluate();
+    MonteCarloSingleLevel direct(act, std::make_shared<QoISusceptibility>(lat), std::make_shared<OverrelaxedHeatBathSamplerFactory>(op), mp);
+    direct.evaluate();
+    auto a = mc.get_statistics(), b = direct.get_statistics();
+    std::printf(" rotor chi_t: hierarchical %.6f +- %.6f (p_accept %.3f), direct %.6f +- %.6f\n", a->average(), a->error(),
+                mc.get_sampler()->p_accept(), b->average(), b->error());
+    EXPECT(std::fabs(a->average() - b->average()) < 5 * std::hypot(a->error(), b->error()), "rotor hierarchical chi_t");
+    // a/m0 = 0.5 here: the O(a) formula is only a rough guide
+    EXPECT(std::fabs(b->average() - act->chit_perturbative()) < 0.4 * act->chit_perturbative(), "rotor chi_t near the O(a) formula");
+  }
   std::printf(failures ? "%d FAILURES\n" : "host layer: all checks passed\n", failures);
   return failures ? 1 : 0;
 }

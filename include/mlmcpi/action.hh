@@ -158,12 +158,48 @@ public:
   const double mu2, lambda, x0;
 };
 
+/** common/auxilliary.cc:7-27: ratio of theta-function sums  sum_m m^p exp(-xi m^2/2) / sum_m exp(-xi m^2/2), m in Z
+ *  (99 terms on each side, as in the reference) */
+inline double Sigma_hat(const double xi, const unsigned int p) {
+  if (p % 2) return 0.0;
+  if (p == 0) return 1.0;
+  double num = 0.0, denom = 1.0;
+  for (unsigned int m = 1; m < 100; ++m) {
+    const double e = std::exp(-0.5 * xi * m * m);
+    num += 2. * std::pow((double)m, (double)p) * e;
+    denom += 2. * e;
+  }
+  return num / denom;
+}
+
 /** action/qm/rotoraction.hh:93-289 */
 class RotorAction : public QMAction {
 public:
   RotorAction(const std::shared_ptr<Lattice1D> lattice_, const RenormalisationType r, const double m0_)
       : QMAction(lattice_, r, MLMCPI_ROTOR, m0_) {
     seed = 21172817;  // rotoraction.hh:106
+  }
+  /** rotoraction.hh:120-125 with RenormalisedRotorParameters (rotorrenormalisation.hh:22-71, .cc:8-14):
+   *  m0_coarse = (1 + delta_I(T/m0) a/m0) m0 under perturbative renormalisation */
+  std::shared_ptr<Action> coarse_action() override {
+    double m0c = m0;
+    if (renormalisation == RenormalisationPerturbative) {
+      const double xi = lattice->getT_final() / m0, s2 = Sigma_hat(xi, 2), s4 = Sigma_hat(xi, 4);
+      const double delta_I = 0.5 * (1. - 2. * xi * s2 + 0.5 * xi * xi * (s4 - s2 * s2)) / (1. - 2. * xi * s2 + xi * xi * (s4 - s2 * s2));
+      m0c = (1. + delta_I * a_lat / m0) * m0;
+    } else if (renormalisation == RenormalisationNonperturbative) {
+      fatal("nonperturbative renormalisation not implemented for rotor action ");
+    }
+    return std::make_shared<RotorAction>(lattice->coarse_lattice(), renormalisation, m0c);
+  }
+  /** rotoraction.cc:97-115: chi_t to O(a/m0), and its continuum limit */
+  double chit_perturbative() const {
+    const double xi = lattice->getT_final() / m0, z = a_lat / m0, s2 = Sigma_hat(xi, 2), s4 = Sigma_hat(xi, 4);
+    return 1. / (4. * M_PI * M_PI * m0) * (1. - xi * s2 + (0.5 - xi * s2 + 0.25 * xi * xi * (s4 - s2 * s2)) * z);
+  }
+  double chit_continuum() const {
+    const double xi = lattice->getT_final() / m0;
+    return 1. / (4. * M_PI * M_PI * m0) * (1. - xi * Sigma_hat(xi, 2));
   }
   bool has_local_updates() const override { return true; }
   void sweep(std::shared_ptr<SampleState> x, std::shared_ptr<SampleState> scratch, unsigned n_or, unsigned n_hb,

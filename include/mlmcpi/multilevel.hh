@@ -1,6 +1,7 @@
 // multilevel.hh -- the multilevel glue of the reference for 1-D (QM) actions, on device chains:
 //   ConditionedFineAction            action/conditionedfineaction.hh:38-67
 //   GaussianConditionedFineAction    action/qm/gaussianconditionedfineaction.{hh,cc}
+//   RotorConditionedFineAction       action/qm/rotorconditionedfineaction.{hh,cc}
 //   TwoLevelMetropolisStep           montecarlo/twolevelmetropolisstep.{hh,cc}
 //   HierarchicalSampler              sampler/hierarchicalsampler.{hh,cc}
 //   MonteCarloMultiLevel             montecarlo/montecarlomultilevel.{hh,cc}
@@ -35,6 +36,17 @@ private:
   const std::shared_ptr<QMAction> action;
 };
 
+/** action/qm/rotorconditionedfineaction.{hh,cc}: fill-in x_{2j+1} = mod_2pi(Wminimum + ExpSin2(2 Wcurvature)).
+ *  fill_fine_points / evaluate run inside mlmcpi_path_twolevel_draw. */
+class RotorConditionedFineAction : public ConditionedFineAction {
+public:
+  explicit RotorConditionedFineAction(const std::shared_ptr<RotorAction> action_) : action(action_) {}
+  std::shared_ptr<QMAction> fine_action() const override { return action; }
+
+private:
+  const std::shared_ptr<RotorAction> action;
+};
+
 class ConditionedFineActionFactory {
 public:
   virtual ~ConditionedFineActionFactory() {}
@@ -47,6 +59,15 @@ public:
     auto qm = std::dynamic_pointer_cast<QMAction>(action);
     if (!qm) fatal("Gaussian conditioned fine action needs a 1-D action");
     return std::make_shared<GaussianConditionedFineAction>(qm);
+  }
+};
+
+class RotorConditionedFineActionFactory : public ConditionedFineActionFactory {
+public:
+  std::shared_ptr<ConditionedFineAction> get(std::shared_ptr<Action> action) override {
+    auto rotor = std::dynamic_pointer_cast<RotorAction>(action);
+    if (!rotor) fatal("rotor conditioned fine action needs a RotorAction");
+    return std::make_shared<RotorConditionedFineAction>(rotor);
   }
 };
 
@@ -79,7 +100,7 @@ public:
   /** twolevelmetropolisstep.cc:35-89 */
   void draw(const std::shared_ptr<SampleState> phi_coarse_state, std::shared_ptr<SampleState> phi_state) {
     check(mlmcpi_path_twolevel_draw(&fine->abi_action(), &coarse->abi_action(), phi_coarse_state->device(),
-                                    theta_fine->device_mutable(), B, fine->get_seed() ^ 0x5517A4B3ull, fine->get_chain0(),
+                                    theta_fine->device_mutable(), B, level_seed(), fine->get_chain0(),
                                     step++, work, (int32_t *)accept_flags.ptr(), nullptr, nullptr), "path_twolevel_draw");
     std::vector<int32_t> flags = accept_flags.download<int32_t>();
     double acc = 0;
@@ -93,6 +114,11 @@ public:
   double cost_per_sample() override { return cost_per_sample_; }
 
 private:
+  /** every level of a hierarchy gets its own Philox key: the fill-in streams of two levels share
+   *  (site, chain, step) counters */
+  uint64_t level_seed() const {
+    return (fine->get_seed() ^ 0x5517A4B3ull) + 0x9E3779B97F4A7C15ull * (uint64_t)(fine->get_coarsening_level() + 1);
+  }
   const std::shared_ptr<QMAction> coarse, fine;
   const std::shared_ptr<ConditionedFineAction> cfa;
   const unsigned int B;

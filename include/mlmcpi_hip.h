@@ -140,9 +140,10 @@ int mlmcpi_path_sweep_draw(const mlmcpi_path_action *act, double *d_x, double *d
                            uint32_t n_overrelax, uint32_t n_heatbath, uint64_t seed, uint32_t chain0,
                            uint32_t sweep0, void *stream);
 
-/* TwoLevelMetropolisStep::draw (montecarlo/twolevelmetropolisstep.cc:35-89) for the harmonic / quartic
- * oscillator with the Gaussian conditioned fine action (action/qm/gaussianconditionedfineaction.cc:7-43)
- * and QMAction::copy_from_{coarse,fine} (action/qm/qmaction.cc:7-24):
+/* TwoLevelMetropolisStep::draw (montecarlo/twolevelmetropolisstep.cc:35-89) with QMAction::copy_from_{coarse,fine}
+ * (action/qm/qmaction.cc:7-24) and the action's conditioned fine action: Gaussian for the harmonic / quartic
+ * oscillator (action/qm/gaussianconditionedfineaction.cc:7-43), ExpSin2 for the rotor
+ * (action/qm/rotorconditionedfineaction.cc:7-43; theta'[2j+1] = mod_2pi(Wmin + ExpSin2(2 W''))):
  *   theta'[2j] = x_coarse[j];  theta'[2j+1] ~ N(Wmin(theta'[2j], theta'[2j+2]), 1/W'')
  *   dS = [S_f(theta') - S_f(theta)] + [S_c(theta_C) - S_c(x_coarse)] + [S_cfa(theta) - S_cfa(theta')]
  *   accept with min(1, exp(-dS)); accepted chains get theta <- theta'.

@@ -294,9 +294,11 @@ __device__ __forceinline__ double vm_envelope(double kappa) {  // kappa already 
 constexpr uint32_t kMaxVmAttempts = 1024u;
 
 // one proposal; returns true when accepted (or when the attempt bound is hit).  f = cos(theta).
+// sub0 separates streams that share (site, chain, step): 0 for sweeps, kVmFillin for two-level fill-ins.
+constexpr uint32_t kVmFillin = 1u << 23;
 __device__ __forceinline__ bool vm_attempt(const RngKey &k, uint32_t site, uint32_t attempt, double kappa, double r,
-                                           double &f, bool &negative) {
-  const U4 q = philox4x32_10(site, k.chain, k.step, (P_VONMISES << 24) | attempt, k.k0, k.k1);
+                                           double &f, bool &negative, uint32_t sub0 = 0) {
+  const U4 q = philox4x32_10(site, k.chain, k.step, (P_VONMISES << 24) | sub0 | attempt, k.k0, k.k1);
   const double u1 = u01(q.x, q.y), u2 = u01(q.z, q.w);
   negative = (q.x & 1u) != 0;  // bit 0 does not enter u1 (u01 drops the low 11 bits)
   const double z = cospi_unit(u1);
@@ -319,12 +321,12 @@ __device__ __forceinline__ double vm_angle(double f, bool negative) {
   return negative ? -theta : theta;
 }
 
-__device__ __forceinline__ double vonmises_draw(const RngKey &k, uint32_t site, double kappa) {
+__device__ __forceinline__ double vonmises_draw(const RngKey &k, uint32_t site, double kappa, uint32_t sub0 = 0) {
   kappa = vm_clamp(kappa);
   const double r = vm_envelope(kappa);
   double f = 1.0;
   bool negative = false;
-  for (uint32_t attempt = 0; !vm_attempt(k, site, attempt, kappa, r, f, negative); ++attempt) {
+  for (uint32_t attempt = 0; !vm_attempt(k, site, attempt, kappa, r, f, negative, sub0); ++attempt) {
   }
   return vm_angle(f, negative);
 }
@@ -349,6 +351,41 @@ __device__ __forceinline__ double expcos_draw(const RngKey &k, uint32_t site, do
 // rotoraction.cc:20-37 -> expsin2distribution.hh:45-58
 __device__ __forceinline__ double expsin2_draw(const RngKey &k, uint32_t site, double sigma) {
   return vonmises_draw(k, site, 0.5 * sigma);
+}
+
+// exp(-z) I0(z), z >= 0 (the normalisation of the rotor's conditioned fine action): power series in
+// z^2/4 for z < 30 (all terms positive: no cancellation), Hankel asymptotic series beyond.  Relative
+// accuracy ~1e-15.  The reference calls gsl_sf_bessel_I0_scaled (expsin2distribution.cc:7-17).
+__device__ __forceinline__ double bessel_i0_scaled(double z) {
+  if (z < 30.0) {
+    const double q = 0.25 * z * z;
+    double term = 1.0, sum = 1.0;
+    for (int k = 1; k < 120; ++k) {
+      term *= q / ((double)k * (double)k);
+      sum += term;
+      if (term < 1e-17 * sum) break;
+    }
+    return exp(-z) * sum;
+  }
+  const double w = 1.0 / (8.0 * z);
+  double term = 1.0, sum = 1.0;
+  for (int k = 1; k < 30; ++k) {
+    const double odd = 2.0 * k - 1.0;
+    term *= odd * odd * w / (double)k;
+    sum += term;
+    if (term < 1e-17 * sum) break;
+  }
+  return sum / sqrt(kTwoPi * z);
+}
+
+// ExpSin2Distribution::fast_2pi_I0_scaled (expsin2distribution.cc:7-17), including the reference's
+// three-term expansion for z > 100
+__device__ __forceinline__ double two_pi_i0_scaled(double z) {
+  if (z > 100.) {
+    const double zi = 1. / z;
+    return sqrt(2. * kPi * zi) * (1. + 0.125 * zi + 0.0703125 * zi * zi);
+  }
+  return 2. * kPi * bessel_i0_scaled(z);
 }
 
 // ---- LDS reads that stay ds_read_b64 ---------------------------------------------------------------------

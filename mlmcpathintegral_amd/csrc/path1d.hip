@@ -514,7 +514,13 @@ __global__ void __launch_bounds__(256)
 // quartic quarticoscillatoraction.hh:160-194: W'' = (2/a + a mu2) m0 + 3 lambda a (xbar - x0)^2, x0 by 4 fixed-point steps
 template <int KIND>
 __device__ __forceinline__ void w_conditioned(const PathP &P, double x_m, double x_p, double &w_min, double &w_curv) {
-  if (KIND == MLMCPI_HARMONIC) {
+  if (KIND == MLMCPI_ROTOR) {  // rotoraction.hh:195-213
+    double sm, cm, sp, cp;
+    sincos(x_m, &sm, &cm);
+    sincos(x_p, &sp, &cp);
+    w_min = atan2(sp + sm, cp + cm);
+    w_curv = 2.0 * P.m0 / P.a * fabs(cos(0.5 * (x_p - x_m)));
+  } else if (KIND == MLMCPI_HARMONIC) {
     w_curv = (2. / P.a + P.a * P.mu2) * P.m0;
     w_min = (0.5 / (1. + 0.5 * P.a * P.a * P.mu2)) * (x_m + x_p);
   } else {
@@ -552,16 +558,31 @@ __global__ void __launch_bounds__(256)
     const double x_m = xc[j], x_p = xc[jn];
     double w_min, w_curv;
     w_conditioned<KIND>(Pf, x_m, x_p, w_min, w_curv);
-    const double sigma = 1. / sqrt(w_curv);
-    const double fill = w_min + rng_normal0(key, 2 * j + 1, P_FILLIN, 0) * sigma;
+    double fill;
+    if (KIND == MLMCPI_ROTOR) {
+      // RotorConditionedFineAction (action/qm/rotorconditionedfineaction.cc:7-43): fill-in from the
+      // ExpSin2 law with sigma = 2 W'' (a von Mises law, see device_common.hpp), -log of its density
+      const double sigma = 2. * w_curv;
+      fill = mod_2pi(w_min + vonmises_draw(key, 2 * j + 1, 0.5 * sigma, kVmFillin));
+      const double sh = sin(0.5 * (fill - w_min));
+      acc[0] += sigma * sh * sh + log(two_pi_i0_scaled(0.5 * sigma));
+    } else {
+      const double sigma = 1. / sqrt(w_curv);
+      fill = w_min + rng_normal0(key, 2 * j + 1, P_FILLIN, 0) * sigma;
+      const double dxp = fill - w_min;
+      acc[0] += 0.5 * w_curv * dxp * dxp - 0.5 * log(w_curv);
+    }
     tp[2 * j] = x_m;
     tp[2 * j + 1] = fill;
-    const double dxp = fill - w_min;
-    acc[0] += 0.5 * w_curv * dxp * dxp - 0.5 * log(w_curv);
     const double t_m = th[2 * j], t_p = th[2 * jn];
     w_conditioned<KIND>(Pf, t_m, t_p, w_min, w_curv);
     const double dx = th[2 * j + 1] - w_min;
-    acc[1] += 0.5 * w_curv * dx * dx - 0.5 * log(w_curv);
+    if (KIND == MLMCPI_ROTOR) {
+      const double sigma = 2. * w_curv, sh = sin(0.5 * dx);
+      acc[1] += sigma * sh * sh + log(two_pi_i0_scaled(0.5 * sigma));
+    } else {
+      acc[1] += 0.5 * w_curv * dx * dx - 0.5 * log(w_curv);
+    }
   }
   block_sum<2>(acc, red);
   if (threadIdx.x == 0) {
@@ -873,9 +894,6 @@ int mlmcpi_path_twolevel_draw(const mlmcpi_path_action *fine, const mlmcpi_path_
   MLMCPI_REQUIRE(d_x_coarse && d_theta && d_work && d_accept && B > 0, "bad arguments");
   MLMCPI_REQUIRE(fine->M % 2 == 0 && coarse->M == fine->M / 2 && coarse->kind == fine->kind,
                  "coarse action must live on the lattice with half the sites (M %u vs %u)", coarse->M, fine->M);
-  // conditionedfineaction.hh: the Gaussian fill-in exists for the harmonic and quartic oscillators
-  if (fine->kind == MLMCPI_ROTOR)
-    return fail(MLMCPI_ERR_UNSUPPORTED, "Gaussian conditioned fine action not defined for the rotor action");
   hipStream_t st = as_stream(stream);
   const PathP Pf = make_params(*fine), Pc = make_params(*coarse);
   const uint32_t nblk = twolevel_blocks(Pf.M, B);
@@ -889,8 +907,10 @@ int mlmcpi_path_twolevel_draw(const mlmcpi_path_action *fine, const mlmcpi_path_
   dim3 grid(nblk, B), block(256);
   if (Pf.kind == MLMCPI_HARMONIC)
     hipLaunchKernelGGL(twolevel_propose_kernel<MLMCPI_HARMONIC>, grid, block, 0, st, Pf, d_x_coarse, (const double *)d_theta, theta_prime, cfa, key);
-  else
+  else if (Pf.kind == MLMCPI_QUARTIC)
     hipLaunchKernelGGL(twolevel_propose_kernel<MLMCPI_QUARTIC>, grid, block, 0, st, Pf, d_x_coarse, (const double *)d_theta, theta_prime, cfa, key);
+  else
+    hipLaunchKernelGGL(twolevel_propose_kernel<MLMCPI_ROTOR>, grid, block, 0, st, Pf, d_x_coarse, (const double *)d_theta, theta_prime, cfa, key);
   MLMCPI_LAUNCH_CHECK("twolevel_propose_kernel");
   if (int rc = launch_reduce<R_ENERGY>(Pf, theta_prime, B, energy_scale(Pf), en4, st)) return rc;
   if (int rc = launch_reduce<R_ENERGY>(Pf, d_theta, B, energy_scale(Pf), en4 + B, st)) return rc;

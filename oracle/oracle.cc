@@ -158,7 +158,8 @@ double expcos_draw(Src &src, double beta, double x_p, double x_m) {
 // envelope of Best & Fisher (Appl. Statist. 28 (1979) 152-157), whose acceptance rate is >= 0.65
 // for every concentration.  Equality in distribution with the reference's samplers is a test
 // (tests/test_distributions.py), not an assumption.
-inline double dev_vonmises(const DevRng &rng, uint32_t site, double kappa) {
+constexpr uint32_t kVmFillin = 1u << 23;  // sub-stream of the two-level fill-in draws
+inline double dev_vonmises(const DevRng &rng, uint32_t site, double kappa, uint32_t sub0 = 0) {
   kappa = std::fmax(kappa, 1e-12);  // also maps NaN to a finite concentration: the loop always ends
   const double s = std::sqrt(1. + 4. * kappa * kappa);
   const double a = 1. + s;
@@ -168,7 +169,7 @@ inline double dev_vonmises(const DevRng &rng, uint32_t site, double kappa) {
   double f = 1.0;
   bool negative = false;
   for (uint32_t attempt = 0; attempt < 1024u; ++attempt) {
-    Philox4 w = rng.raw(site, P_VONMISES, attempt);
+    Philox4 w = rng.raw(site, P_VONMISES, sub0 | attempt);
     const double u1 = u01(w.v[0], w.v[1]), u2 = u01(w.v[2], w.v[3]);
     negative = (w.v[0] & 1u) != 0;  // bit 0 is not part of u1 (u01 drops the low 11 bits)
     const double z = std::cos(kPi * u1);
@@ -594,18 +595,30 @@ int dev_hmc_trajectory(const ActionO &A, double *x, unsigned nt, double dt, cons
 // action/qm/gaussianconditionedfineaction.cc:7-43 and action/qm/qmaction.cc:7-24.
 // theta (fine, current state of the step) is updated in place on acceptance; terms = the three action
 // differences (fine, coarse, trial).
-double cfa_gaussian(const ActionO &F, const double *x) {  // gaussianconditionedfineaction.cc:27-43, same order
-  unsigned M = F.M;
-  double xm = x[M - 2], xp = x[0];
-  double dx = x[M - 1] - F.w_minimum(xm, xp);
-  double curv = F.w_curvature(xm, xp);
-  double S = 0.5 * curv * dx * dx - 0.5 * std::log(curv);
-  for (unsigned j = 0; j < M / 2 - 1; ++j) {
-    xm = x[2 * j]; xp = x[2 * j + 2];
-    double d = x[2 * j + 1] - F.w_minimum(xm, xp);
-    double c = F.w_curvature(xm, xp);
-    S += 0.5 * c * d * d - 0.5 * std::log(c);
+// distribution/expsin2distribution.cc:7-24; std::cyl_bessel_i stands in for gsl_sf_bessel_I0_scaled (GSL is
+// not in this image)
+double two_pi_i0_scaled(double z) {
+  if (z > 100.) {
+    double zi = 1. / z;
+    return std::sqrt(2. * kPi * zi) * (1. + 0.125 * zi + 0.0703125 * zi * zi);
   }
+  return 2. * kPi * std::exp(-z) * std::cyl_bessel_i(0.0, z);
+}
+double expsin2_neg_log_pdf(double x, double sigma) {
+  double sh = std::sin(0.5 * x);
+  return -std::log(std::exp(-sigma * sh * sh) / two_pi_i0_scaled(0.5 * sigma));
+}
+
+// gaussianconditionedfineaction.cc:27-43 / rotorconditionedfineaction.cc:26-43, same summation order
+double cfa_term(const ActionO &F, double x, double xm, double xp) {
+  double d = x - F.w_minimum(xm, xp), c = F.w_curvature(xm, xp);
+  if (F.kind == ROTOR) return expsin2_neg_log_pdf(d, 2.0 * c);
+  return 0.5 * c * d * d - 0.5 * std::log(c);
+}
+double cfa_gaussian(const ActionO &F, const double *x) {
+  unsigned M = F.M;
+  double S = cfa_term(F, x[M - 1], x[M - 2], x[0]);
+  for (unsigned j = 0; j < M / 2 - 1; ++j) S += cfa_term(F, x[2 * j + 1], x[2 * j], x[2 * j + 2]);
   return S;
 }
 
@@ -616,7 +629,13 @@ int dev_twolevel_draw(const ActionO &F, const ActionO &Cc, const double *x_coars
   for (unsigned j = 0; j < Mc; ++j) tp[2 * j] = x_coarse[j];  // copy_from_coarse
   for (unsigned j = 0; j < Mc; ++j) {                         // fill_fine_points
     double xm = tp[2 * j], xp = tp[(2 * j + 2) % M];
-    double x0 = F.w_minimum(xm, xp), sigma = 1. / std::sqrt(F.w_curvature(xm, xp));
+    double x0 = F.w_minimum(xm, xp);
+    if (F.kind == ROTOR) {  // rotorconditionedfineaction.cc:7-24
+      double sigma = 2. * F.w_curvature(xm, xp);
+      tp[2 * j + 1] = wrap_2pi(x0 + dev_vonmises(rng, 2 * j + 1, 0.5 * sigma, kVmFillin));
+      continue;
+    }
+    double sigma = 1. / std::sqrt(F.w_curvature(xm, xp));
     double n0, n1;
     rng.normals(2 * j + 1, P_FILLIN, 0, n0, n1);
     tp[2 * j + 1] = x0 + n0 * sigma;

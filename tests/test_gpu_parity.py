@@ -281,11 +281,15 @@ def test_hmc_n_rep_short_circuit(gpu_ops, orc):
     assert seen == {0, 1}, "test should exercise both outcomes"
 
 
-@pytest.mark.parametrize("name,M,B", [("harmonic", 64, 3), ("quartic", 64, 3), ("quartic", 1000, 2), ("quartic", 32768, 2)])
+@pytest.mark.parametrize("name,M,B", [("harmonic", 64, 3), ("quartic", 64, 3), ("quartic", 1000, 2), ("quartic", 32768, 2),
+                                      ("rotor", 64, 3), ("rotor", 4096, 2)])
 def test_twolevel_step_matches_oracle(gpu_ops, orc, name, M, B):
-    """TwoLevelMetropolisStep::draw with the Gaussian fill-in: trial state, the three action differences,
-    accept flags and the updated fine state against the oracle's device-order restatement."""
+    """TwoLevelMetropolisStep::draw with the action's conditioned fine action (Gaussian fill-in for the
+    oscillators, ExpSin2 fill-in for the rotor): trial state, the three action differences, accept flags and
+    the updated fine state against the oracle's device-order restatement."""
     p = dict(M=M, T_final=M / 8.0, m0=1.0, mu2=1.0)
+    if name == "rotor":
+        p = dict(M=M, T_final=M / 8.0, m0=0.25)
     if name == "quartic":
         p.update(lam=1.0, x0=1.0)
     pc = dict(p, M=M // 2)
@@ -294,6 +298,8 @@ def test_twolevel_step_matches_oracle(gpu_ops, orc, name, M, B):
     rng = np.random.default_rng(M)
     step = gpu_ops.PathTwoLevelStep(fine, coarse, B, seed=SEED, chain0=9)
     theta0 = rng.normal(0.5, 0.6, (B, M))
+    if name == "rotor":
+        theta0 = rng.uniform(-np.pi, np.pi, (B, M))
     step.set_state(dev(theta0))
     theta = theta0.copy()
     seen = set()
@@ -309,7 +315,7 @@ def test_twolevel_step_matches_oracle(gpu_ops, orc, name, M, B):
             assert acc[b] == a, (t, b, want)
             seen.add(int(a))
         assert_close(step.theta.cpu().numpy(), theta, tol=1e-12, what=f"fine state after draw {t}")
-    if name == "quartic":  # (for the HO the Gaussian fill-in is exact and these proposals are all accepted)
+    if name in ("quartic", "rotor"):  # (for the HO the Gaussian fill-in is exact: these proposals are all accepted)
         assert seen == {0, 1}
 
 
@@ -359,8 +365,8 @@ def test_config5_hierarchy_matches_oracle(gpu_ops, orc):
 
 def test_twolevel_step_errors(gpu_ops):
     from mlmcpathintegral_amd import abi
-    with pytest.raises(abi.MlmcpiError, match="not defined for the rotor"):
-        gpu_ops.PathTwoLevelStep(abi.path_action(2, 64, 8.0, 0.25), abi.path_action(2, 32, 8.0, 0.25), 1).draw(
+    with pytest.raises(abi.MlmcpiError, match="half the sites"):
+        gpu_ops.PathTwoLevelStep(abi.path_action(2, 64, 8.0, 0.25), abi.path_action(0, 32, 8.0, 0.25), 1).draw(
             torch.zeros((1, 32), dtype=torch.float64, device="cuda"))
     with pytest.raises(abi.MlmcpiError, match="half the sites"):
         gpu_ops.PathTwoLevelStep(abi.path_action(1, 64, 8.0), abi.path_action(1, 16, 8.0), 1).draw(

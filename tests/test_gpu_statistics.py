@@ -151,3 +151,45 @@ def test_hierarchical_twolevel_chain_samples_fine_distribution(gpu_ops):
     exact = oracle.lib().orc_ho_xsquared_analytical(M, T, 1.0, 1.0)
     print(f"hierarchical two-level <x^2> = {m:.6f} +- {e:.6f} (fine-level analytic {exact:.6f})")
     assert abs(m - exact) < 4 * e
+
+
+def test_rotor_hierarchical_chain_samples_fine_distribution(gpu_ops, orc):
+    """Rotor: coarse-level overrelaxed heat bath + TwoLevelMetropolisStep with the ExpSin2 conditioned fine
+    action (action/qm/rotorconditionedfineaction.cc) must sample the FINE-level distribution: topological
+    susceptibility and <cos(x_1 - x_0)> against a direct fine-level heat-bath chain."""
+    from mlmcpathintegral_amd import abi
+    M, T, m0, B = 32, 4.0, 0.25, 512
+    fine, coarse = abi.path_action(2, M, T, m0), abi.path_action(2, M // 2, T, m0)
+    xc = gpu_ops.path_initialise(coarse, B, SEED)
+    scratch = torch.empty_like(xc)
+    step = gpu_ops.PathTwoLevelStep(fine, coarse, B, seed=SEED + 1)
+    step.set_state(gpu_ops.path_initialise(fine, B, SEED + 2))
+    chi, cosd, sweep, n_acc = [], [], 0, 0
+    burn, n = 200, 1500
+    for k in range(burn + n):
+        gpu_ops.path_sweep_draw(coarse, xc, scratch, 1, 1, SEED, 0, sweep)
+        sweep += 2
+        acc = step.draw(xc)
+        xc.copy_(step.theta[:, ::2])                                     # hierarchicalsampler.cc:57-60
+        if k >= burn:
+            n_acc += float(acc.double().mean())
+            chi.append(gpu_ops.qoi_susceptibility(step.theta, T))
+            cosd.append(torch.cos(step.theta[:, 1] - step.theta[:, 0]))
+    mchi, echi = chain_mean_and_error(torch.stack(chi))
+    mcos, ecos = chain_mean_and_error(torch.stack(cosd))
+    # direct fine-level chain
+    x = gpu_ops.path_initialise(fine, B, SEED + 3)
+    sc = torch.empty_like(x)
+    dcos, dchi = [], []
+    for k in range(burn + n):
+        gpu_ops.path_sweep_draw(fine, x, sc, 1, 1, SEED + 3, 0, 2 * k)
+        if k >= burn:
+            dcos.append(torch.cos(x[:, 1] - x[:, 0]))
+            dchi.append(gpu_ops.qoi_susceptibility(x, T))
+    rcos, rerr = chain_mean_and_error(torch.stack(dcos))
+    rchi, rchierr = chain_mean_and_error(torch.stack(dchi))
+    print(f"rotor two-level: p_accept {n_acc / n:.3f}; chi_t {mchi:.5f} +- {echi:.5f} vs direct {rchi:.5f} +- {rchierr:.5f}; "
+          f"cos {mcos:.5f} +- {ecos:.5f} vs direct {rcos:.5f} +- {rerr:.5f}")
+    assert n_acc / n > 0.3
+    assert abs(mchi - rchi) < 4 * math.hypot(echi, rchierr)
+    assert abs(mcos - rcos) < 4 * math.hypot(ecos, rerr)
