@@ -197,6 +197,21 @@ int mlmcpi_lattice_copy_from_fine(const mlmcpi_lattice_action *fine, uint32_t rt
                                   double *d_coarse, uint32_t B, void *stream);
 int mlmcpi_lattice_copy_from_coarse(const mlmcpi_lattice_action *fine, uint32_t rt, uint32_t rx, const double *d_coarse,
                                     double *d_fine, uint32_t B, void *stream);
+/* TwoLevelMetropolisStep::draw (montecarlo/twolevelmetropolisstep.cc:35-89) on the quenched Schwinger lattice
+ * with semi-coarsening (CoarsenTemporal / CoarsenSpatial / the levels of CoarsenAlternate): copy_from_coarse,
+ * QuenchedSchwingerSemiConditionedFineAction::{fill_fine_points, evaluate}
+ * (action/qft/quenchedschwingerconditionedfineaction.cc:130-204, 332-379), copy_from_fine, the three action
+ * differences, the Metropolis test and the copy of accepted states.  `coarse` carries the coarse lattice extents
+ * (one of them half the fine one) and the coarse beta (QuenchedSchwingerAction::coarse_action).
+ *   d_phi_coarse [B][2 Mt_c Mx_c]  coarse-level proposal;  d_theta [B][2 Mt Mx]  current fine state (updated when
+ *   accepted);  d_accept [B];  d_terms [B][3] = (dS_fine, dS_coarse, dS_trial) or NULL.
+ * Coarsening in both directions (Bessel-product fill-in) returns MLMCPI_ERR_UNSUPPORTED. */
+int mlmcpi_lattice_twolevel_workspace_bytes(const mlmcpi_lattice_action *fine, const mlmcpi_lattice_action *coarse,
+                                            uint32_t B, size_t *bytes);
+int mlmcpi_lattice_twolevel_draw(const mlmcpi_lattice_action *fine, const mlmcpi_lattice_action *coarse,
+                                 const double *d_phi_coarse, double *d_theta, uint32_t B, uint64_t seed,
+                                 uint32_t chain0, uint32_t step, void *d_work, int32_t *d_accept, double *d_terms,
+                                 void *stream);
 /* QoI2DPhiSquared (qoi/qft/qoi2dphisquared.cc:8-15), QoIAvgPlaquette (qoi/qft/qoiavgplaquette.cc:8-27),
  * QoI2DSusceptibility (qoi/qft/qoi2dsusceptibility.cc:8-27); d_out[b]. */
 int mlmcpi_qoi_phi_squared(const double *d_phi, uint32_t n_vertices, uint32_t B, double *d_out, void *stream);

@@ -342,10 +342,10 @@ __device__ __forceinline__ void expcos_params(double beta, double x_p, double x_
 }
 
 __device__ __forceinline__ double expcos_draw(const RngKey &k, uint32_t site, double beta, double x_p,
-                                              double x_m) {
+                                              double x_m, uint32_t sub0 = 0) {
   double tau, centre;
   expcos_params(beta, x_p, x_m, tau, centre);
-  return mod_2pi_fast(vonmises_draw(k, site, tau) + centre);
+  return mod_2pi_fast(vonmises_draw(k, site, tau, sub0) + centre);
 }
 
 // rotoraction.cc:20-37 -> expsin2distribution.hh:45-58
@@ -386,6 +386,20 @@ __device__ __forceinline__ double two_pi_i0_scaled(double z) {
     return sqrt(2. * kPi * zi) * (1. + 0.125 * zi + 0.0703125 * zi * zi);
   }
   return 2. * kPi * bessel_i0_scaled(z);
+}
+
+// -log of ExpCosDistribution::evaluate(x, x_p, x_m) (distribution/expcosdistribution.cc:7-21)
+__device__ __forceinline__ double expcos_neg_log_pdf(double beta, double x, double x_p, double x_m) {
+  double dx = x_p - x_m, z = x - x_m;
+  double flip = (dx < 0.0) ? -1.0 : 1.0;
+  dx *= flip;
+  if (dx > kPi) {
+    flip = -flip;
+    dx = kTwoPi - dx;
+  }
+  z *= flip;
+  const double sigma = 2. * beta * fabs(cos(0.5 * dx));
+  return -sigma * (cos(z - 0.5 * dx) - 1.0) + log(kTwoPi * bessel_i0_scaled(sigma));
 }
 
 // ---- LDS reads that stay ds_read_b64 ---------------------------------------------------------------------

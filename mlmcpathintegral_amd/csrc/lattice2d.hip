@@ -1203,3 +1203,202 @@ int mlmcpi_lattice_copy_from_coarse(const mlmcpi_lattice_action *fine, uint32_t 
 }
 
 }  // extern "C"
+
+// =================================================================================================
+// Two-level Metropolis step on the Schwinger lattice with semi-coarsening (one direction halved):
+//   TwoLevelMetropolisStep::draw                               montecarlo/twolevelmetropolisstep.cc:35-89
+//   QuenchedSchwingerAction::copy_from_{coarse,fine}           action/qft/quenchedschwingeraction.cc:92-195
+//   QuenchedSchwingerSemiConditionedFineAction::{fill_fine_points,evaluate}
+//                                                              action/qft/quenchedschwingerconditionedfineaction.cc:130-204,332-379
+// One coarse cell (i, j) owns two fine vertices.  In the coarsened direction d the coarse link splits into a
+// pair  a0 = theta_c/2 + dtheta, a1 = theta_c/2 - dtheta  (dtheta ~ U(-pi, pi)); the coarse link in the other
+// direction is copied; the remaining fine link (direction 1-d, between the two halves) is drawn from its
+// heat-bath conditional (ExpCos) given the staples  theta_p = s0 + b0 - a0,  theta_m = a1 + s2 - b1, where
+// (b0, b1) is the pair of the neighbouring cell and s2 the copied link of the next cell.  The neighbour's pair
+// is recomputed from its own Philox stream (no exchange).  RNG: dtheta of coarse cell c = Philox(site c,
+// P_FILLIN, 0); the ExpCos draw of fine link l = von Mises stream (site l, kVmFillin).
+// =================================================================================================
+namespace mlmcpi {
+
+// theta (fine, double2 per vertex) in reference order; rt = 2: temporal coarsening, else spatial (rx = 2).
+// partial[(b * gridDim.x + blockIdx.x) * 2 + {0, 1}] = CFA sums of (theta', theta).
+__global__ void __launch_bounds__(256)
+    schwinger_twolevel_propose_kernel(uint32_t Mtc, uint32_t Mxc, uint32_t rt, double beta,
+                                      const double2 *__restrict__ coarse_all, const double2 *__restrict__ theta_all,
+                                      double2 *__restrict__ prime_all, double *__restrict__ partial, RngKey key0) {
+  __shared__ double red[2 * 4];
+  const uint32_t b = blockIdx.y;
+  const uint32_t Mtf = (rt == 2) ? 2 * Mtc : Mtc, Mxf = (rt == 2) ? Mxc : 2 * Mxc;
+  const double2 *coarse = coarse_all + (size_t)b * Mtc * Mxc;
+  const double2 *theta = theta_all + (size_t)b * Mtf * Mxf;
+  double2 *prime = prime_all + (size_t)b * Mtf * Mxf;
+  RngKey key = key0;
+  key.chain += b;
+  double acc[2] = {0.0, 0.0};
+  for (uint32_t j = blockIdx.x; j < Mxc; j += gridDim.x) {
+    const uint32_t jp = j + 1 == Mxc ? 0 : j + 1;
+    for (uint32_t i = threadIdx.x; i < Mtc; i += blockDim.x) {
+      const uint32_t ip = i + 1 == Mtc ? 0 : i + 1;
+      const uint32_t c = j * Mtc + i;
+      // neighbour cell in the direction the pair does NOT point in, and the next cell along the pair
+      const uint32_t cn = (rt == 2) ? jp * Mtc + i : j * Mtc + ip;
+      const uint32_t cs = (rt == 2) ? j * Mtc + ip : jp * Mtc + i;
+      const double2 lc = coarse[c], ln = coarse[cn], ls = coarse[cs];
+      const double pair_c = (rt == 2) ? lc.x : lc.y, pair_n = (rt == 2) ? ln.x : ln.y;
+      const double s0 = (rt == 2) ? lc.y : lc.x, s2 = (rt == 2) ? ls.y : ls.x;
+      double u, v;
+      rng_uniforms(key, c, P_FILLIN, 0, u, v);
+      const double d_c = (2. * u - 1.) * kPi;
+      rng_uniforms(key, cn, P_FILLIN, 0, u, v);
+      const double d_n = (2. * u - 1.) * kPi;
+      const double a0 = mod_2pi(0.5 * pair_c + d_c), a1 = mod_2pi(0.5 * pair_c - d_c);
+      const double b0 = mod_2pi(0.5 * pair_n + d_n), b1 = mod_2pi(0.5 * pair_n - d_n);
+      const double th_p = mod_2pi(s0 + b0 - a0), th_m = mod_2pi(a1 + s2 - b1);
+      // fine vertices of this cell and the linear index of the filled link
+      size_t v0, v1;
+      uint32_t l_fill;
+      if (rt == 2) {
+        v0 = (size_t)j * Mtf + 2 * i;
+        v1 = v0 + 1;
+        l_fill = 2 * (uint32_t)v1 + 1;
+      } else {
+        v0 = (size_t)(2 * j) * Mtf + i;
+        v1 = v0 + Mtf;
+        l_fill = 2 * (uint32_t)v1;
+      }
+      const double fill = expcos_draw(key, l_fill, beta, th_p, th_m, kVmFillin);
+      if (rt == 2) {
+        prime[v0] = make_double2(a0, s0);
+        prime[v1] = make_double2(a1, fill);
+      } else {
+        prime[v0] = make_double2(s0, a0);
+        prime[v1] = make_double2(fill, a1);
+      }
+      acc[0] += expcos_neg_log_pdf(beta, fill, th_p, th_m);
+      // the same term for the current fine state
+      double t_a0, t_a1, t_b0, t_b1, t_s0, t_s2, t_x;
+      if (rt == 2) {
+        const uint32_t i2 = 2 * i, i2p = (i2 + 2 == Mtf) ? 0 : i2 + 2;
+        const double2 q0 = theta[(size_t)j * Mtf + i2], q1 = theta[(size_t)j * Mtf + i2 + 1];
+        const double2 n0 = theta[(size_t)jp * Mtf + i2], n1 = theta[(size_t)jp * Mtf + i2 + 1];
+        t_a0 = q0.x; t_a1 = q1.x; t_s0 = q0.y; t_x = q1.y; t_b0 = n0.x; t_b1 = n1.x;
+        t_s2 = theta[(size_t)j * Mtf + i2p].y;
+      } else {
+        const uint32_t j2 = 2 * j, j2p = (j2 + 2 == Mxf) ? 0 : j2 + 2;
+        const double2 q0 = theta[(size_t)j2 * Mtf + i], q1 = theta[(size_t)(j2 + 1) * Mtf + i];
+        const double2 n0 = theta[(size_t)j2 * Mtf + ip], n1 = theta[(size_t)(j2 + 1) * Mtf + ip];
+        t_a0 = q0.y; t_a1 = q1.y; t_s0 = q0.x; t_x = q1.x; t_b0 = n0.y; t_b1 = n1.y;
+        t_s2 = theta[(size_t)j2p * Mtf + i].x;
+      }
+      acc[1] += expcos_neg_log_pdf(beta, mod_2pi(t_x), mod_2pi(-t_a0 + t_s0 + t_b0), mod_2pi(t_a1 + t_s2 - t_b1));
+    }
+  }
+  block_sum<2>(acc, red);
+  if (threadIdx.x == 0) {
+    partial[((size_t)b * gridDim.x + blockIdx.x) * 2 + 0] = acc[0];
+    partial[((size_t)b * gridDim.x + blockIdx.x) * 2 + 1] = acc[1];
+  }
+}
+
+// en4 = [4][B]: S_f(theta'), S_f(theta), S_c(theta_C), S_c(phi_c); twolevelmetropolisstep.cc:46-84
+__global__ void __launch_bounds__(256)
+    lattice_twolevel_accept_kernel(uint32_t n, double *__restrict__ theta, const double *__restrict__ theta_prime,
+                                   const double *__restrict__ en4, const double *__restrict__ cfa_partial, uint32_t nblk,
+                                   uint32_t B, int32_t *__restrict__ accept, double *__restrict__ terms, RngKey key0) {
+  const uint32_t b = blockIdx.y;
+  double cfa_p = 0.0, cfa_c = 0.0;
+  for (uint32_t k = 0; k < nblk; ++k) {
+    cfa_p += cfa_partial[((size_t)b * nblk + k) * 2 + 0];
+    cfa_c += cfa_partial[((size_t)b * nblk + k) * 2 + 1];
+  }
+  const double dS_fine = en4[b] - en4[B + b];
+  const double dS_coarse = en4[2 * B + b] - en4[3 * B + b];
+  const double dS_trial = cfa_c - cfa_p;
+  const double dS = dS_fine + dS_coarse + dS_trial;
+  bool acc;
+  if (dS < 0.0) {
+    acc = true;
+  } else {
+    RngKey key = key0;
+    key.chain += b;
+    double u, v;
+    rng_uniforms(key, 0, P_ACCEPT2, 0, u, v);
+    acc = u < exp(-dS);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    accept[b] = acc ? 1 : 0;
+    if (terms) {
+      terms[3 * b + 0] = dS_fine; terms[3 * b + 1] = dS_coarse; terms[3 * b + 2] = dS_trial;
+    }
+  }
+  if (!acc) return;
+  const size_t off = (size_t)b * n;
+  for (uint32_t l = blockIdx.x * blockDim.x + threadIdx.x; l < n; l += gridDim.x * blockDim.x)
+    theta[off + l] = theta_prime[off + l];
+}
+
+}  // namespace mlmcpi
+
+extern "C" {
+
+static int check_twolevel(const mlmcpi_lattice_action *fine, const mlmcpi_lattice_action *coarse, uint32_t *rt, uint32_t *rx) {
+  if (int rc = check_lattice(fine)) return rc;
+  if (int rc = check_lattice(coarse)) return rc;
+  if (fine->kind != MLMCPI_SCHWINGER || coarse->kind != MLMCPI_SCHWINGER)
+    return fail(MLMCPI_ERR_UNSUPPORTED, "two-level step: only the quenched Schwinger action has a device conditioned fine action");
+  *rt = (coarse->Mt && fine->Mt == 2 * coarse->Mt) ? 2 : (fine->Mt == coarse->Mt ? 1 : 0);
+  *rx = (coarse->Mx && fine->Mx == 2 * coarse->Mx) ? 2 : (fine->Mx == coarse->Mx ? 1 : 0);
+  if (*rt == 0 || *rx == 0 || *rt * *rx == 1)
+    return fail(MLMCPI_ERR_INVALID, "invalid coarsening for fill-in (%u x %u from %u x %u)", coarse->Mt, coarse->Mx, fine->Mt, fine->Mx);
+  if (*rt * *rx == 4)
+    return fail(MLMCPI_ERR_UNSUPPORTED, "two-level step: coarsening in both directions (Bessel-product fill-in) is not available on the device");
+  return MLMCPI_OK;
+}
+
+// workspace: theta' | theta_C | energies [4][B] | CFA partials [B * nblk * 2]
+int mlmcpi_lattice_twolevel_workspace_bytes(const mlmcpi_lattice_action *fine, const mlmcpi_lattice_action *coarse,
+                                            uint32_t B, size_t *bytes) {
+  uint32_t rt, rx;
+  if (int rc = check_twolevel(fine, coarse, &rt, &rx)) return rc;
+  MLMCPI_REQUIRE(bytes && B > 0, "bad arguments");
+  const size_t nf = (size_t)2 * fine->Mt * fine->Mx, nc = (size_t)2 * coarse->Mt * coarse->Mx;
+  *bytes = align256_((size_t)B * nf * 8) + align256_((size_t)B * nc * 8) + align256_((size_t)4 * B * 8) +
+           align256_((size_t)B * row_blocks(coarse->Mx, B) * 2 * 8);
+  return MLMCPI_OK;
+}
+
+int mlmcpi_lattice_twolevel_draw(const mlmcpi_lattice_action *fine, const mlmcpi_lattice_action *coarse,
+                                 const double *d_phi_coarse, double *d_theta, uint32_t B, uint64_t seed, uint32_t chain0,
+                                 uint32_t step, void *d_work, int32_t *d_accept, double *d_terms, void *stream) {
+  uint32_t rt, rx;
+  if (int rc = check_twolevel(fine, coarse, &rt, &rx)) return rc;
+  MLMCPI_REQUIRE(d_phi_coarse && d_theta && d_work && d_accept && B > 0, "bad arguments");
+  hipStream_t st = as_stream(stream);
+  const size_t nf = (size_t)2 * fine->Mt * fine->Mx, nc = (size_t)2 * coarse->Mt * coarse->Mx;
+  char *w = (char *)d_work;
+  double *theta_prime = (double *)w;
+  w += align256_((size_t)B * nf * 8);
+  double *theta_c = (double *)w;
+  w += align256_((size_t)B * nc * 8);
+  double *en4 = (double *)w;
+  w += align256_((size_t)4 * B * 8);
+  double *cfa = (double *)w;
+  const RngKey key = make_key(seed, chain0, step);
+  const uint32_t nblk = row_blocks(coarse->Mx, B);
+  hipLaunchKernelGGL(schwinger_twolevel_propose_kernel, dim3(nblk, B), dim3(256), 0, st, coarse->Mt, coarse->Mx, rt,
+                     fine->beta, (const double2 *)d_phi_coarse, (const double2 *)d_theta, (double2 *)theta_prime, cfa, key);
+  MLMCPI_LAUNCH_CHECK("schwinger_twolevel_propose_kernel");
+  if (int rc = lattice_energy(fine, theta_prime, B, en4, st)) return rc;
+  if (int rc = lattice_energy(fine, d_theta, B, en4 + B, st)) return rc;
+  if (int rc = mlmcpi_lattice_copy_from_fine(fine, rt, rx, d_theta, theta_c, B, stream)) return rc;
+  if (int rc = lattice_energy(coarse, theta_c, B, en4 + 2 * (size_t)B, st)) return rc;
+  if (int rc = lattice_energy(coarse, d_phi_coarse, B, en4 + 3 * (size_t)B, st)) return rc;
+  uint32_t nb = (uint32_t)((nf + 255) / 256);
+  if (nb > 1024) nb = 1024;
+  hipLaunchKernelGGL(lattice_twolevel_accept_kernel, dim3(nb, B), dim3(256), 0, st, (uint32_t)nf, d_theta,
+                     (const double *)theta_prime, (const double *)en4, (const double *)cfa, nblk, B, d_accept, d_terms, key);
+  MLMCPI_LAUNCH_CHECK("lattice_twolevel_accept_kernel");
+  return MLMCPI_OK;
+}
+
+}  // extern "C"

@@ -127,6 +127,30 @@ class PathTwoLevelStep:
         return self.accept
 
 
+class LatticeTwoLevelStep:
+    """TwoLevelMetropolisStep on the Schwinger lattice, semi-coarsening (ExpCos fill-in), B device chains."""
+
+    def __init__(self, fine, coarse, B, seed=1, chain0=0, device="cuda"):
+        self.fine, self.coarse, self.B, self.seed, self.chain0 = fine, coarse, B, seed, chain0
+        nbytes = C.c_size_t(0)
+        abi.call("mlmcpi_lattice_twolevel_workspace_bytes", C.byref(fine), C.byref(coarse), B, C.byref(nbytes))
+        self.work = torch.empty(nbytes.value, dtype=torch.uint8, device=device)
+        self.accept = torch.zeros(B, dtype=torch.int32, device=device)
+        self.terms = torch.zeros((B, 3), dtype=torch.float64, device=device)
+        self.theta = torch.zeros((B, 2 * fine.Mt * fine.Mx), dtype=torch.float64, device=device)  # current fine state
+        self.step = 0
+
+    def set_state(self, x):
+        self.theta.copy_(x)
+
+    def draw(self, phi_coarse):
+        _check_state(phi_coarse, 2 * self.coarse.Mt * self.coarse.Mx)
+        abi.call("mlmcpi_lattice_twolevel_draw", C.byref(self.fine), C.byref(self.coarse), _p(phi_coarse), _p(self.theta),
+                 self.B, self.seed, self.chain0, self.step, _p(self.work), _p(self.accept), _p(self.terms), _stream())
+        self.step += 1
+        return self.accept
+
+
 def path_sweep_draw(act, x, scratch, n_overrelax, n_heatbath, seed, chain0, sweep0):
     _check_state(x, act.M)
     abi.call("mlmcpi_path_sweep_draw", C.byref(act), _p(x), _p(scratch), x.shape[0], n_overrelax, n_heatbath, seed,

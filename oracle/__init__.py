@@ -77,6 +77,9 @@ _SIGS = {
     "orc_dev_hmc_trajectory": (_i, [_vp, _dp, _u32, _d, _u64, _u32, _u32, _dp, _dp]),
     "orc_dev_initialise": (None, [_vp, _dp, _u64, _u32]),
     "orc_dev_twolevel_draw": (_i, [_vp, _vp, _dp, _dp, _u64, _u32, _u32, _dp]),
+    "orc_dev_lattice_twolevel_draw": (_i, [_vp, _vp, _dp, _dp, _u64, _u32, _u32, _dp]),
+    "orc_expcos_pdf": (_d, [_d, _d, _d, _d]),
+    "orc_i0_scaled": (_d, [_d]),
     "orc_schwinger_copy_from_fine": (None, [_i, _i, _i, _i, _dp, _dp]),
     "orc_schwinger_copy_from_coarse": (None, [_i, _i, _i, _i, _dp, _dp]),
     "orc_gff_transfer": (None, [_i, _i, _i, _i, _dp, _dp, _i]),
@@ -158,6 +161,14 @@ class Action:
         """self = fine action; returns (accept, [dS_fine, dS_coarse, dS_trial]); theta updated in place."""
         terms = np.zeros(3)
         acc = lib().orc_dev_twolevel_draw(self.h, coarse.h, np.ascontiguousarray(x_coarse), theta, seed, chain, step, terms)
+        return acc, terms
+
+    def dev_lattice_twolevel_draw(self, coarse, phi_coarse, theta, seed, chain, step):
+        """self = fine Schwinger action (semi-coarsening); returns (accept, terms); theta updated in place."""
+        terms = np.zeros(3)
+        acc = lib().orc_dev_lattice_twolevel_draw(self.h, coarse.h, np.ascontiguousarray(phi_coarse), theta, seed, chain, step, terms)
+        if acc < 0:
+            raise ValueError("invalid coarsening for fill-in")
         return acc, terms
 
     def dev_initialise(self, seed, chain):

@@ -658,6 +658,167 @@ int dev_twolevel_draw(const ActionO &F, const ActionO &Cc, const double *x_coars
   return acc ? 1 : 0;
 }
 
+// common/fastbessel.cc:7-55: exp(-z) I0(z); beyond z = 100 the reference sums the Hankel series with the
+// coefficients of fastbessel.hh:25-33 (4-7 terms), below it calls GSL (std::cyl_bessel_i stands in here).
+double fast_bessel_i0_scaled(double z) {
+  if (z > 100.) {
+    const int terms = z > 1100. ? 4 : (z > 400. ? 5 : (z > 200. ? 6 : 7));
+    double coeff[8];
+    coeff[0] = 1.0;
+    for (int n = 1; n <= terms; ++n) coeff[n] = 0.125 * (2.0 * n - 1.0) * (2.0 * n - 1.0) / n * coeff[n - 1];
+    const double zi = 1. / z;
+    double p = coeff[terms];
+    for (int n = terms - 1; n >= 0; --n) p = zi * p + coeff[n];
+    return p / std::sqrt(2. * kPi * z);
+  }
+  return std::exp(-z) * std::cyl_bessel_i(0.0, z);
+}
+
+// distribution/expcosdistribution.cc:7-21
+double expcos_pdf(double beta, double x, double x_p, double x_m) {
+  double dx = x_p - x_m, z = x - x_m;
+  int flip = (dx < 0.0) ? -1 : +1;
+  dx *= flip;
+  if (dx > kPi) {
+    flip *= -1;
+    dx = 2. * kPi - dx;
+  }
+  z *= flip;
+  const double sigma = 2. * beta * std::fabs(std::cos(0.5 * dx));
+  const double Z = 2. * kPi * fast_bessel_i0_scaled(sigma);
+  return 1. / Z * std::exp(sigma * (std::cos(z - 0.5 * dx) - 1.0));
+}
+
+// QuenchedSchwingerSemiConditionedFineAction::evaluate (quenchedschwingerconditionedfineaction.cc:332-379);
+// rt == 2: the fine lattice is twice as long in the temporal direction as the coarse one, else in the spatial one
+double schwinger_semi_cfa(const ActionO &F, int rt, const double *x) {
+  const Grid2 &g = F.g;
+  double S = 0.0;
+  if (rt == 2) {
+    for (int i = 0; i < g.Mt / 2; ++i)
+      for (int j = 0; j < g.Mx; ++j) {
+        double phi_p = wrap_2pi(-x[g.link(2 * i, j, 0)] + x[g.link(2 * i, j, 1)] + x[g.link(2 * i, j + 1, 0)]);
+        double phi_m = wrap_2pi(+x[g.link(2 * i + 1, j, 0)] + x[g.link(2 * i + 2, j, 1)] - x[g.link(2 * i + 1, j + 1, 0)]);
+        double theta = wrap_2pi(+x[g.link(2 * i + 1, j, 1)]);
+        S -= std::log(expcos_pdf(F.beta, theta, phi_p, phi_m));
+      }
+  } else {
+    for (int i = 0; i < g.Mt; ++i)
+      for (int j = 0; j < g.Mx / 2; ++j) {
+        double phi_p = wrap_2pi(-x[g.link(i, 2 * j, 1)] + x[g.link(i, 2 * j, 0)] + x[g.link(i + 1, 2 * j, 1)]);
+        double phi_m = wrap_2pi(+x[g.link(i, 2 * j + 1, 1)] + x[g.link(i, 2 * j + 2, 0)] - x[g.link(i + 1, 2 * j + 1, 1)]);
+        double theta = wrap_2pi(+x[g.link(i, 2 * j + 1, 0)]);
+        S -= std::log(expcos_pdf(F.beta, theta, phi_p, phi_m));
+      }
+  }
+  return S;
+}
+
+// quenchedschwingeraction.cc:147-195 (copy_from_fine: three coarsening cases); Mt, Mx = COARSE extents
+void schwinger_copy_from_fine(int Mt, int Mx, int rt, int rx, const double *fine, double *coarse) {
+  Grid2 gc{Mt, Mx, false}, gf{Mt * rt, Mx * rx, false};
+  for (int i = 0; i < Mt; ++i)
+    for (int j = 0; j < Mx; ++j) {
+      double t0 = fine[gf.link(rt * i, rx * j, 0)];
+      if (rt == 2) t0 += fine[gf.link(2 * i + 1, rx * j, 0)];
+      double t1 = fine[gf.link(rt * i, rx * j, 1)];
+      if (rx == 2) t1 += fine[gf.link(rt * i, 2 * j + 1, 1)];
+      coarse[gc.link(i, j, 0)] = wrap_2pi(t0);
+      coarse[gc.link(i, j, 1)] = wrap_2pi(t1);
+    }
+}
+// quenchedschwingeraction.cc:92-144 (copy_from_coarse)
+void schwinger_copy_from_coarse(int Mt, int Mx, int rt, int rx, const double *coarse, double *fine) {
+  Grid2 gc{Mt, Mx, false}, gf{Mt * rt, Mx * rx, false};
+  for (int i = 0; i < Mt; ++i)
+    for (int j = 0; j < Mx; ++j) {
+      double c0 = coarse[gc.link(i, j, 0)], c1 = coarse[gc.link(i, j, 1)];
+      if (rt == 2) {
+        fine[gf.link(2 * i, rx * j, 0)] = 0.5 * c0;
+        fine[gf.link(2 * i + 1, rx * j, 0)] = 0.5 * c0;
+      } else {
+        fine[gf.link(i, rx * j, 0)] = c0;
+      }
+      if (rx == 2) {
+        fine[gf.link(rt * i, 2 * j, 1)] = 0.5 * c1;
+        fine[gf.link(rt * i, 2 * j + 1, 1)] = 0.5 * c1;
+      } else {
+        fine[gf.link(rt * i, j, 1)] = c1;
+      }
+    }
+}
+
+// Two-level step on the Schwinger lattice, semi-coarsening, device order: twolevelmetropolisstep.cc:35-89 with
+// quenchedschwingeraction.cc:92-195 and QuenchedSchwingerSemiConditionedFineAction::fill_fine_points
+// (quenchedschwingerconditionedfineaction.cc:130-204).  dtheta of coarse cell c comes from Philox(site c,
+// P_FILLIN); the ExpCos draw of fine link l from the von Mises stream (site l, kVmFillin).
+int dev_schwinger_twolevel_draw(const ActionO &F, const ActionO &Cc, const double *phi_coarse, double *theta,
+                                const DevRng &rng, double *terms) {
+  const Grid2 &g = F.g, &gc = Cc.g;
+  const int rt = g.Mt / gc.Mt, rx = g.Mx / gc.Mx;
+  const unsigned nf = 2u * g.Mt * g.Mx, nc = 2u * gc.Mt * gc.Mx;
+  std::vector<double> tp(nf, 0.0), thetaC(nc);
+  schwinger_copy_from_coarse(gc.Mt, gc.Mx, rt, rx, phi_coarse, tp.data());
+  auto dtheta = [&](int i, int j) {  // coarse cell (i, j)
+    double u, v;
+    rng.uniforms((uint32_t)(j * gc.Mt + i), P_FILLIN, 0, u, v);
+    return (2. * u - 1.) * kPi;
+  };
+  auto draw = [&](unsigned l, double x_p, double x_m) {  // expcosdistribution.hh:51-65 with the device sampler
+    const double dx = x_m - x_p;
+    const double tau = 2. * F.beta * std::fabs(std::cos(0.5 * dx));
+    const double x = dev_vonmises(rng, l, tau, kVmFillin);
+    return wrap_2pi(x + 0.5 * (x_p + x_m) + (std::fabs(dx) > kPi ? kPi : 0.0));
+  };
+  if (rt == 2 && rx == 1) {
+    for (int i = 0; i < g.Mt / 2; ++i)
+      for (int j = 0; j < g.Mx; ++j) {
+        const double d = dtheta(i, j);
+        tp[g.link(2 * i, j, 0)] = wrap_2pi(tp[g.link(2 * i, j, 0)] + d);
+        tp[g.link(2 * i + 1, j, 0)] = wrap_2pi(tp[g.link(2 * i + 1, j, 0)] - d);
+      }
+    for (int i = 0; i < g.Mt / 2; ++i)
+      for (int j = 0; j < g.Mx; ++j) {
+        double theta_p = wrap_2pi(tp[g.link(2 * i, j, 1)] + tp[g.link(2 * i, j + 1, 0)] - tp[g.link(2 * i, j, 0)]);
+        double theta_m = wrap_2pi(tp[g.link(2 * i + 1, j, 0)] + tp[g.link(2 * i + 2, j, 1)] - tp[g.link(2 * i + 1, j + 1, 0)]);
+        const unsigned l = g.link(2 * i + 1, j, 1);
+        tp[l] = draw(l, theta_p, theta_m);
+      }
+  } else if (rt == 1 && rx == 2) {
+    for (int i = 0; i < g.Mt; ++i)
+      for (int j = 0; j < g.Mx / 2; ++j) {
+        const double d = dtheta(i, j);
+        tp[g.link(i, 2 * j, 1)] = wrap_2pi(tp[g.link(i, 2 * j, 1)] + d);
+        tp[g.link(i, 2 * j + 1, 1)] = wrap_2pi(tp[g.link(i, 2 * j + 1, 1)] - d);
+      }
+    for (int i = 0; i < g.Mt; ++i)
+      for (int j = 0; j < g.Mx / 2; ++j) {
+        double theta_p = wrap_2pi(tp[g.link(i, 2 * j, 0)] + tp[g.link(i + 1, 2 * j, 1)] - tp[g.link(i, 2 * j, 1)]);
+        double theta_m = wrap_2pi(tp[g.link(i, 2 * j + 1, 1)] + tp[g.link(i, 2 * j + 2, 0)] - tp[g.link(i + 1, 2 * j + 1, 1)]);
+        const unsigned l = g.link(i, 2 * j + 1, 0);
+        tp[l] = draw(l, theta_p, theta_m);
+      }
+  } else {
+    return -1;  // "invalid coarsening for fill-in"
+  }
+  double dS_fine = F.evaluate(tp.data()) - F.evaluate(theta);
+  schwinger_copy_from_fine(gc.Mt, gc.Mx, rt, rx, theta, thetaC.data());
+  double dS_coarse = Cc.evaluate(thetaC.data()) - Cc.evaluate(phi_coarse);
+  double dS_trial = schwinger_semi_cfa(F, rt, theta) - schwinger_semi_cfa(F, rt, tp.data());
+  double dS = dS_fine + dS_coarse + dS_trial;
+  if (terms) { terms[0] = dS_fine; terms[1] = dS_coarse; terms[2] = dS_trial; }
+  bool acc;
+  if (dS < 0.0) {
+    acc = true;
+  } else {
+    double u, v;
+    rng.uniforms(0, P_ACCEPT2, 0, u, v);
+    acc = u < std::exp(-dS);
+  }
+  if (acc) std::copy(tp.begin(), tp.end(), theta);
+  return acc ? 1 : 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Reference-order samplers.
 // ---------------------------------------------------------------------------------------------
@@ -1022,39 +1183,20 @@ int orc_dev_twolevel_draw(void *fine, void *coarse, const double *x_coarse, doub
   return dev_twolevel_draw(*(ActionO *)fine, *(ActionO *)coarse, x_coarse, theta, r, terms);
 }
 
-// ---- transfers between lattice levels ------------------------------------------------------------------
-// quenchedschwingeraction.cc:147-195 (copy_from_fine: three coarsening cases); Mt, Mx = COARSE extents
-void orc_schwinger_copy_from_fine(int Mt, int Mx, int rt, int rx, const double *fine, double *coarse) {
-  Grid2 gc{Mt, Mx, false}, gf{Mt * rt, Mx * rx, false};
-  for (int i = 0; i < Mt; ++i)
-    for (int j = 0; j < Mx; ++j) {
-      double t0 = fine[gf.link(rt * i, rx * j, 0)];
-      if (rt == 2) t0 += fine[gf.link(2 * i + 1, rx * j, 0)];
-      double t1 = fine[gf.link(rt * i, rx * j, 1)];
-      if (rx == 2) t1 += fine[gf.link(rt * i, 2 * j + 1, 1)];
-      coarse[gc.link(i, j, 0)] = wrap_2pi(t0);
-      coarse[gc.link(i, j, 1)] = wrap_2pi(t1);
-    }
+int orc_dev_lattice_twolevel_draw(void *fine, void *coarse, const double *phi_coarse, double *theta, uint64_t seed,
+                                  uint32_t chain, uint32_t step, double *terms) {
+  DevRng r{(uint32_t)seed, (uint32_t)(seed >> 32), chain, step};
+  return dev_schwinger_twolevel_draw(*(ActionO *)fine, *(ActionO *)coarse, phi_coarse, theta, r, terms);
 }
-// quenchedschwingeraction.cc:92-144 (copy_from_coarse)
+double orc_expcos_pdf(double beta, double x, double x_p, double x_m) { return expcos_pdf(beta, x, x_p, x_m); }
+double orc_i0_scaled(double z) { return fast_bessel_i0_scaled(z); }
+
+// ---- transfers between lattice levels ------------------------------------------------------------------
+void orc_schwinger_copy_from_fine(int Mt, int Mx, int rt, int rx, const double *fine, double *coarse) {
+  schwinger_copy_from_fine(Mt, Mx, rt, rx, fine, coarse);
+}
 void orc_schwinger_copy_from_coarse(int Mt, int Mx, int rt, int rx, const double *coarse, double *fine) {
-  Grid2 gc{Mt, Mx, false}, gf{Mt * rt, Mx * rx, false};
-  for (int i = 0; i < Mt; ++i)
-    for (int j = 0; j < Mx; ++j) {
-      double c0 = coarse[gc.link(i, j, 0)], c1 = coarse[gc.link(i, j, 1)];
-      if (rt == 2) {
-        fine[gf.link(2 * i, rx * j, 0)] = 0.5 * c0;
-        fine[gf.link(2 * i + 1, rx * j, 0)] = 0.5 * c0;
-      } else {
-        fine[gf.link(i, rx * j, 0)] = c0;
-      }
-      if (rx == 2) {
-        fine[gf.link(rt * i, 2 * j, 1)] = 0.5 * c1;
-        fine[gf.link(rt * i, 2 * j + 1, 1)] = 0.5 * c1;
-      } else {
-        fine[gf.link(rt * i, j, 1)] = c1;
-      }
-    }
+  schwinger_copy_from_coarse(Mt, Mx, rt, rx, coarse, fine);
 }
 // gffaction.cc:97-118 with the fine2coarse_map of lattice2d.cc:126-134 (unrotated): vertex (rt i, rx j) <-> (i, j)
 void orc_gff_transfer(int Mt, int Mx, int rt, int rx, double *fine, double *coarse, int to_coarse) {

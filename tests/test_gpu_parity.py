@@ -688,3 +688,48 @@ def test_rotor_65536_and_gff_512_properties(gpu_ops):
     c = phi.clone()
     gpu_ops.lattice_sweep_draw(act, c, scratch, 6, 0, SEED, 0, 0, fuse=3)
     assert_close(gpu_ops.lattice_evaluate(act, c).cpu().numpy(), S0, tol=1e-11, what="GFF OR conserves S")
+
+
+@pytest.mark.parametrize("Mt,Mx,rt,rx,beta,B", [(16, 8, 2, 1, 2.0, 3), (8, 16, 1, 2, 2.0, 3), (64, 32, 2, 1, 1.0, 2),
+                                                (32, 64, 1, 2, 6.0, 2), (256, 256, 2, 1, 1.0, 1), (4, 4, 1, 2, 0.7, 2)])
+def test_schwinger_twolevel_step_matches_oracle(gpu_ops, orc, Mt, Mx, rt, rx, beta, B):
+    """TwoLevelMetropolisStep::draw on the Schwinger lattice with semi-coarsening (copy_from_coarse, uniform pair
+    shifts + ExpCos fill-in, copy_from_fine, the three action differences, Metropolis test) against the oracle's
+    device-order restatement: accept flags, action differences and the fine state after every draw."""
+    from mlmcpathintegral_amd import abi
+    fine, F = make_lattice(orc, "schwinger", Mt, Mx, beta=beta)
+    coarse, Cc = make_lattice(orc, "schwinger", Mt // rt, Mx // rx, beta=0.5 * beta)   # quenchedschwingeraction.hh coarse_action
+    rng = np.random.default_rng(Mt * 7 + Mx)
+    step = gpu_ops.LatticeTwoLevelStep(fine, coarse, B, seed=SEED, chain0=4)
+    theta0 = rng.uniform(-np.pi, np.pi, (B, 2 * Mt * Mx)) * (0.15 if Mt * Mx <= 256 else 1.0)
+    step.set_state(dev(theta0))
+    theta = theta0.copy()
+    seen = set()
+    for t in range(5):
+        # proposals: the coarse image of the current state, perturbed a little (mostly accepted on small
+        # lattices) or a lot (mostly rejected)
+        base = gpu_ops.lattice_copy_from_fine(fine, rt, rx, dev(theta)).cpu().numpy()
+        pc = base + rng.normal(0, 0.02 if t % 2 == 0 else 1.5, base.shape)
+        acc = step.draw(dev(pc)).cpu().numpy()
+        terms = step.terms.cpu().numpy()
+        for b in range(B):
+            a, want = F.dev_lattice_twolevel_draw(Cc, pc[b], theta[b], SEED, 4 + b, t)
+            assert_close(terms[b], want, tol=2e-10, scale=max(1.0, float(np.max(np.abs(want)))), what=f"action differences t={t} b={b}")
+            assert acc[b] == a, (t, b, want)
+            seen.add(int(a))
+        assert_angles_close(step.theta.cpu().numpy(), theta, tol=1e-10, what=f"fine state after draw {t}")
+        theta = step.theta.cpu().numpy().copy()   # resync (angle wrap at +-pi may differ by 2 pi)
+    print("outcomes seen:", seen)
+    if Mt * Mx == 128:
+        assert seen == {0, 1}
+
+
+def test_schwinger_twolevel_step_errors(gpu_ops):
+    from mlmcpathintegral_amd import abi
+    f = abi.lattice_action(4, 16, 16, beta=1.0)
+    with pytest.raises(abi.MlmcpiError, match="both directions"):
+        gpu_ops.LatticeTwoLevelStep(f, abi.lattice_action(4, 8, 8, beta=0.25), 1)
+    with pytest.raises(abi.MlmcpiError, match="invalid coarsening"):
+        gpu_ops.LatticeTwoLevelStep(f, abi.lattice_action(4, 16, 16, beta=1.0), 1)
+    with pytest.raises(abi.MlmcpiError, match="only the quenched Schwinger"):
+        gpu_ops.LatticeTwoLevelStep(abi.lattice_action(3, 16, 16, mass=1.0), abi.lattice_action(3, 8, 8, mass=1.0), 1)

@@ -193,3 +193,46 @@ def test_rotor_hierarchical_chain_samples_fine_distribution(gpu_ops, orc):
     assert n_acc / n > 0.3
     assert abs(mchi - rchi) < 4 * math.hypot(echi, rchierr)
     assert abs(mcos - rcos) < 4 * math.hypot(ecos, rerr)
+
+
+@pytest.mark.parametrize("rt,rx", [(2, 1), (1, 2)])
+def test_schwinger_hierarchical_chain_samples_fine_distribution(gpu_ops, rt, rx):
+    """Schwinger 8 x 8, beta = 1.5: coarse-level overrelaxed heat bath on the semi-coarsened lattice (beta/2) +
+    TwoLevelMetropolisStep with the ExpCos conditioned fine action must sample the FINE-level distribution:
+    average plaquette and Q^2 against a direct fine-level heat-bath chain."""
+    from mlmcpathintegral_amd import abi
+    Mt = Mx = 8
+    beta, B = 1.5, 512
+    fine, coarse = abi.lattice_action(4, Mt, Mx, beta=beta), abi.lattice_action(4, Mt // rt, Mx // rx, beta=0.5 * beta)
+    pc = gpu_ops.lattice_initialise(coarse, B, SEED)
+    scratch = torch.empty_like(pc)
+    step = gpu_ops.LatticeTwoLevelStep(fine, coarse, B, seed=SEED + 1)
+    step.set_state(gpu_ops.lattice_initialise(fine, B, SEED + 2))
+    burn, n = 200, 1200
+    plaq, chi, sweep, n_acc = [], [], 0, 0.0
+    for k in range(burn + n):
+        gpu_ops.lattice_sweep_draw(coarse, pc, scratch, 1, 1, SEED, 0, sweep)
+        sweep += 2
+        acc = step.draw(pc)
+        pc.copy_(gpu_ops.lattice_copy_from_fine(fine, rt, rx, step.theta))   # hierarchicalsampler.cc:57-60
+        if k >= burn:
+            n_acc += float(acc.double().mean())
+            plaq.append(gpu_ops.qoi_avg_plaquette(step.theta, Mt, Mx))
+            chi.append(gpu_ops.qoi_2d_susceptibility(step.theta, Mt, Mx))
+    mp, ep = chain_mean_and_error(torch.stack(plaq))
+    mc, ec = chain_mean_and_error(torch.stack(chi))
+    x = gpu_ops.lattice_initialise(fine, B, SEED + 3)
+    sc = torch.empty_like(x)
+    dplaq, dchi = [], []
+    for k in range(burn + n):
+        gpu_ops.lattice_sweep_draw(fine, x, sc, 1, 1, SEED + 3, 0, 2 * k)
+        if k >= burn:
+            dplaq.append(gpu_ops.qoi_avg_plaquette(x, Mt, Mx))
+            dchi.append(gpu_ops.qoi_2d_susceptibility(x, Mt, Mx))
+    rp, erp = chain_mean_and_error(torch.stack(dplaq))
+    rc, erc = chain_mean_and_error(torch.stack(dchi))
+    print(f"Schwinger two-level ({rt},{rx}): p_accept {n_acc / n:.3f}; plaquette {mp:.5f} +- {ep:.5f} vs direct {rp:.5f} +- {erp:.5f}; "
+          f"Q^2/(4 pi^2) {mc:.4f} +- {ec:.4f} vs direct {rc:.4f} +- {erc:.4f}")
+    assert n_acc / n > 0.05
+    assert abs(mp - rp) < 4 * math.hypot(ep, erp)
+    assert abs(mc - rc) < 4 * math.hypot(ec, erc)
