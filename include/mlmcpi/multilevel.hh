@@ -1,7 +1,9 @@
-// multilevel.hh -- the multilevel glue of the reference for 1-D (QM) actions, on device chains:
+// multilevel.hh -- the multilevel glue of the reference (1-D actions; Schwinger lattice with semi-coarsening), on
+// device chains:
 //   ConditionedFineAction            action/conditionedfineaction.hh:38-67
 //   GaussianConditionedFineAction    action/qm/gaussianconditionedfineaction.{hh,cc}
 //   RotorConditionedFineAction       action/qm/rotorconditionedfineaction.{hh,cc}
+//   QuenchedSchwingerSemiConditionedFineAction (+ factory)  action/qft/quenchedschwingerconditionedfineaction.{hh,cc}
 //   TwoLevelMetropolisStep           montecarlo/twolevelmetropolisstep.{hh,cc}
 //   HierarchicalSampler              sampler/hierarchicalsampler.{hh,cc}
 //   MonteCarloMultiLevel             montecarlo/montecarlomultilevel.{hh,cc}
@@ -20,7 +22,7 @@ class ConditionedFineAction {
 public:
   virtual ~ConditionedFineAction() {}
   /** the fine-level action whose fine-only points this object fills in */
-  virtual std::shared_ptr<QMAction> fine_action() const = 0;
+  virtual std::shared_ptr<Action> fine_action() const = 0;
 };
 
 /** Gaussian fill-in x_{2j+1} ~ N(Wminimum(x_2j, x_2j+2), 1/Wcurvature): harmonic and quartic oscillator.
@@ -30,7 +32,7 @@ public:
   explicit GaussianConditionedFineAction(const std::shared_ptr<QMAction> action_) : action(action_) {
     if (action->abi_action().kind == MLMCPI_ROTOR) fatal("Gaussian conditioned fine action not defined for the rotor action");
   }
-  std::shared_ptr<QMAction> fine_action() const override { return action; }
+  std::shared_ptr<Action> fine_action() const override { return action; }
 
 private:
   const std::shared_ptr<QMAction> action;
@@ -41,7 +43,7 @@ private:
 class RotorConditionedFineAction : public ConditionedFineAction {
 public:
   explicit RotorConditionedFineAction(const std::shared_ptr<RotorAction> action_) : action(action_) {}
-  std::shared_ptr<QMAction> fine_action() const override { return action; }
+  std::shared_ptr<Action> fine_action() const override { return action; }
 
 private:
   const std::shared_ptr<RotorAction> action;
@@ -71,18 +73,44 @@ public:
   }
 };
 
+/** action/qft/quenchedschwingerconditionedfineaction.hh:134-170 (QuenchedSchwingerSemiConditionedFineAction):
+ *  semi-coarsened lattices; uniform shifts of the split links and an ExpCos draw of the links in between run
+ *  inside mlmcpi_lattice_twolevel_draw. */
+class QuenchedSchwingerSemiConditionedFineAction : public ConditionedFineAction {
+public:
+  explicit QuenchedSchwingerSemiConditionedFineAction(const std::shared_ptr<QuenchedSchwingerAction> action_) : action(action_) {}
+  std::shared_ptr<Action> fine_action() const override { return action; }
+
+private:
+  const std::shared_ptr<QuenchedSchwingerAction> action;
+};
+
+/** quenchedschwingerconditionedfineaction.hh:218-238: the fill-in follows the coarsening type of the lattice */
+class QuenchedSchwingerConditionedFineActionFactory : public ConditionedFineActionFactory {
+public:
+  std::shared_ptr<ConditionedFineAction> get(std::shared_ptr<Action> action) override {
+    auto schwinger = std::dynamic_pointer_cast<QuenchedSchwingerAction>(action);
+    if (!schwinger) fatal("Schwinger conditioned fine action needs a QuenchedSchwingerAction");
+    if (schwinger->get_lattice()->get_coarsening_type() == CoarsenBoth)
+      fatal("the Bessel-product fill-in (coarsening in both directions) is not available on the device; use CoarsenTemporal, CoarsenSpatial or CoarsenAlternate");
+    return std::make_shared<QuenchedSchwingerSemiConditionedFineAction>(schwinger);
+  }
+};
+
 /** twolevelmetropolisstep.{hh,cc}: draws a fine-level sample from a coarse-level proposal. */
 class TwoLevelMetropolisStep : public MCMCStep {
 public:
   TwoLevelMetropolisStep(const std::shared_ptr<Action> coarse_action_, const std::shared_ptr<Action> fine_action_,
                          const std::shared_ptr<ConditionedFineAction> conditioned_fine_action_, unsigned int batch = 1,
                          unsigned int n_meas = 200)
-      : MCMCStep(), coarse(std::dynamic_pointer_cast<QMAction>(coarse_action_)),
-        fine(std::dynamic_pointer_cast<QMAction>(fine_action_)), cfa(conditioned_fine_action_), B(batch),
+      : MCMCStep(), coarse(coarse_action_), fine(fine_action_), qm_coarse(std::dynamic_pointer_cast<QMAction>(coarse_action_)),
+        qm_fine(std::dynamic_pointer_cast<QMAction>(fine_action_)), qft_coarse(std::dynamic_pointer_cast<QFTAction>(coarse_action_)),
+        qft_fine(std::dynamic_pointer_cast<QFTAction>(fine_action_)), cfa(conditioned_fine_action_), B(batch),
         accept_flags(batch, sizeof(int32_t)), cost_per_sample_(0.0) {
-    if (!coarse || !fine || !cfa) fatal("TwoLevelMetropolisStep: actions have no device implementation");
+    if (!cfa || !((qm_coarse && qm_fine) || (qft_coarse && qft_fine))) fatal("TwoLevelMetropolisStep: actions have no device implementation");
     size_t bytes = 0;
-    check(mlmcpi_path_twolevel_workspace_bytes(&fine->abi_action(), B, &bytes), "twolevel_workspace_bytes");
+    if (qm_fine) check(mlmcpi_path_twolevel_workspace_bytes(&qm_fine->abi_action(), B, &bytes), "twolevel_workspace_bytes");
+    else check(mlmcpi_lattice_twolevel_workspace_bytes(&qft_fine->abi_action(), &qft_coarse->abi_action(), B, &bytes), "twolevel_workspace_bytes");
     check(mlmcpi_malloc(&work, bytes), "mlmcpi_malloc");
     theta_fine = std::make_shared<SampleState>(fine->sample_size(), B);
     // twolevelmetropolisstep.cc:23-31: cost per sample by timing draws (10 000 in the reference)
@@ -99,9 +127,14 @@ public:
 
   /** twolevelmetropolisstep.cc:35-89 */
   void draw(const std::shared_ptr<SampleState> phi_coarse_state, std::shared_ptr<SampleState> phi_state) {
-    check(mlmcpi_path_twolevel_draw(&fine->abi_action(), &coarse->abi_action(), phi_coarse_state->device(),
-                                    theta_fine->device_mutable(), B, level_seed(), fine->get_chain0(),
-                                    step++, work, (int32_t *)accept_flags.ptr(), nullptr, nullptr), "path_twolevel_draw");
+    if (qm_fine)
+      check(mlmcpi_path_twolevel_draw(&qm_fine->abi_action(), &qm_coarse->abi_action(), phi_coarse_state->device(),
+                                      theta_fine->device_mutable(), B, level_seed(), fine->get_chain0(), step++, work,
+                                      (int32_t *)accept_flags.ptr(), nullptr, nullptr), "path_twolevel_draw");
+    else
+      check(mlmcpi_lattice_twolevel_draw(&qft_fine->abi_action(), &qft_coarse->abi_action(), phi_coarse_state->device(),
+                                         theta_fine->device_mutable(), B, level_seed(), fine->get_chain0(), step++, work,
+                                         (int32_t *)accept_flags.ptr(), nullptr, nullptr), "lattice_twolevel_draw");
     std::vector<int32_t> flags = accept_flags.download<int32_t>();
     double acc = 0;
     for (int32_t f : flags) acc += f;
@@ -119,7 +152,9 @@ private:
   uint64_t level_seed() const {
     return (fine->get_seed() ^ 0x5517A4B3ull) + 0x9E3779B97F4A7C15ull * (uint64_t)(fine->get_coarsening_level() + 1);
   }
-  const std::shared_ptr<QMAction> coarse, fine;
+  const std::shared_ptr<Action> coarse, fine;
+  const std::shared_ptr<QMAction> qm_coarse, qm_fine;
+  const std::shared_ptr<QFTAction> qft_coarse, qft_fine;
   const std::shared_ptr<ConditionedFineAction> cfa;
   const unsigned int B;
   std::shared_ptr<SampleState> theta_fine;
@@ -445,6 +480,28 @@ public:
     return std::make_shared<QoIXsquared>(qm->get_lattice());
   }
 };
+
+/** qoi/qm/qoisusceptibility.hh, qoi/qft/{qoi2dsusceptibility,qoiavgplaquette,qoi2dphisquared}.hh factories */
+class QoISusceptibilityFactory : public QoIFactory {
+public:
+  std::shared_ptr<QoI> get(std::shared_ptr<Action> action) override {
+    auto qm = std::dynamic_pointer_cast<QMAction>(action);
+    if (!qm) fatal("QoISusceptibility needs a 1-D action");
+    return std::make_shared<QoISusceptibility>(qm->get_lattice());
+  }
+};
+template <class Q>
+class QFTQoIFactory : public QoIFactory {
+public:
+  std::shared_ptr<QoI> get(std::shared_ptr<Action> action) override {
+    auto qft = std::dynamic_pointer_cast<QFTAction>(action);
+    if (!qft) fatal("this QoI needs a 2-D action");
+    return std::make_shared<Q>(qft->get_lattice());
+  }
+};
+typedef QFTQoIFactory<QoI2DSusceptibility> QoI2DSusceptibilityFactory;
+typedef QFTQoIFactory<QoIAvgPlaquette> QoIAvgPlaquetteFactory;
+typedef QFTQoIFactory<QoI2DPhiSquared> QoI2DPhiSquaredFactory;
 
 }  // namespace mlmcpi
 #endif
