@@ -262,6 +262,27 @@ int main(int argc, char **argv) {
     std::printf(" Schwinger MLMC plaquette = %.6f +- %.6f (exact %.6f)\n", mlmc.numerical_result(), mlmc.statistical_error(), exact);
     EXPECT(std::fabs(mlmc.numerical_result() - exact) < 5 * mlmc.statistical_error(), "Schwinger MLMC estimate");
   }
+  // ---- Schwinger 8 x 8, beta = 1.5, CoarsenBoth (the reference template's default): Bessel-product fill-in -------
+  {
+    auto lat = std::make_shared<Lattice2D>(8, 8, CoarsenBoth);
+    auto act = std::make_shared<QuenchedSchwingerAction>(lat, nullptr, RenormalisationNone, 1.5);
+    OverrelaxedHeatBathParameters hb;
+    hb.n_sweep_heatbath = 1; hb.n_sweep_overrelax = 1; hb.n_burnin = 100;
+    HierarchicalParameters hier;
+    hier.n_max_level = 2; hier.n_meas = 1000;
+    auto hfac = std::make_shared<HierarchicalSamplerFactory>(std::make_shared<OverrelaxedHeatBathSamplerFactory>(hb),
+                                                             std::make_shared<QuenchedSchwingerConditionedFineActionFactory>(), hier);
+    SingleLevelMCParameters mp;
+    mp.n_burnin = 500; mp.n_samples = 20000; mp.n_autocorr_window = 50;
+    MonteCarloSingleLevel mc(act, std::make_shared<QoIAvgPlaquette>(lat), hfac, mp);
+    mc.evaluate();
+    auto st = mc.get_statistics();
+    const double exact = 0.596133;  // I1(1.5) / I0(1.5)
+    std::printf(" Schwinger CoarsenBoth hierarchical sampler: plaquette %.6f +- %.6f (exact %.6f), p_accept %.3f\n", st->average(),
+                st->error(), exact, mc.get_sampler()->p_accept());
+    EXPECT(std::fabs(st->average() - exact) < 5 * std::fmax(st->error(), 5e-4), "Schwinger CoarsenBoth plaquette");
+    EXPECT(mc.get_sampler()->p_accept() > 0.5, "Schwinger CoarsenBoth acceptance");
+  }
   std::printf(failures ? "%d FAILURES\n" : "host layer: all checks passed\n", failures);
   return failures ? 1 : 0;
 }

@@ -85,6 +85,17 @@ private:
   const std::shared_ptr<QuenchedSchwingerAction> action;
 };
 
+/** quenchedschwingerconditionedfineaction.hh:44-96 (QuenchedSchwingerConditionedFineAction): lattices coarsened in
+ *  both directions; Bessel-product fill-in (beta <= 8) or its approximation, inside mlmcpi_lattice_twolevel_draw. */
+class QuenchedSchwingerConditionedFineAction : public ConditionedFineAction {
+public:
+  explicit QuenchedSchwingerConditionedFineAction(const std::shared_ptr<QuenchedSchwingerAction> action_) : action(action_) {}
+  std::shared_ptr<Action> fine_action() const override { return action; }
+
+private:
+  const std::shared_ptr<QuenchedSchwingerAction> action;
+};
+
 /** quenchedschwingerconditionedfineaction.hh:218-238: the fill-in follows the coarsening type of the lattice */
 class QuenchedSchwingerConditionedFineActionFactory : public ConditionedFineActionFactory {
 public:
@@ -92,7 +103,7 @@ public:
     auto schwinger = std::dynamic_pointer_cast<QuenchedSchwingerAction>(action);
     if (!schwinger) fatal("Schwinger conditioned fine action needs a QuenchedSchwingerAction");
     if (schwinger->get_lattice()->get_coarsening_type() == CoarsenBoth)
-      fatal("the Bessel-product fill-in (coarsening in both directions) is not available on the device; use CoarsenTemporal, CoarsenSpatial or CoarsenAlternate");
+      return std::make_shared<QuenchedSchwingerConditionedFineAction>(schwinger);
     return std::make_shared<QuenchedSchwingerSemiConditionedFineAction>(schwinger);
   }
 };

@@ -197,15 +197,17 @@ int mlmcpi_lattice_copy_from_fine(const mlmcpi_lattice_action *fine, uint32_t rt
                                   double *d_coarse, uint32_t B, void *stream);
 int mlmcpi_lattice_copy_from_coarse(const mlmcpi_lattice_action *fine, uint32_t rt, uint32_t rx, const double *d_coarse,
                                     double *d_fine, uint32_t B, void *stream);
-/* TwoLevelMetropolisStep::draw (montecarlo/twolevelmetropolisstep.cc:35-89) on the quenched Schwinger lattice
- * with semi-coarsening (CoarsenTemporal / CoarsenSpatial / the levels of CoarsenAlternate): copy_from_coarse,
- * QuenchedSchwingerSemiConditionedFineAction::{fill_fine_points, evaluate}
- * (action/qft/quenchedschwingerconditionedfineaction.cc:130-204, 332-379), copy_from_fine, the three action
- * differences, the Metropolis test and the copy of accepted states.  `coarse` carries the coarse lattice extents
- * (one of them half the fine one) and the coarse beta (QuenchedSchwingerAction::coarse_action).
+/* TwoLevelMetropolisStep::draw (montecarlo/twolevelmetropolisstep.cc:35-89) on the quenched Schwinger lattice:
+ * copy_from_coarse, the conditioned fine action's fill_fine_points and evaluate, copy_from_fine, the three action
+ * differences, the Metropolis test and the copy of accepted states.  Conditioned fine action by coarsening
+ * (quenchedschwingerconditionedfineaction.hh:218-238):
+ *   one direction halved (CoarsenTemporal / CoarsenSpatial / levels of CoarsenAlternate):
+ *     QuenchedSchwingerSemiConditionedFineAction (.cc:130-204, 332-379): uniform shifts + ExpCos draws;
+ *   both directions halved (CoarsenBoth): QuenchedSchwingerConditionedFineAction (.cc:7-78, 207-289):
+ *     BesselProductDistribution for beta <= 8, ApproximateBesselProductDistribution beyond.
+ * `coarse` carries the coarse lattice extents and the coarse beta (QuenchedSchwingerAction::coarse_action).
  *   d_phi_coarse [B][2 Mt_c Mx_c]  coarse-level proposal;  d_theta [B][2 Mt Mx]  current fine state (updated when
- *   accepted);  d_accept [B];  d_terms [B][3] = (dS_fine, dS_coarse, dS_trial) or NULL.
- * Coarsening in both directions (Bessel-product fill-in) returns MLMCPI_ERR_UNSUPPORTED. */
+ *   accepted);  d_accept [B];  d_terms [B][3] = (dS_fine, dS_coarse, dS_trial) or NULL. */
 int mlmcpi_lattice_twolevel_workspace_bytes(const mlmcpi_lattice_action *fine, const mlmcpi_lattice_action *coarse,
                                             uint32_t B, size_t *bytes);
 int mlmcpi_lattice_twolevel_draw(const mlmcpi_lattice_action *fine, const mlmcpi_lattice_action *coarse,

@@ -182,6 +182,7 @@ enum Purpose : uint32_t {
   P_INIT = 6,
   P_FILLIN = 7,   // two-level step: Gaussian fill-in of the fine-only sites
   P_ACCEPT2 = 8,  // two-level step: Metropolis uniform
+  P_BESSEL = 9,   // two-level step, Schwinger coarsened in both directions: Bessel-product fill-in, sub = call counter
 };
 
 struct RngKey {
@@ -400,6 +401,118 @@ __device__ __forceinline__ double expcos_neg_log_pdf(double beta, double x, doub
   z *= flip;
   const double sigma = 2. * beta * fabs(cos(0.5 * dx));
   return -sigma * (cos(z - 0.5 * dx) - 1.0) + log(kTwoPi * bessel_i0_scaled(sigma));
+}
+
+// ---- fill-in distributions of the Schwinger lattice coarsened in both directions ----------------------------
+// distribution/besselproductdistribution.{hh,cc} (beta <= 8), approximatebesselproductdistribution.{hh,cc} (beyond)
+struct BesselFill {
+  double beta, I0_twobeta, sigma_beta;
+  double alphaZ[17];   // besselproductdistribution.hh:55-71 (host-built)
+  int approximate;     // beta > 8 (quenchedschwingerconditionedfineaction.hh:62-71)
+};
+
+__device__ __forceinline__ double bessel_i0(double z) {  // gsl_sf_bessel_I0
+  const double az = fabs(z);
+  return exp(az) * bessel_i0_scaled(az);
+}
+
+// BesselProductDistribution::Znorm_inv(phi, rescaled = true), besselproductdistribution.cc:15-25
+__device__ __forceinline__ double bessel_znorm_inv_rescaled(const BesselFill &P, double phi) {
+  double s = 1.0;
+  for (int k = 1; k <= 16; ++k) s += P.alphaZ[k] * cos(k * phi);
+  return 1.0 / s;
+}
+
+// BesselProductDistribution::draw (besselproductdistribution.hh:88-152).  The calls of `site` are numbered
+// n = 0, 1, ...: an outer attempt takes one call (two uniforms), the truncated-normal loop one call per two
+// normals; n is bounded, so every lane leaves the loop.
+__device__ __forceinline__ double bessel_product_draw(const RngKey &k, uint32_t site, const BesselFill &P, double x_p,
+                                                      double x_m) {
+  double dx = x_m - x_p;
+  const double flip = (dx < 0) ? -1. : +1.;
+  dx *= flip;
+  const double N_p = erf((kPi - 0.5 * dx) / P.sigma_beta);
+  const double N_m = erf(0.5 * dx / P.sigma_beta) * pow(P.I0_twobeta, 2. * (dx / kPi - 1.));
+  const double C_p = pow(P.I0_twobeta, 2. * (1. - dx * dx / (4. * kPi * kPi)));
+  const double C_m = pow(P.I0_twobeta, 2. * (1. - (dx - 2. * kPi) * (dx - 2. * kPi) / (4. * kPi * kPi)));
+  const double sigma = P.sigma_beta / sqrt(2.);
+  uint32_t n = 0;
+  double x = 0.0;
+  while (n < 60000u) {
+    double xi, xi2;
+    rng_uniforms(k, site, P_BESSEL, n++, xi, xi2);
+    double a_min, a_max, mu, C;
+    if (xi >= N_m / (N_p + N_m)) {
+      a_min = -kPi + dx; a_max = +kPi; mu = 0.5 * dx; C = C_p;
+    } else {
+      a_min = -kPi; a_max = -kPi + dx; mu = 0.5 * (dx - 2. * kPi); C = C_m;
+    }
+    bool inside = false;
+    while (!inside && n < 60000u) {
+      double g0, g1;
+      rng_normals(k, site, P_BESSEL, n++, g0, g1);
+      x = sigma * g0 + mu;
+      inside = (x >= a_min) && (x < a_max);
+      if (!inside) {
+        x = sigma * g1 + mu;
+        inside = (x >= a_min) && (x < a_max);
+      }
+    }
+    const double I0 = bessel_i0(2. * P.beta * cos(0.5 * x));
+    const double I0_dx = bessel_i0(2. * P.beta * cos(0.5 * (x - dx)));
+    const double xs = (x - mu) / P.sigma_beta;
+    if (xi2 <= I0 * I0_dx / C * exp(xs * xs)) break;
+  }
+  return mod_2pi(flip * x + x_p);
+}
+
+// approximatebesselproductdistribution.cc:43-54
+__device__ __forceinline__ void approx_bessel_params(double beta, double x0, double &N_p, double &s2p_inv,
+                                                     double &s2m_inv) {
+  if (x0 < 0.125 * kPi) {
+    s2p_inv = beta; s2m_inv = 0.0; N_p = 1.0;
+  } else {
+    s2p_inv = beta * cos(0.25 * x0);
+    s2m_inv = beta * sin(0.25 * x0);
+    const double rho = pow(s2p_inv / s2m_inv, 1.5) * exp(-4.0 * (s2p_inv - s2m_inv));
+    N_p = 1.0 / (1.0 + rho);
+  }
+}
+// approximatebesselproductdistribution.hh:82-107: call 0 = the uniform, call 1 = the normal
+__device__ __forceinline__ double approx_bessel_draw(const RngKey &k, uint32_t site, double beta, double x_p,
+                                                     double x_m) {
+  double x0 = x_p - x_m;
+  double flip = (x0 < 0) ? -1. : +1.;
+  x0 *= flip;
+  if (x0 > kPi) { x0 = kTwoPi - x0; flip = -flip; }
+  double N_p, s2p, s2m;
+  approx_bessel_params(beta, x0, N_p, s2p, s2m);
+  double xi, unused, g0, g1;
+  rng_uniforms(k, site, P_BESSEL, 0, xi, unused);
+  rng_normals(k, site, P_BESSEL, 1, g0, g1);
+  const double sigma = (xi <= N_p) ? 1. / sqrt(s2p) : 1. / sqrt(s2m);
+  const double xshift = (xi <= N_p) ? 0.0 : kPi;
+  const double x = sigma * g0 + 0.5 * x0 - xshift;
+  return mod_2pi(flip * x + x_m);
+}
+// approximatebesselproductdistribution.cc:7-40
+__device__ __forceinline__ double approx_bessel_pdf(double beta, double x, double x_p, double x_m) {
+  double x0 = x_p - x_m, z = x - x_m;
+  double flip = (x0 < 0) ? -1. : +1.;
+  x0 *= flip;
+  if (x0 > kPi) { x0 = kTwoPi - x0; flip = -flip; }
+  z *= flip;
+  double N_p, s2p, s2m;
+  approx_bessel_params(beta, x0, N_p, s2p, s2m);
+  const double N_m = 1. - N_p;
+  double sp = 0.0, sm = 0.0;
+  for (int kk = -4; kk <= 4; ++kk) {
+    double zs = z - 0.5 * x0 + 2 * kk * kPi;
+    sp += sqrt(s2p) * exp(-0.5 * s2p * zs * zs);
+    zs += kPi;
+    sm += sqrt(s2m) * exp(-0.5 * s2m * zs * zs);
+  }
+  return sqrt(0.5 / kPi) * (N_p * sp + N_m * sm);
 }
 
 // ---- LDS reads that stay ds_read_b64 ---------------------------------------------------------------------

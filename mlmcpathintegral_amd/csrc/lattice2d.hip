@@ -1300,6 +1300,123 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// ---- coarsening in both directions: QuenchedSchwingerConditionedFineAction (quenchedschwingerconditionedfineaction.cc:7-78,
+// 207-289).  Three kernels: (A) per coarse cell, steps 1 and 2 -- uniform shifts of the two split coarse links, then the
+// two interior spatial links from the Bessel-product law of their sum (the staples of the 2 x 2 block need the split
+// links of the cells (i+1, j) and (i, j+1), recomputed from those cells' Philox streams); (B) per fine link
+// (i, 2 jc + 1, 0), step 3 -- the ExpCos heat-bath conditional, reading what (A) wrote; (C) the conditioned fine action
+// of a state.
+__device__ __forceinline__ void split_pair(const RngKey &key, uint32_t cell, double2 coarse_link, double (&t)[2], double (&x)[2]) {
+  double u, v;
+  rng_uniforms(key, cell, P_FILLIN, 0, u, v);
+  const double dt = (2. * u - 1.) * kPi, dx = (2. * v - 1.) * kPi;
+  t[0] = mod_2pi(0.5 * coarse_link.x + dt);
+  t[1] = mod_2pi(0.5 * coarse_link.x - dt);
+  x[0] = mod_2pi(0.5 * coarse_link.y + dx);
+  x[1] = mod_2pi(0.5 * coarse_link.y - dx);
+}
+
+__global__ void __launch_bounds__(256)
+    schwinger_both_fill_kernel(uint32_t Mtc, uint32_t Mxc, BesselFill P, const double2 *__restrict__ coarse_all,
+                               double2 *__restrict__ prime_all, RngKey key0) {
+  const uint32_t b = blockIdx.y, Mtf = 2 * Mtc;
+  const double2 *coarse = coarse_all + (size_t)b * Mtc * Mxc;
+  double *prime = (double *)(prime_all + (size_t)b * 4 * Mtc * Mxc);
+  RngKey key = key0;
+  key.chain += b;
+  for (uint32_t j = blockIdx.x; j < Mxc; j += gridDim.x) {
+    const uint32_t jp = j + 1 == Mxc ? 0 : j + 1;
+    for (uint32_t i = threadIdx.x; i < Mtc; i += blockDim.x) {
+      const uint32_t ip = i + 1 == Mtc ? 0 : i + 1;
+      const uint32_t c = j * Mtc + i, c_t = j * Mtc + ip, c_x = jp * Mtc + i;
+      double t[2], x[2], tt[2], tx[2], xt[2], xx[2];
+      split_pair(key, c, coarse[c], t, x);         // this cell
+      split_pair(key, c_t, coarse[c_t], tt, tx);   // cell (i+1, j): its spatial pair closes the block on the right
+      split_pair(key, c_x, coarse[c_x], xt, xx);   // cell (i, j+1): its temporal pair closes the block on top
+      // theta_p = th(2i+1,2j,0) + th(2i+2,2j,1) + th(2i+2,2j+1,1) - th(2i+1,2j+2,0)
+      const double theta_p = mod_2pi(t[1] + tx[0] + tx[1] - xt[1]);
+      // theta_m = th(2i,2j,1) + th(2i,2j+1,1) + th(2i,2j+2,0) - th(2i,2j,0)
+      const double theta_m = mod_2pi(x[0] + x[1] + xt[0] - t[0]);
+      const double tilde = P.approximate ? approx_bessel_draw(key, c, P.beta, theta_p, theta_m)
+                                         : bessel_product_draw(key, c, P, theta_p, theta_m);
+      double u, v;
+      rng_uniforms(key, c, P_FILLIN, 1, u, v);
+      const double d = (2. * u - 1.) * kPi;
+      // fine vertices (2i, 2j), (2i+1, 2j), (2i, 2j+1), (2i+1, 2j+1); link index = 2 * vertex + mu
+      const size_t v00 = (size_t)(2 * j) * Mtf + 2 * i, v01 = v00 + Mtf;
+      prime[2 * v00] = t[0];
+      prime[2 * v00 + 1] = x[0];
+      prime[2 * (v00 + 1)] = t[1];
+      prime[2 * (v00 + 1) + 1] = mod_2pi(0.5 * tilde + d);
+      prime[2 * v01 + 1] = x[1];
+      prime[2 * (v01 + 1) + 1] = mod_2pi(0.5 * tilde - d);
+    }
+  }
+}
+
+// step 3: links (i, 2 jc + 1, 0), i = 0..Mt-1, jc = 0..Mx/2-1
+__global__ void __launch_bounds__(256)
+    schwinger_both_rows_kernel(uint32_t Mt, uint32_t Mx, double beta, double2 *__restrict__ prime_all, RngKey key0) {
+  const uint32_t b = blockIdx.y;
+  double *prime = (double *)(prime_all + (size_t)b * Mt * Mx);
+  RngKey key = key0;
+  key.chain += b;
+  for (uint32_t jc = blockIdx.x; jc < Mx / 2; jc += gridDim.x) {
+    const uint32_t j0 = 2 * jc, j1 = j0 + 1, j2 = (j0 + 2 == Mx) ? 0 : j0 + 2;
+    for (uint32_t i = threadIdx.x; i < Mt; i += blockDim.x) {
+      const uint32_t ip = i + 1 == Mt ? 0 : i + 1;
+      auto link = [&](uint32_t ii, uint32_t jj, uint32_t mu) { return prime[2 * ((size_t)jj * Mt + ii) + mu]; };
+      const double theta_p = mod_2pi(link(i, j0, 0) + link(ip, j0, 1) - link(i, j0, 1));
+      const double theta_m = mod_2pi(link(i, j1, 1) + link(i, j2, 0) - link(ip, j1, 1));
+      const uint32_t l = 2 * (j1 * Mt + i);
+      prime[l] = expcos_draw(key, l, beta, theta_p, theta_m, kVmFillin);
+    }
+  }
+}
+
+// partial[(b * gridDim.x + blockIdx.x) * 2 + slot] = conditioned fine action of `state`, one 2 x 2 block per thread
+__global__ void __launch_bounds__(256)
+    schwinger_both_cfa_kernel(uint32_t Mt, uint32_t Mx, BesselFill P, const double2 *__restrict__ state_all,
+                              double *__restrict__ partial, uint32_t slot) {
+  __shared__ double red[4];
+  const uint32_t b = blockIdx.y;
+  const double *th = (const double *)(state_all + (size_t)b * Mt * Mx);
+  auto link = [&](uint32_t ii, uint32_t jj, uint32_t mu) { return th[2 * ((size_t)jj * Mt + ii) + mu]; };
+  double acc[1] = {0.0};
+  for (uint32_t jc = blockIdx.x; jc < Mx / 2; jc += gridDim.x) {
+    const uint32_t j0 = 2 * jc, j1 = j0 + 1, j2 = (j0 + 2 == Mx) ? 0 : j0 + 2;
+    for (uint32_t ic = threadIdx.x; ic < Mt / 2; ic += blockDim.x) {
+      const uint32_t i0 = 2 * ic, i1 = i0 + 1, i2 = (i0 + 2 == Mt) ? 0 : i0 + 2;
+      if (!P.approximate) {
+        const double phi_12 = +link(i0, j1, 1) + link(i0, j2, 0);
+        const double phi_23 = +link(i1, j2, 0) - link(i2, j1, 1);
+        const double phi_34 = -link(i1, j0, 0) - link(i2, j0, 1);
+        const double phi_41 = -link(i0, j0, 0) + link(i0, j0, 1);
+        const double theta_1 = +link(i0, j1, 0), theta_2 = -link(i1, j1, 1), theta_3 = -link(i1, j1, 0),
+                     theta_4 = +link(i1, j0, 1);
+        const double Phi = phi_12 + phi_23 + phi_34 + phi_41;
+        acc[0] -= P.beta * (cos(theta_1 - theta_2 - phi_12) + cos(theta_2 - theta_3 - phi_23) +
+                            cos(theta_3 - theta_4 - phi_34) + cos(theta_4 - theta_1 - phi_41));
+        acc[0] -= log(bessel_znorm_inv_rescaled(P, Phi));
+      } else {
+        const double phi_p = mod_2pi(+link(i1, j0, 0) + link(i2, j0, 1) + link(i2, j1, 1) - link(i1, j2, 0));
+        const double phi_m = mod_2pi(-link(i0, j0, 0) + link(i0, j0, 1) + link(i0, j1, 1) + link(i0, j2, 0));
+        const double theta = mod_2pi(+link(i1, j0, 1) + link(i1, j1, 1));
+        acc[0] -= log(approx_bessel_pdf(P.beta, theta, phi_p, phi_m));
+        // the two horizontal links (i0, j1, 0), (i1, j1, 0) of this block
+        for (uint32_t r = 0; r < 2; ++r) {
+          const uint32_t i = i0 + r, ip = (r == 0) ? i1 : i2;
+          const double hp = mod_2pi(-link(i, j0, 1) + link(i, j0, 0) + link(ip, j0, 1));
+          const double hm = mod_2pi(+link(i, j1, 1) + link(i, j2, 0) - link(ip, j1, 1));
+          acc[0] += expcos_neg_log_pdf(P.beta, mod_2pi(link(i, j1, 0)), hp, hm);
+        }
+      }
+    }
+  }
+  block_sum<1>(acc, red);
+  if (threadIdx.x == 0) partial[((size_t)b * gridDim.x + blockIdx.x) * 2 + slot] = acc[0];
+}
+
 // en4 = [4][B]: S_f(theta'), S_f(theta), S_c(theta_C), S_c(phi_c); twolevelmetropolisstep.cc:46-84
 __global__ void __launch_bounds__(256)
     lattice_twolevel_accept_kernel(uint32_t n, double *__restrict__ theta, const double *__restrict__ theta_prime,
@@ -1341,6 +1458,37 @@ __global__ void __launch_bounds__(256)
 
 extern "C" {
 
+// besselproductdistribution.hh:44-72: I0(2 beta), the envelope width and the Fourier coefficients alpha_k of the
+// normalisation constant (k <= 16, sums truncated at n, m <= 32)
+static BesselFill make_bessel_fill(double beta) {
+  static BesselFill cached;
+  static bool have = false;
+  if (have && cached.beta == beta) return cached;
+  BesselFill P;
+  P.beta = beta;
+  P.approximate = beta > 8.0 ? 1 : 0;
+  P.I0_twobeta = std::cyl_bessel_i(0.0, 2. * beta);
+  P.sigma_beta = kPi / std::sqrt(2. * std::log(P.I0_twobeta));
+  double logfact[65];
+  logfact[0] = logfact[1] = 0.0;
+  for (int n = 2; n <= 64; ++n) logfact[n] = logfact[n - 1] + std::log((double)n);
+  auto log_binom = [&](int n, int k) { return logfact[n] - logfact[k] - logfact[n - k]; };
+  double alpha0 = 1.0;
+  for (int k = 0; k <= 16; ++k) {
+    double sum = 0.0;
+    for (int n = k; n <= 32; ++n)
+      for (int m = k; m <= 32; ++m)
+        sum += std::pow(0.5 * beta, 2.0 * (n + m)) *
+               std::exp(log_binom(2 * n, n - k) + log_binom(2 * m, m - k) - 2 * (logfact[n] + logfact[m]));
+    const double alpha = ((k == 0) ? 2 : 4) * kPi * sum;
+    if (k == 0) alpha0 = alpha;
+    P.alphaZ[k] = (k == 0) ? alpha : alpha / alpha0;
+  }
+  cached = P;
+  have = true;
+  return P;
+}
+
 static int check_twolevel(const mlmcpi_lattice_action *fine, const mlmcpi_lattice_action *coarse, uint32_t *rt, uint32_t *rx) {
   if (int rc = check_lattice(fine)) return rc;
   if (int rc = check_lattice(coarse)) return rc;
@@ -1350,8 +1498,6 @@ static int check_twolevel(const mlmcpi_lattice_action *fine, const mlmcpi_lattic
   *rx = (coarse->Mx && fine->Mx == 2 * coarse->Mx) ? 2 : (fine->Mx == coarse->Mx ? 1 : 0);
   if (*rt == 0 || *rx == 0 || *rt * *rx == 1)
     return fail(MLMCPI_ERR_INVALID, "invalid coarsening for fill-in (%u x %u from %u x %u)", coarse->Mt, coarse->Mx, fine->Mt, fine->Mx);
-  if (*rt * *rx == 4)
-    return fail(MLMCPI_ERR_UNSUPPORTED, "two-level step: coarsening in both directions (Bessel-product fill-in) is not available on the device");
   return MLMCPI_OK;
 }
 
@@ -1385,9 +1531,22 @@ int mlmcpi_lattice_twolevel_draw(const mlmcpi_lattice_action *fine, const mlmcpi
   double *cfa = (double *)w;
   const RngKey key = make_key(seed, chain0, step);
   const uint32_t nblk = row_blocks(coarse->Mx, B);
-  hipLaunchKernelGGL(schwinger_twolevel_propose_kernel, dim3(nblk, B), dim3(256), 0, st, coarse->Mt, coarse->Mx, rt,
-                     fine->beta, (const double2 *)d_phi_coarse, (const double2 *)d_theta, (double2 *)theta_prime, cfa, key);
-  MLMCPI_LAUNCH_CHECK("schwinger_twolevel_propose_kernel");
+  if (rt * rx == 4) {
+    const BesselFill P = make_bessel_fill(fine->beta);
+    const dim3 grid(nblk, B), block(256);
+    hipLaunchKernelGGL(schwinger_both_fill_kernel, grid, block, 0, st, coarse->Mt, coarse->Mx, P, (const double2 *)d_phi_coarse,
+                       (double2 *)theta_prime, key);
+    MLMCPI_LAUNCH_CHECK("schwinger_both_fill_kernel");
+    hipLaunchKernelGGL(schwinger_both_rows_kernel, grid, block, 0, st, fine->Mt, fine->Mx, fine->beta, (double2 *)theta_prime, key);
+    MLMCPI_LAUNCH_CHECK("schwinger_both_rows_kernel");
+    hipLaunchKernelGGL(schwinger_both_cfa_kernel, grid, block, 0, st, fine->Mt, fine->Mx, P, (const double2 *)theta_prime, cfa, 0u);
+    hipLaunchKernelGGL(schwinger_both_cfa_kernel, grid, block, 0, st, fine->Mt, fine->Mx, P, (const double2 *)d_theta, cfa, 1u);
+    MLMCPI_LAUNCH_CHECK("schwinger_both_cfa_kernel");
+  } else {
+    hipLaunchKernelGGL(schwinger_twolevel_propose_kernel, dim3(nblk, B), dim3(256), 0, st, coarse->Mt, coarse->Mx, rt,
+                       fine->beta, (const double2 *)d_phi_coarse, (const double2 *)d_theta, (double2 *)theta_prime, cfa, key);
+    MLMCPI_LAUNCH_CHECK("schwinger_twolevel_propose_kernel");
+  }
   if (int rc = lattice_energy(fine, theta_prime, B, en4, st)) return rc;
   if (int rc = lattice_energy(fine, d_theta, B, en4 + B, st)) return rc;
   if (int rc = mlmcpi_lattice_copy_from_fine(fine, rt, rx, d_theta, theta_c, B, stream)) return rc;

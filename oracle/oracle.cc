@@ -29,6 +29,7 @@
 #include <cstring>
 #include <deque>
 #include <numeric>
+#include <memory>
 #include <random>
 #include <vector>
 
@@ -72,6 +73,7 @@ enum Purpose : uint32_t {
   P_INIT = 6,        // initial states: one uniform per entry
   P_FILLIN = 7,      // two-level step: Gaussian fill-in of fine-only sites (site = fine index)
   P_ACCEPT2 = 8,     // two-level step: Metropolis uniform
+  P_BESSEL = 9,      // two-level step, Schwinger coarsened in both directions: Bessel-product fill-in (sub = call counter)
 };
 
 inline double u01(uint32_t lo, uint32_t hi) {
@@ -748,10 +750,238 @@ void schwinger_copy_from_coarse(int Mt, int Mx, int rt, int rx, const double *co
     }
 }
 
+// ---- fill-in distributions of the Schwinger lattice coarsened in both directions --------------------------
+// distribution/besselproductdistribution.{hh,cc} (beta <= 8) and approximatebesselproductdistribution.{hh,cc}
+double bessel_i0(double z) { return std::cyl_bessel_i(0.0, std::fabs(z)); }  // gsl_sf_bessel_I0
+double log_factorial(unsigned n) {  // auxilliary.cc:30-36
+  double s = 0.0;
+  for (unsigned k = 2; k <= n; ++k) s += std::log((double)k);
+  return s;
+}
+double log_nCk(unsigned n, unsigned k) { return log_factorial(n) - log_factorial(k) - log_factorial(n - k); }
+
+struct BesselProductO {
+  double beta, I0_twobeta, sigma_beta;
+  double alphaZ[17];
+  explicit BesselProductO(double beta_) : beta(beta_) {  // besselproductdistribution.hh:44-72
+    const unsigned kmax = 16, nmax = 32;
+    I0_twobeta = bessel_i0(2 * beta);
+    sigma_beta = kPi / std::sqrt(2 * std::log(I0_twobeta));
+    double alpha0 = 1.0;
+    for (unsigned k = 0; k <= kmax; ++k) {
+      double sum = 0.0;
+      for (unsigned n = k; n <= nmax; ++n)
+        for (unsigned m = k; m <= nmax; ++m) {
+          double log_comb = log_nCk(2 * n, n - k) + log_nCk(2 * m, m - k) - 2 * (log_factorial(n) + log_factorial(m));
+          sum += std::pow(0.5 * beta, 2.0 * (n + m)) * std::exp(log_comb);
+        }
+      double alpha = ((k == 0) ? 2 : 4) * kPi * sum;
+      if (k == 0) alpha0 = alpha; else alpha /= alpha0;
+      alphaZ[k] = alpha;
+    }
+  }
+  double Znorm_inv(double phi, bool rescaled) const {  // besselproductdistribution.cc:15-25
+    double s = 1.0;
+    for (unsigned k = 1; k <= 16; ++k) s += alphaZ[k] * std::cos(k * phi);
+    if (!rescaled) s *= alphaZ[0];
+    return 1.0 / s;
+  }
+  // besselproductdistribution.hh:88-152, device order: the calls of cell `site` are numbered n = 0, 1, ...;
+  // an outer attempt takes one call (two uniforms), the truncated-normal loop one call per two normals.
+  double draw(const DevRng &rng, uint32_t site, double x_p, double x_m) const {
+    double dx = x_m - x_p;
+    const double flip = (dx < 0) ? -1 : +1;
+    dx *= flip;
+    const double N_p = std::erf((kPi - 0.5 * dx) / sigma_beta);
+    const double N_m = std::erf(0.5 * dx / sigma_beta) * std::pow(I0_twobeta, 2. * (dx / kPi - 1.));
+    const double C_p = std::pow(I0_twobeta, 2. * (1. - dx * dx / (4. * kPi * kPi)));
+    const double C_m = std::pow(I0_twobeta, 2. * (1. - (dx - 2. * kPi) * (dx - 2. * kPi) / (4. * kPi * kPi)));
+    const double sigma = sigma_beta / std::sqrt(2.);
+    uint32_t n = 0;
+    double x = 0.0;
+    while (n < 60000u) {
+      double xi, xi2;
+      rng.uniforms(site, P_BESSEL, n++, xi, xi2);
+      double a_min, a_max, mu, C;
+      if (xi >= N_m / (N_p + N_m)) {
+        a_min = -kPi + dx; a_max = +kPi; mu = 0.5 * dx; C = C_p;
+      } else {
+        a_min = -kPi; a_max = -kPi + dx; mu = 0.5 * (dx - 2. * kPi); C = C_m;
+      }
+      bool inside = false;
+      while (!inside && n < 60000u) {
+        double g0, g1;
+        rng.normals(site, P_BESSEL, n++, g0, g1);
+        x = sigma * g0 + mu;
+        inside = (x >= a_min) && (x < a_max);
+        if (!inside) {
+          x = sigma * g1 + mu;
+          inside = (x >= a_min) && (x < a_max);
+        }
+      }
+      const double I0 = bessel_i0(2. * beta * std::cos(0.5 * x));
+      const double I0_dx = bessel_i0(2. * beta * std::cos(0.5 * (x - dx)));
+      const double xs = (x - mu) / sigma_beta;
+      if (xi2 <= I0 * I0_dx / C * std::exp(xs * xs)) break;
+    }
+    return wrap_2pi(flip * x + x_p);
+  }
+};
+
+// approximatebesselproductdistribution.cc:43-54
+void approx_bessel_params(double beta, double x0, double &N_p, double &s2p_inv, double &s2m_inv) {
+  const double epsilon = 0.125 * kPi;
+  if (x0 < epsilon) {
+    s2p_inv = beta; s2m_inv = 0.0; N_p = 1.0;
+  } else {
+    s2p_inv = beta * std::cos(0.25 * x0);
+    s2m_inv = beta * std::sin(0.25 * x0);
+    const double rho = std::pow(s2p_inv / s2m_inv, 1.5) * std::exp(-4.0 * (s2p_inv - s2m_inv));
+    N_p = 1.0 / (1.0 + rho);
+  }
+}
+// approximatebesselproductdistribution.hh:82-107, device order: one call (uniform, unused) + one call (normal)
+double approx_bessel_draw(const DevRng &rng, uint32_t site, double beta, double x_p, double x_m) {
+  double x0 = x_p - x_m;
+  double flip = (x0 < 0) ? -1 : +1;
+  x0 *= flip;
+  if (x0 > kPi) { x0 = 2. * kPi - x0; flip *= -1; }
+  double N_p, s2p, s2m;
+  approx_bessel_params(beta, x0, N_p, s2p, s2m);
+  double xi, unused, g0, g1;
+  rng.uniforms(site, P_BESSEL, 0, xi, unused);
+  rng.normals(site, P_BESSEL, 1, g0, g1);
+  const double sigma = (xi <= N_p) ? 1. / std::sqrt(s2p) : 1. / std::sqrt(s2m);
+  const double xshift = (xi <= N_p) ? 0.0 : kPi;
+  const double x = sigma * g0 + 0.5 * x0 - xshift;
+  return wrap_2pi(flip * x + x_m);
+}
+// approximatebesselproductdistribution.cc:7-40
+double approx_bessel_pdf(double beta, double x, double x_p, double x_m) {
+  double x0 = x_p - x_m, z = x - x_m;
+  double flip = (x0 < 0) ? -1 : +1;
+  x0 *= flip;
+  if (x0 > kPi) { x0 = 2. * kPi - x0; flip *= -1; }
+  z *= flip;
+  double N_p, s2p, s2m;
+  approx_bessel_params(beta, x0, N_p, s2p, s2m);
+  const double N_m = 1. - N_p;
+  double sp = 0.0, sm = 0.0;
+  for (int k = -4; k <= 4; ++k) {
+    double zs = z - 0.5 * x0 + 2 * k * kPi;
+    sp += std::sqrt(s2p) * std::exp(-0.5 * s2p * zs * zs);
+    zs += kPi;
+    sm += std::sqrt(s2m) * std::exp(-0.5 * s2m * zs * zs);
+  }
+  return std::sqrt(0.5 / kPi) * (N_p * sp + N_m * sm);
+}
+
+// QuenchedSchwingerConditionedFineAction::evaluate (quenchedschwingerconditionedfineaction.cc:207-289)
+double schwinger_both_cfa(const ActionO &F, const BesselProductO *bp, const double *x) {
+  const Grid2 &g = F.g;
+  const double beta = F.beta;
+  double S = 0.0;
+  if (bp) {
+    for (int i = 0; i < g.Mt / 2; ++i)
+      for (int j = 0; j < g.Mx / 2; ++j) {
+        double phi_12 = +x[g.link(2 * i, 2 * j + 1, 1)] + x[g.link(2 * i, 2 * j + 2, 0)];
+        double phi_23 = +x[g.link(2 * i + 1, 2 * j + 2, 0)] - x[g.link(2 * i + 2, 2 * j + 1, 1)];
+        double phi_34 = -x[g.link(2 * i + 1, 2 * j, 0)] - x[g.link(2 * i + 2, 2 * j, 1)];
+        double phi_41 = -x[g.link(2 * i, 2 * j, 0)] + x[g.link(2 * i, 2 * j, 1)];
+        double theta_1 = +x[g.link(2 * i, 2 * j + 1, 0)];
+        double theta_2 = -x[g.link(2 * i + 1, 2 * j + 1, 1)];
+        double theta_3 = -x[g.link(2 * i + 1, 2 * j + 1, 0)];
+        double theta_4 = +x[g.link(2 * i + 1, 2 * j, 1)];
+        double Phi = phi_12 + phi_23 + phi_34 + phi_41;
+        S -= beta * (std::cos(theta_1 - theta_2 - phi_12) + std::cos(theta_2 - theta_3 - phi_23) +
+                     std::cos(theta_3 - theta_4 - phi_34) + std::cos(theta_4 - theta_1 - phi_41));
+        S -= std::log(bp->Znorm_inv(Phi, true));
+      }
+  } else {
+    for (int i = 0; i < g.Mt / 2; ++i)
+      for (int j = 0; j < g.Mx / 2; ++j) {
+        double phi_p = wrap_2pi(+x[g.link(2 * i + 1, 2 * j, 0)] + x[g.link(2 * i + 2, 2 * j, 1)] +
+                                x[g.link(2 * i + 2, 2 * j + 1, 1)] - x[g.link(2 * i + 1, 2 * j + 2, 0)]);
+        double phi_m = wrap_2pi(-x[g.link(2 * i, 2 * j, 0)] + x[g.link(2 * i, 2 * j, 1)] + x[g.link(2 * i, 2 * j + 1, 1)] +
+                                x[g.link(2 * i, 2 * j + 2, 0)]);
+        double theta = wrap_2pi(+x[g.link(2 * i + 1, 2 * j, 1)] + x[g.link(2 * i + 1, 2 * j + 1, 1)]);
+        S -= std::log(approx_bessel_pdf(beta, theta, phi_p, phi_m));
+      }
+    for (int i = 0; i < g.Mt; ++i)
+      for (int j = 0; j < g.Mx / 2; ++j) {
+        double phi_p = wrap_2pi(-x[g.link(i, 2 * j, 1)] + x[g.link(i, 2 * j, 0)] + x[g.link(i + 1, 2 * j, 1)]);
+        double phi_m = wrap_2pi(+x[g.link(i, 2 * j + 1, 1)] + x[g.link(i, 2 * j + 2, 0)] - x[g.link(i + 1, 2 * j + 1, 1)]);
+        double theta = wrap_2pi(+x[g.link(i, 2 * j + 1, 0)]);
+        S -= std::log(expcos_pdf(beta, theta, phi_p, phi_m));
+      }
+  }
+  return S;
+}
+
+// QuenchedSchwingerConditionedFineAction::fill_fine_points (quenchedschwingerconditionedfineaction.cc:7-78), device
+// order: coarse cell c = j Mt_c + i: Philox(c, P_FILLIN, 0) -> (dtheta of the temporal pair, of the spatial pair),
+// Philox(c, P_FILLIN, 1) -> dtheta of the interior pair, Bessel-product draw = stream (c, P_BESSEL), ExpCos draw of
+// fine link l = von Mises stream (l, kVmFillin).
+void schwinger_both_fill(const ActionO &F, const ActionO &Cc, const BesselProductO *bp, const DevRng &rng, double *tp) {
+  const Grid2 &g = F.g, &gc = Cc.g;
+  for (int i = 0; i < g.Mt / 2; ++i)
+    for (int j = 0; j < g.Mx / 2; ++j) {
+      double dt, dx;
+      rng.uniforms((uint32_t)(j * gc.Mt + i), P_FILLIN, 0, dt, dx);
+      dt = (2. * dt - 1.) * kPi;
+      dx = (2. * dx - 1.) * kPi;
+      tp[g.link(2 * i, 2 * j, 0)] = wrap_2pi(tp[g.link(2 * i, 2 * j, 0)] + dt);
+      tp[g.link(2 * i + 1, 2 * j, 0)] = wrap_2pi(tp[g.link(2 * i + 1, 2 * j, 0)] - dt);
+      tp[g.link(2 * i, 2 * j, 1)] = wrap_2pi(tp[g.link(2 * i, 2 * j, 1)] + dx);
+      tp[g.link(2 * i, 2 * j + 1, 1)] = wrap_2pi(tp[g.link(2 * i, 2 * j + 1, 1)] - dx);
+    }
+  for (int i = 0; i < g.Mt / 2; ++i)
+    for (int j = 0; j < g.Mx / 2; ++j) {
+      const uint32_t c = (uint32_t)(j * gc.Mt + i);
+      double theta_p = wrap_2pi(tp[g.link(2 * i + 1, 2 * j, 0)] + tp[g.link(2 * i + 2, 2 * j, 1)] +
+                                tp[g.link(2 * i + 2, 2 * j + 1, 1)] - tp[g.link(2 * i + 1, 2 * j + 2, 0)]);
+      double theta_m = wrap_2pi(tp[g.link(2 * i, 2 * j, 1)] + tp[g.link(2 * i, 2 * j + 1, 1)] + tp[g.link(2 * i, 2 * j + 2, 0)] -
+                                tp[g.link(2 * i, 2 * j, 0)]);
+      double theta_tilde = bp ? bp->draw(rng, c, theta_p, theta_m) : approx_bessel_draw(rng, c, F.beta, theta_p, theta_m);
+      double d, unused;
+      rng.uniforms(c, P_FILLIN, 1, d, unused);
+      d = (2. * d - 1.) * kPi;
+      tp[g.link(2 * i + 1, 2 * j, 1)] = wrap_2pi(0.5 * theta_tilde + d);
+      tp[g.link(2 * i + 1, 2 * j + 1, 1)] = wrap_2pi(0.5 * theta_tilde - d);
+    }
+  for (int i = 0; i < g.Mt; ++i)
+    for (int j = 0; j < g.Mx / 2; ++j) {
+      double theta_p = wrap_2pi(tp[g.link(i, 2 * j, 0)] + tp[g.link(i + 1, 2 * j, 1)] - tp[g.link(i, 2 * j, 1)]);
+      double theta_m = wrap_2pi(tp[g.link(i, 2 * j + 1, 1)] + tp[g.link(i, 2 * j + 2, 0)] - tp[g.link(i + 1, 2 * j + 1, 1)]);
+      const unsigned l = g.link(i, 2 * j + 1, 0);
+      const double dxx = theta_m - theta_p;
+      const double tau = 2. * F.beta * std::fabs(std::cos(0.5 * dxx));
+      const double x = dev_vonmises(rng, l, tau, kVmFillin);
+      tp[l] = wrap_2pi(x + 0.5 * (theta_p + theta_m) + (std::fabs(dxx) > kPi ? kPi : 0.0));
+    }
+}
+
 // Two-level step on the Schwinger lattice, semi-coarsening, device order: twolevelmetropolisstep.cc:35-89 with
 // quenchedschwingeraction.cc:92-195 and QuenchedSchwingerSemiConditionedFineAction::fill_fine_points
 // (quenchedschwingerconditionedfineaction.cc:130-204).  dtheta of coarse cell c comes from Philox(site c,
 // P_FILLIN); the ExpCos draw of fine link l from the von Mises stream (site l, kVmFillin).
+// twolevelmetropolisstep.cc:69-84
+int twolevel_decide(double dS_fine, double dS_coarse, double dS_trial, const DevRng &rng, const std::vector<double> &tp,
+                    double *theta, double *terms) {
+  const double dS = dS_fine + dS_coarse + dS_trial;
+  if (terms) { terms[0] = dS_fine; terms[1] = dS_coarse; terms[2] = dS_trial; }
+  bool acc;
+  if (dS < 0.0) {
+    acc = true;
+  } else {
+    double u, v;
+    rng.uniforms(0, P_ACCEPT2, 0, u, v);
+    acc = u < std::exp(-dS);
+  }
+  if (acc) std::copy(tp.begin(), tp.end(), theta);
+  return acc ? 1 : 0;
+}
+
 int dev_schwinger_twolevel_draw(const ActionO &F, const ActionO &Cc, const double *phi_coarse, double *theta,
                                 const DevRng &rng, double *terms) {
   const Grid2 &g = F.g, &gc = Cc.g;
@@ -798,6 +1028,21 @@ int dev_schwinger_twolevel_draw(const ActionO &F, const ActionO &Cc, const doubl
         const unsigned l = g.link(i, 2 * j + 1, 0);
         tp[l] = draw(l, theta_p, theta_m);
       }
+  } else if (rt == 2 && rx == 2) {
+    // quenchedschwingerconditionedfineaction.hh:62-71: true distribution up to beta = 8, approximation beyond
+    static std::unique_ptr<BesselProductO> cached;  // the coefficient table costs ~10 ms to build
+    const BesselProductO *bp_ptr = nullptr;
+    if (!(F.beta > 8.0)) {
+      if (!cached || cached->beta != F.beta) cached.reset(new BesselProductO(F.beta));
+      bp_ptr = cached.get();
+    }
+    struct { const BesselProductO *p; const BesselProductO *get() const { return p; } } bp{bp_ptr};
+    schwinger_both_fill(F, Cc, bp.get(), rng, tp.data());
+    double dS_fine = F.evaluate(tp.data()) - F.evaluate(theta);
+    schwinger_copy_from_fine(gc.Mt, gc.Mx, rt, rx, theta, thetaC.data());
+    double dS_coarse = Cc.evaluate(thetaC.data()) - Cc.evaluate(phi_coarse);
+    double dS_trial = schwinger_both_cfa(F, bp.get(), theta) - schwinger_both_cfa(F, bp.get(), tp.data());
+    return twolevel_decide(dS_fine, dS_coarse, dS_trial, rng, tp, theta, terms);
   } else {
     return -1;  // "invalid coarsening for fill-in"
   }
@@ -805,18 +1050,7 @@ int dev_schwinger_twolevel_draw(const ActionO &F, const ActionO &Cc, const doubl
   schwinger_copy_from_fine(gc.Mt, gc.Mx, rt, rx, theta, thetaC.data());
   double dS_coarse = Cc.evaluate(thetaC.data()) - Cc.evaluate(phi_coarse);
   double dS_trial = schwinger_semi_cfa(F, rt, theta) - schwinger_semi_cfa(F, rt, tp.data());
-  double dS = dS_fine + dS_coarse + dS_trial;
-  if (terms) { terms[0] = dS_fine; terms[1] = dS_coarse; terms[2] = dS_trial; }
-  bool acc;
-  if (dS < 0.0) {
-    acc = true;
-  } else {
-    double u, v;
-    rng.uniforms(0, P_ACCEPT2, 0, u, v);
-    acc = u < std::exp(-dS);
-  }
-  if (acc) std::copy(tp.begin(), tp.end(), theta);
-  return acc ? 1 : 0;
+  return twolevel_decide(dS_fine, dS_coarse, dS_trial, rng, tp, theta, terms);
 }
 
 // ---------------------------------------------------------------------------------------------

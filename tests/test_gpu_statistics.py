@@ -195,15 +195,16 @@ def test_rotor_hierarchical_chain_samples_fine_distribution(gpu_ops, orc):
     assert abs(mcos - rcos) < 4 * math.hypot(ecos, rerr)
 
 
-@pytest.mark.parametrize("rt,rx", [(2, 1), (1, 2)])
+@pytest.mark.parametrize("rt,rx", [(2, 1), (1, 2), (2, 2)])
 def test_schwinger_hierarchical_chain_samples_fine_distribution(gpu_ops, rt, rx):
-    """Schwinger 8 x 8, beta = 1.5: coarse-level overrelaxed heat bath on the semi-coarsened lattice (beta/2) +
-    TwoLevelMetropolisStep with the ExpCos conditioned fine action must sample the FINE-level distribution:
+    """Schwinger 8 x 8, beta = 1.5: coarse-level overrelaxed heat bath on the coarsened lattice (beta/2 for
+    semi-coarsening, beta/4 for both directions) + TwoLevelMetropolisStep with the conditioned fine action (ExpCos,
+    Bessel product) must sample the FINE-level distribution:
     average plaquette and Q^2 against a direct fine-level heat-bath chain."""
     from mlmcpathintegral_amd import abi
     Mt = Mx = 8
     beta, B = 1.5, 512
-    fine, coarse = abi.lattice_action(4, Mt, Mx, beta=beta), abi.lattice_action(4, Mt // rt, Mx // rx, beta=0.5 * beta)
+    fine, coarse = abi.lattice_action(4, Mt, Mx, beta=beta), abi.lattice_action(4, Mt // rt, Mx // rx, beta=beta / (rt * rx))
     pc = gpu_ops.lattice_initialise(coarse, B, SEED)
     scratch = torch.empty_like(pc)
     step = gpu_ops.LatticeTwoLevelStep(fine, coarse, B, seed=SEED + 1)
