@@ -197,6 +197,28 @@ int main(int argc, char **argv) {
     std::printf(" MLMC <x^2> = %.6f +- %.6f (analytic %.6f)\n", mlmc.numerical_result(), mlmc.statistical_error(), exact);
     EXPECT(std::fabs(mlmc.numerical_result() - exact) < 5 * mlmc.statistical_error(), "MLMC estimate");
     EXPECT(mlmc.level_statistics(0)->variance() < mlmc.level_statistics(2)->variance(), "variance decays towards fine levels");
+    // level sharding: two ranks in lockstep, rank r owns the levels l with l % 2 == r; what they
+    // exchange per pass is the 3 x 5 table, summed element-wise (the all-reduce of a real two-process run)
+    MultiLevelMCParameters p0 = mlp, p1 = mlp;
+    p0.level_ranks = p1.level_ranks = 2;
+    p0.level_rank = 0; p1.level_rank = 1;
+    MonteCarloMultiLevel r0(act, std::make_shared<QoIXsquaredFactory>(), hfac, cfa, p0);
+    MonteCarloMultiLevel r1(act, std::make_shared<QoIXsquaredFactory>(), hfac, cfa, p1);
+    r0.begin(); r1.begin();
+    bool done0, done1;
+    int passes = 0;
+    do {
+      std::vector<double> t0 = r0.pass(), t1 = r1.pass();
+      for (size_t k = 0; k < t0.size(); ++k) t0[k] += t1[k];
+      done0 = r0.update(t0);
+      done1 = r1.update(t0);
+      ++passes;
+    } while (!done0);
+    std::printf(" level-sharded MLMC (2 ranks, %d passes): <x^2> = %.6f +- %.6f (analytic %.6f)\n", passes, r0.numerical_result(),
+                r0.statistical_error(), exact);
+    EXPECT(done0 == done1 && r0.numerical_result() == r1.numerical_result(), "ranks agree on the combined estimate");
+    EXPECT(std::fabs(r0.numerical_result() - exact) < 5 * r0.statistical_error(), "level-sharded MLMC estimate");
+    EXPECT(r0.owns(0) && !r0.owns(1) && r0.owns(2) && r1.owns(1), "level ownership");
   }
   // ---- rotor: hierarchical sampler (heat bath on the coarsest level, ExpSin2 fill-in) vs the direct sampler ---
   {

@@ -342,6 +342,20 @@ struct MultiLevelMCParameters {
   unsigned int n_autocorr_window = 20, n_min_samples_qoi = 100;
   bool sub_sample_coarse = true;  // hierarchical coarse samplers: draw ceil(2 tau_int) times between uses
   unsigned int n_meas = 200;
+  // level sharding: this process is rank `level_rank` of `level_ranks`; it owns, builds and samples
+  // the levels l with l % level_ranks == level_rank.  1 rank = the reference's single-process estimator.
+  unsigned int level_rank = 0, level_ranks = 1;
+};
+
+/** What the ranks of a level-sharded estimator exchange once per pass of the do-while of
+ *  montecarlomultilevel.cc:115-165: a table [n_level][5] = (samples, mean, variance, tau_int, cost) in which every
+ *  rank fills the rows of its own levels and leaves the others zero, summed element-wise over ranks (an all-reduce
+ *  of 5 n_level doubles, which for disjoint rows is the all-gather).  Implementations: MPI_Allreduce in the
+ *  reference's build, ncclAllReduce / torch.distributed over RCCL (mlmcpathintegral_amd/chains.py), none for 1 rank. */
+class LevelExchange {
+public:
+  virtual ~LevelExchange() {}
+  virtual void allreduce_sum(std::vector<double> &table) = 0;
 };
 
 /** montecarlomultilevel.cc:7-282: telescoping-sum estimator Q = sum_l E[Y_l], Y_L = Q_L on the coarsest
@@ -355,13 +369,16 @@ public:
                        const MultiLevelMCParameters p)
       : param(p), n_level(p.n_level) {
     if (n_level < 2) fatal("multilevel method needs at least two levels");
+    if (p.level_ranks < 1 || p.level_rank >= p.level_ranks) fatal("multilevel method: invalid level partition");
     action.push_back(fine_action_);
     for (unsigned int level = 0; level + 1 < n_level; ++level) {
       std::shared_ptr<Action> c = action[level]->coarse_action();
       c->set_seed(fine_action_->get_seed() + 7919 * (level + 1), fine_action_->get_chain0());
       action.push_back(c);
-      twolevel_step.push_back(std::make_shared<TwoLevelMetropolisStep>(c, action[level], cfa_factory->get(action[level]), 1, p.n_meas));
-      coarse_sampler.push_back(sampler_factory->get(c));  // sampler for level + 1
+      // level `level` needs its two-level step and the sampler of level + 1; the coarsest level its own sampler
+      const bool needed = owns(level) || (level + 2 == n_level && owns(level + 1));
+      twolevel_step.push_back(owns(level) ? std::make_shared<TwoLevelMetropolisStep>(c, action[level], cfa_factory->get(action[level]), 1, p.n_meas) : nullptr);
+      coarse_sampler.push_back(needed ? sampler_factory->get(c) : nullptr);  // sampler for level + 1
     }
     for (unsigned int level = 0; level < n_level; ++level) {
       qoi.push_back(qoi_factory->get(action[level]));
@@ -376,11 +393,27 @@ public:
     n_target.assign(n_level, p.n_min_samples_qoi);
   }
 
+  bool owns(unsigned int level) const { return level % param.level_ranks == param.level_rank; }
+  void set_exchange(std::shared_ptr<LevelExchange> e) { exchange = e; }
+
+  /** montecarlomultilevel.cc:71-167 = begin(); do { table = pass(); exchange; } while (!update(table)); */
   void evaluate() {
+    if (param.level_ranks > 1 && !exchange) fatal("level-sharded multilevel estimator needs a LevelExchange");
+    begin();
+    bool sufficient;
+    do {
+      std::vector<double> table = pass();
+      if (exchange) exchange->allreduce_sum(table);
+      sufficient = update(table);
+    } while (!sufficient);
+  }
+
+  /** burn-in of the owned levels (montecarlomultilevel.cc:83-100): straight from the coarse samplers, no sub-sampling */
+  void begin() {
     for (unsigned int level = 0; level < n_level; ++level) stats_qoi[level]->hard_reset();
     for (auto &s : stats_coarse_sampler) s->hard_reset();
-    // burn-in (montecarlomultilevel.cc:83-100): straight from the coarse samplers, no sub-sampling
-    for (int level = (int)n_level - 1; level >= 0; --level)
+    for (int level = (int)n_level - 1; level >= 0; --level) {
+      if (!owns(level)) continue;
       for (unsigned int j = 0; j < param.n_burnin; ++j) {
         double qoi_Y;
         if (level == (int)n_level - 1) {
@@ -393,40 +426,60 @@ public:
         }
         stats_qoi[level]->record_sample(qoi_Y);
       }
+    }
     for (unsigned int level = 0; level < n_level; ++level) {
       stats_qoi[level]->reset();
       n_target[level] = param.n_min_samples_qoi;
     }
+    summary.assign(5 * n_level, 0.0);
+  }
+
+  /** one pass of montecarlomultilevel.cc:115-147 over the owned levels; returns the table with the owned rows filled */
+  std::vector<double> pass() {
+    std::vector<double> table(5 * n_level, 0.0);
+    for (int level = (int)n_level - 1; level >= 0; --level) {
+      if (!owns(level)) continue;
+      for (unsigned int j = stats_qoi[level]->samples(); j < n_target[level]; ++j) stats_qoi[level]->record_sample(sample_Y(level));
+      if (verbose) std::cout << "  level " << level << ": " << stats_qoi[level]->samples() << " samples" << std::endl;
+      double *row = &table[5 * level];
+      row[0] = stats_qoi[level]->samples();
+      row[1] = stats_qoi[level]->average();
+      row[2] = stats_qoi[level]->variance();
+      row[3] = stats_qoi[level]->tau_int();
+      row[4] = cost_eff(level);
+    }
+    return table;
+  }
+
+  /** sample targets from the complete table (montecarlomultilevel.cc:148-164); true when every level has enough */
+  bool update(const std::vector<double> &table) {
+    summary = table;
     const double two_epsilon_inv2 = 2. / (param.epsilon * param.epsilon);
-    bool sufficient = false;
-    do {
-      for (int level = (int)n_level - 1; level >= 0; --level) {
-        for (unsigned int j = stats_qoi[level]->samples(); j < n_target[level]; ++j) stats_qoi[level]->record_sample(sample_Y(level));
-        if (verbose) std::cout << "  level " << level << ": " << stats_qoi[level]->samples() << " samples" << std::endl;
-      }
-      sufficient = true;
-      double sum = 0;
-      for (unsigned int ell = 0; ell < n_level; ++ell) sum += std::sqrt(stats_qoi[ell]->variance() * cost_eff(ell));
-      for (unsigned int ell = 0; ell < n_level; ++ell) {
-        const double V = stats_qoi[ell]->variance(), C = cost_eff(ell);
-        n_target[ell] = (unsigned int)std::ceil(two_epsilon_inv2 * sum * std::sqrt(V / C) * stats_qoi[ell]->tau_int());
-        sufficient = sufficient && (stats_qoi[ell]->samples() >= n_target[ell]);
-      }
-    } while (!sufficient);
+    bool sufficient = true;
+    double sum = 0;
+    for (unsigned int ell = 0; ell < n_level; ++ell) sum += std::sqrt(table[5 * ell + 2] * table[5 * ell + 4]);
+    for (unsigned int ell = 0; ell < n_level; ++ell) {
+      const double V = table[5 * ell + 2], C = table[5 * ell + 4];
+      n_target[ell] = (unsigned int)std::ceil(two_epsilon_inv2 * sum * std::sqrt(V / C) * table[5 * ell + 3]);
+      sufficient = sufficient && (table[5 * ell] >= n_target[ell]);
+    }
+    return sufficient;
   }
   /** montecarlomultilevel.cc:255-271 */
   double numerical_result() const {
     double q = 0;
-    for (unsigned int ell = 0; ell < n_level; ++ell) q += stats_qoi[ell]->average();
+    for (unsigned int ell = 0; ell < n_level; ++ell) q += summary[5 * ell + 1];
     return q;
   }
+  /** sum of the levels' error^2 = tau_int variance / samples (statistics.cc:62-64) */
   double statistical_error() const {
     double e2 = 0;
-    for (unsigned int ell = 0; ell < n_level; ++ell) e2 += stats_qoi[ell]->error() * stats_qoi[ell]->error();
+    for (unsigned int ell = 0; ell < n_level; ++ell) e2 += summary[5 * ell + 3] * summary[5 * ell + 2] / summary[5 * ell];
     return std::sqrt(e2);
   }
   void show_statistics() {
-    for (unsigned int ell = 0; ell < n_level; ++ell) std::cout << *stats_qoi[ell] << "  target samples = " << n_target[ell] << std::endl;
+    for (unsigned int ell = 0; ell < n_level; ++ell)
+      if (owns(ell)) std::cout << *stats_qoi[ell] << "  target samples = " << n_target[ell] << std::endl;
     std::cout << " Q = " << std::setprecision(6) << numerical_result() << " +/- " << statistical_error() << std::endl;
   }
   std::shared_ptr<Statistics> level_statistics(unsigned int ell) { return stats_qoi[ell]; }
@@ -480,6 +533,8 @@ private:
   std::vector<std::shared_ptr<Statistics>> stats_qoi, stats_coarse_sampler;
   std::vector<double> t_indep, n_indep, t_sampler;
   std::vector<unsigned int> n_target;
+  std::vector<double> summary;  // the last exchanged table
+  std::shared_ptr<LevelExchange> exchange;
 };
 
 /** QoI factories (qoi/qm/qoixsquared.hh etc.): a QoI per level */

@@ -51,3 +51,49 @@ def summarise(packed, n_chains_total=None, chain_means=None):
     if chain_means is not None and chain_means.numel() > 1:
         out["error"] = float(chain_means.std(unbiased=True)) / math.sqrt(chain_means.numel())
     return out
+
+
+# ---- level sharding of the multilevel estimator -------------------------------------------
+# Levels are independent estimators (montecarlomultilevel.cc:27-45): level l runs on rank l % world.  Once per pass of
+# the do-while of montecarlomultilevel.cc:115-165 the ranks exchange a table [n_level, 5] =
+# (samples, mean, variance, tau_int, cost): every rank fills the rows of its levels, leaves the others zero, and one
+# all-reduce(SUM) of the table (= the all-gather of disjoint rows) gives every rank the whole picture.  This is the
+# same contract as LevelExchange::allreduce_sum in include/mlmcpi/multilevel.hh.
+N_LEVEL_FIELDS = 5
+
+
+def level_owner(level, world):
+    return level % world
+
+
+def owned_levels(n_level, rank, world):
+    return [l for l in range(n_level) if level_owner(l, world) == rank]
+
+
+def level_table(n_level, rows, device="cpu"):
+    """rows: {level: (samples, mean, variance, tau_int, cost)} for the levels this rank owns."""
+    t = torch.zeros((n_level, N_LEVEL_FIELDS), dtype=torch.float64, device=device)
+    for level, row in rows.items():
+        t[level] = torch.tensor(row, dtype=torch.float64, device=device)
+    return t
+
+
+def allreduce_level_table(table, group=None):
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(table, op=dist.ReduceOp.SUM, group=group)
+    return table
+
+
+def level_targets(table, epsilon):
+    """montecarlomultilevel.cc:148-164: samples needed per level for a statistical error epsilon / sqrt(2);
+    returns (targets [n_level], sufficient)."""
+    n, var, tau, cost = table[:, 0], table[:, 2], table[:, 3], table[:, 4]
+    total = torch.sqrt(var * cost).sum()
+    targets = torch.ceil(2.0 / (epsilon * epsilon) * total * torch.sqrt(var / cost) * tau)
+    return targets, bool((n >= targets).all())
+
+
+def combine_levels(table):
+    """montecarlomultilevel.cc:255-271: telescoping sum and its statistical error."""
+    n, mean, var, tau = table[:, 0], table[:, 1], table[:, 2], table[:, 3]
+    return float(mean.sum()), float(torch.sqrt((tau * var / n).sum()))

@@ -61,3 +61,45 @@ def test_distribute_n_matches_reference_rule():
         for world in (1, 2, 3, 8):
             parts = [chains.distribute_n(n, r, world) for r in range(world)]
             assert sum(parts) == n and max(parts) - min(parts) <= 1 and parts == sorted(parts, reverse=True)
+
+
+def _level_worker(rank, world, port, n_level, q):
+    sys.path.insert(0, ROOT)
+    from mlmcpathintegral_amd import chains
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rows = {l: _level_row(l) for l in chains.owned_levels(n_level, rank, world)}
+    table = chains.allreduce_level_table(chains.level_table(n_level, rows))
+    targets, sufficient = chains.level_targets(table, 0.05)
+    q.put((rank, sorted(rows), table.tolist(), targets.tolist(), sufficient, chains.combine_levels(table)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _level_row(level):
+    # (samples, mean, variance, tau_int, cost): variance decays, cost grows towards the fine levels (level 0 = finest)
+    return (1000.0 + 100 * level, 0.5 / (level + 1), 0.01 * 4.0 ** level, 1.0 + 0.5 * level, 64.0 / 2.0 ** level)
+
+
+def test_level_sharded_table_exchange():
+    """level l on rank l % world; one all-reduce of the [n_level, 5] table per pass."""
+    from mlmcpathintegral_amd import chains
+    world, port, n_level = 2, 29555, 5
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_level_worker, args=(r, world, port, n_level, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == [0, 2, 4] and res[1][1] == [1, 3]
+    serial = chains.level_table(n_level, {l: _level_row(l) for l in range(n_level)})
+    for r in res:
+        assert torch.equal(torch.tensor(r[2], dtype=torch.float64), serial)
+    t_serial, suff_serial = chains.level_targets(serial, 0.05)
+    assert res[0][3] == res[1][3] == t_serial.tolist() and res[0][4] == res[1][4] == suff_serial
+    q_serial, e_serial = chains.combine_levels(serial)
+    assert res[0][5] == res[1][5] == (q_serial, e_serial)
+    assert abs(q_serial - sum(0.5 / (l + 1) for l in range(n_level))) < 1e-15
