@@ -30,7 +30,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="schwinger", choices=["schwinger", "gff", "rotor_hmc", "quartic_hmc", "ho_hmc"])
+    ap.add_argument("--workload", default="schwinger", choices=["schwinger", "gff", "rotor_hmc", "quartic_hmc", "ho_hmc", "quartic_mlmc"])
     ap.add_argument("--size", type=int, default=0, help="lattice extent (default: BASELINE size of the workload)")
     ap.add_argument("--chains", type=int, default=0, help="independent chains per GPU (default per workload)")
     ap.add_argument("--fuse", type=int, default=0, help="sweeps fused per launch (0 = library default)")
@@ -46,7 +46,8 @@ def parse():
 
 def cpu_baseline(a, size):
     """Reference-order oracle on the host cores; run BEFORE this process touches the GPU."""
-    wl = {"schwinger": "schwinger", "gff": "gff", "rotor_hmc": "rotor", "quartic_hmc": "quartic", "ho_hmc": "harmonic"}[a.workload]
+    wl = {"schwinger": "schwinger", "gff": "gff", "rotor_hmc": "rotor", "quartic_hmc": "quartic", "ho_hmc": "harmonic",
+          "quartic_mlmc": "quartic"}[a.workload]
     draws = a.cpu_draws or {"schwinger": 5, "gff": 40, "rotor": 30, "quartic": 200, "harmonic": 100000}[wl]
     dt = a.dt or {"rotor": 0.05, "harmonic": 0.0558}.get(wl, 0.02)
     cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--workload", wl, "--size", str(size),
@@ -65,8 +66,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    size = a.size or {"schwinger": 1024, "gff": 512, "rotor_hmc": 65536, "quartic_hmc": 32768, "ho_hmc": 128}[a.workload]
-    B = a.chains or {"schwinger": 32, "gff": 1024, "rotor_hmc": 1024, "quartic_hmc": 2048, "ho_hmc": 8192}[a.workload]
+    size = a.size or {"schwinger": 1024, "gff": 512, "rotor_hmc": 65536, "quartic_hmc": 32768, "ho_hmc": 128,
+                      "quartic_mlmc": 32768}[a.workload]
+    B = a.chains or {"schwinger": 32, "gff": 1024, "rotor_hmc": 1024, "quartic_hmc": 2048, "ho_hmc": 8192,
+                     "quartic_mlmc": 512}[a.workload]
 
     cpu = None
     if world == 1 and a.gpus == 1 and not a.no_cpu_baseline:
@@ -132,6 +135,35 @@ def main():
                 return ops.qoi_avg_plaquette(state["x"], size, size)
             return ops.qoi_phi_squared(state["x"])
         bytes_per_unit = 16.0  # each entry read once and written once per sweep
+    elif a.workload == "quartic_mlmc":
+        # BASELINE configs[4]: quartic double well, 5 levels, finest M_lat = 32768, a = 0.125;
+        # level l on rank l % world, every level instance runs B chains; a step = one Y sample per chain on every
+        # level instance (2 trajectories of the level's sampler + the two-level step).
+        from mlmcpathintegral_amd import mlmc
+        n_level = 5
+        est = mlmc.PathMLMC(abi.QUARTIC, size, size / 8.0, n_level, B, nt=a.nt, dt0=a.dt or 0.02, seed=a.seed, rank=rank,
+                            world=world, n_sub=2, params=dict(lam=1.0, x0=1.0))
+        est.thermalise(64)
+        # site-steps per step, all levels (the same on every rank count): HMC of the feeding level + two-level pass
+        units_per_step = 0
+        for l in range(n_level):
+            src = l if l == n_level - 1 else l + 1
+            units_per_step += (2 * (a.nt + 1) * (size >> src) + (0 if l == n_level - 1 else (size >> l))) * B
+        fuse = 1
+
+        def step(record):
+            if record:
+                e0, e1 = ev(), ev()
+                e0.record()
+            est.pass_(1)
+            if record:
+                e1.record()
+                or_events.append((e0, e1))
+
+        def qoi():
+            lv = est.levels[min(est.levels)]
+            return ops.qoi_xsquared(lv.x)
+        bytes_per_unit = 32.0
     else:
         kind = {"rotor_hmc": abi.ROTOR, "quartic_hmc": abi.QUARTIC, "ho_hmc": abi.HARMONIC}[a.workload]
         # a = 0.125 at the BASELINE sizes; config 1 (HO, M_lat = 128) keeps T_final = 4
@@ -143,10 +175,7 @@ def main():
         hmc = ops.PathHMC(act, B, a.nt, dt, seed=a.seed, chain0=chain0)
         # untimed thermalisation from the reference's cold / random start with small steps, so that the
         # timed trajectories run at a realistic acceptance rate (reported as p_accept)
-        for k in range(24):
-            hmc.dt = dt * (0.2 if k < 16 else 0.5)
-            hmc.draw(x, count_stats=False)
-        hmc.dt = dt
+        ops.hmc_thermalise(hmc, x, 32)
         units_per_step = size * (a.nt + 1) * B * draws_per_step  # site-steps: one site x one force evaluation
         fuse = 1
 
@@ -187,6 +216,9 @@ def main():
     acc = torch.zeros((B, chains.N_MOMENTS), dtype=torch.float64, device="cuda")
     ops.stats_accumulate(acc, qoi())
     packed = chains.allreduce_moments(chains.pack_moments(acc))
+    if a.workload == "quartic_mlmc":
+        mlmc_q, mlmc_e, mlmc_t = est.estimate(device="cuda")  # the level-table exchange (RCCL when world > 1)
+        mlmc_t = mlmc_t.cpu()
     tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -194,7 +226,7 @@ def main():
     qoi_mean = float(packed[1] / packed[0])
 
     if rank == 0:
-        total_units = units_per_step * a.steps * world
+        total_units = units_per_step * a.steps * (1 if a.workload == "quartic_mlmc" else world)
         ms = lambda pairs: sum(p[0].elapsed_time(p[1]) for p in pairs)
         or_ms = ms(or_events)
         result = {
@@ -239,6 +271,23 @@ def main():
                                       "algorithmic_GBps": 16.0 * sites * B * a.n_heatbath * a.steps / (hb_ms * 1e-3) / 1e9,
                                       "note": "fp64 VALU bound (Philox + von Mises rejection sampler), not HBM bound "
                                               "(SURVEY F9); ~70 % VALU-active in the PMC profile"}
+        elif a.workload == "quartic_mlmc":
+            result["scaling"] = "strong"
+            result["config"] = {"workload": f"quartic MLMC, 5 levels, finest M_lat={size}, a=0.125, nt={a.nt}, one Y sample per "
+                                            "chain and level per step (2 sampler trajectories + two-level step)",
+                                "chains_per_level": B, "levels_on_rank0": sorted(est.levels),
+                                "parallelism": f"level l on rank l % {world}; per pass one all-reduce of the [5, 5] level table"}
+            result["mlmc"] = {"estimate": mlmc_q, "error": mlmc_e, "level_means": mlmc_t[:, 1].tolist(),
+                              "level_variances": mlmc_t[:, 2].tolist(),
+                              "acceptance_rank0": {str(k): v for k, v in est.p_accept().items()}}
+            launch_ms = or_ms / a.steps
+            alg = bytes_per_unit * units_per_step / world
+            achieved = alg / (launch_ms * 1e-3) / 1e9
+            result["roofline"] = {"kernel": "hmc_trajectory_kernel (the level samplers; > 99 % of the site-steps)", "bound": "hbm",
+                                  "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                                  "traffic": None, "launch_ms": launch_ms, "algorithmic_bytes_per_launch": alg,
+                                  "note": "one step of all level instances of rank 0; states and momenta stay in "
+                                          "registers for a whole trajectory, so frac may exceed 1"}
         else:
             launch_ms = or_ms / a.steps
             alg = bytes_per_unit * units_per_step

@@ -1,0 +1,107 @@
+"""Batched, level-sharded multilevel Monte Carlo over device chains (1-D actions).
+
+The telescoping estimator of montecarlo/montecarlomultilevel.cc:71-204 with B independent chains per level:
+    Q = sum_l E[Y_l],   Y_{L-1} = Q_{L-1}(x)                    (coarsest level: HMCSampler)
+                        Y_l     = Q_l(theta) - Q_{l+1}(x_c)      (TwoLevelMetropolisStep fed by the sampler of level l+1)
+Level l lives on rank l % world (chains.level_owner); per pass the ranks exchange the [n_level, 5] table of
+chains.py.  Everything that computes runs through the C ABI (ops.PathHMC, ops.PathTwoLevelStep, mlmcpi_qoi_*,
+mlmcpi_stats_accumulate); this module is the host loop only -- the Python twin of MonteCarloMultiLevel in
+include/mlmcpi/multilevel.hh, for tests and bench.py.
+"""
+import math
+
+import torch
+
+from . import abi, chains, ops
+
+
+class PathLevel:
+    """One level instance: the sampler of level l+1 (or of the coarsest level) and the two-level step, B chains."""
+
+    def __init__(self, acts, level, B, nt, dts, seed, chain0=0, n_sub=2, qoi=None):
+        self.level, self.B, self.n_sub = level, B, n_sub
+        self.coarsest = level == len(acts) - 1
+        self.qoi = qoi or ops.qoi_xsquared
+        src = level if self.coarsest else level + 1           # level whose sampler feeds this estimator
+        self.act_src = acts[src]
+        # montecarlomultilevel.cc:27-45: every level owns its sampler; distinct Philox keys per level instance
+        self.hmc = ops.PathHMC(acts[src], B, nt, dts[src], seed=seed + 7919 * (level + 1), chain0=chain0)
+        self.x = ops.path_initialise(acts[src], B, seed + 7919 * (level + 1), chain0)
+        self.step = None if self.coarsest else ops.PathTwoLevelStep(acts[level], acts[level + 1], B,
+                                                                     seed=seed + 104729 * (level + 1), chain0=chain0)
+        self.acc = torch.zeros((B, chains.N_MOMENTS), dtype=torch.float64, device=self.x.device)
+        self.site_steps = 0   # leapfrog site-steps + two-level site passes issued (bench accounting)
+        self.n_draws = 0
+        self.step_accepted = torch.zeros(B, dtype=torch.int64, device=self.x.device)
+
+    def thermalise(self, n):
+        """Untimed burn-in (ops.hmc_thermalise), then two-level steps until theta (which starts at zero) has been
+        replaced by an accepted proposal on every chain with near certainty (64 draws: 1e-4 at 13 % acceptance)."""
+        ops.hmc_thermalise(self.hmc, self.x, n)
+        if self.step is not None:
+            for _ in range(64):
+                self.hmc.draw(self.x, count_stats=False)
+                self.step.draw(self.x)
+
+    def sample(self):
+        """One Y sample per chain (montecarlomultilevel.cc:118-146, fixed sub-sampling of the coarse chain)."""
+        for _ in range(self.n_sub):
+            self.hmc.draw(self.x)
+        self.site_steps += self.n_sub * (self.hmc.nt + 1) * self.act_src.M * self.B
+        if self.coarsest:
+            y = self.qoi(self.x)
+        else:
+            self.step_accepted += self.step.draw(self.x)
+            self.site_steps += self.step.fine.M * self.B
+            y = self.qoi(self.step.theta) - self.qoi(self.x)
+        ops.stats_accumulate(self.acc, y)
+        self.n_draws += 1
+        return y
+
+    def row(self, cost=None):
+        """(samples, mean, variance, tau_int, cost) of this level; chains are independent, so the error of the
+        mean comes from the scatter of the per-chain means and tau_int is reported as their ratio."""
+        n = self.acc[:, 0]
+        chain_mean = self.acc[:, 1] / n
+        tot = chains.pack_moments(self.acc)
+        s = chains.summarise(tot, chain_means=chain_mean)
+        tau = (s["error"] / s["naive_error"]) ** 2 if s["naive_error"] > 0 else 1.0
+        if cost is None:
+            cost = float(self.site_steps) / max(1, self.n_draws * self.B)   # site-steps per sample
+        return (float(s["samples"]), s["mean"], s["variance"], max(tau, 1e-3), cost)
+
+
+class PathMLMC:
+    def __init__(self, kind, M0, T_final, n_level, B, nt=20, dt0=0.05, seed=1, rank=0, world=1, n_sub=2, params=None):
+        p = dict(m0=1.0, mu2=1.0, lam=0.0, x0=0.0)
+        p.update(params or {})
+        self.acts = [abi.path_action(kind, M0 >> l, T_final, p["m0"], p["mu2"], p["lam"], p["x0"]) for l in range(n_level)]
+        # stable leapfrog step ~ a^(1/2) for the kinetic term and acceptance ~ M dt^4: scale gently with the level
+        self.dts = [dt0 * (2.0 ** (0.25 * l)) for l in range(n_level)]
+        self.n_level, self.rank, self.world = n_level, rank, world
+        self.levels = {l: PathLevel(self.acts, l, B, nt, self.dts, seed, chain0=0, n_sub=n_sub)
+                       for l in chains.owned_levels(n_level, rank, world)}
+
+    def thermalise(self, n):
+        for lv in self.levels.values():
+            lv.thermalise(n)
+
+    def pass_(self, n_samples):
+        for lv in self.levels.values():
+            for _ in range(n_samples):
+                lv.sample()
+
+    def table(self, device="cpu"):
+        t = chains.level_table(self.n_level, {l: lv.row() for l, lv in self.levels.items()}, device=device)
+        return chains.allreduce_level_table(t)
+
+    def estimate(self, device="cpu"):
+        t = self.table(device)
+        q, e = chains.combine_levels(t)
+        return q, e, t
+
+    def p_accept(self):
+        """{level: (HMC acceptance of its sampler, two-level acceptance or None)}"""
+        return {l: (float(lv.hmc.n_accepted.double().mean()) / max(1, lv.hmc.n_total),
+                    None if lv.step is None else float(lv.step_accepted.double().mean()) / max(1, lv.n_draws))
+                for l, lv in self.levels.items()}

@@ -237,3 +237,48 @@ def test_schwinger_hierarchical_chain_samples_fine_distribution(gpu_ops, rt, rx)
     assert n_acc / n > 0.05
     assert abs(mp - rp) < 4 * math.hypot(ep, erp)
     assert abs(mc - rc) < 4 * math.hypot(ec, erc)
+
+
+def test_batched_mlmc_harmonic_oscillator_matches_closed_form(gpu_ops):
+    """Telescoping estimator on device chains (mlmcpathintegral_amd/mlmc.py, the batched twin of MonteCarloMultiLevel):
+    HO, 3 levels M_lat = 128 / 64 / 32, <x^2> against the fine-level closed form."""
+    from mlmcpathintegral_amd import abi, mlmc
+    import oracle
+    est = mlmc.PathMLMC(abi.HARMONIC, 128, 4.0, 3, B=512, nt=50, dt0=0.08, seed=SEED, n_sub=3)
+    est.thermalise(300)
+    est.pass_(300)
+    q, e, table = est.estimate()
+    exact = oracle.lib().orc_ho_xsquared_analytical(128, 4.0, 1.0, 1.0)
+    print(f"HO MLMC <x^2> = {q:.6f} +- {e:.6f} (closed form {exact:.6f}); level means {table[:, 1].tolist()}, "
+          f"variances {table[:, 2].tolist()}; acceptance {est.p_accept()}")
+    assert abs(q - exact) < 4 * e
+    assert table[0, 2] < table[1, 2] < table[2, 2], "variance of Y_l decays towards the fine levels"
+
+
+def test_batched_mlmc_quartic_five_levels_matches_single_level(gpu_ops):
+    """BASELINE config 5 hierarchy (quartic double well, 5 levels, finest M_lat = 32768, coarsest 2048) at a finer
+    lattice spacing (T_final = 1024, a = 1/32 ... 1/2) where the two-level steps accept often enough for a short test:
+    the telescoping sum of the level estimators against a single-level HMC estimate on the finest lattice.  (At the
+    survey's a = 0.125 ... 2 the two-level acceptance of the unrenormalised quartic action drops to a few per cent on
+    the coarse levels -- parity for that shape is test_config5_hierarchy_matches_oracle.)"""
+    from mlmcpathintegral_amd import abi, mlmc
+    par = dict(lam=1.0, x0=1.0)
+    M0, T, B = 32768, 1024.0, 64
+    est = mlmc.PathMLMC(abi.QUARTIC, M0, T, 5, B=B, nt=50, dt0=0.02, seed=SEED, n_sub=2, params=par)
+    est.thermalise(400)
+    est.pass_(200)
+    q, e, table = est.estimate()
+    fine = abi.path_action(abi.QUARTIC, M0, T, 1.0, 1.0, 1.0, 1.0)
+    x = gpu_ops.path_initialise(fine, B, SEED + 5)
+    hmc = gpu_ops.PathHMC(fine, B, 100, 0.02, seed=SEED + 5)   # long trajectories: the slow modes have period ~ 2 pi
+    gpu_ops.hmc_thermalise(hmc, x, 400)
+    vals = []
+    for k in range(300):
+        hmc.draw(x)
+        vals.append(gpu_ops.qoi_xsquared(x))
+    m, em = chain_mean_and_error(torch.stack(vals))
+    p_fine = float(hmc.n_accepted.double().mean()) / hmc.n_total
+    print(f"quartic 5-level MLMC <x^2> = {q:.6f} +- {e:.6f}; single-level fine HMC {m:.6f} +- {em:.6f} (p_accept {p_fine:.2f}); "
+          f"level means {table[:, 1].tolist()}; acceptance {est.p_accept()}")
+    assert p_fine > 0.3
+    assert abs(q - m) < 4 * math.hypot(e, em)
