@@ -376,38 +376,56 @@ __global__ void __launch_bounds__(NT)
     RngKey skey = key;
     skey.step += s;
     for (uint32_t colour = 0; colour < 2; ++colour) {
-      for_region<NT>(bh - 2, (bw - 2) / 2, [&](uint32_t ri, uint32_t ci) {
-        const uint32_t r = 1 + ri;
-        const uint32_t c = 1 + ((r + 1 + colour) & 1u) + 2 * ci;
-        const uint32_t o = r * bw + c;
+      // One Philox call + one Box-Muller per vertex PAIR (l >> 1): the two vertices of a pair are horizontal
+      // neighbours (c, c ^ 1), hence of opposite colour.  The colour-0 phase draws the pair and parks the
+      // partner's normal in LDS; the colour-1 phase picks it up.  Only colour-1 cells whose partner sits in an
+      // outermost buffer column (never updated, so nothing was parked) draw the pair themselves: exactly one
+      // cell per row (column 1 or bw - 2).  They get a pass of their own, so that the waves of the main
+      // colour-1 pass never execute the Philox + Box-Muller code (one boundary lane would drag its whole wave
+      // through it).
+      auto stencil = [&](uint32_t o) {
         double Delta = 0.0;
         Delta += phi[o + 1];
         Delta += phi[o - 1];
         Delta += phi[o + bw];
         Delta += phi[o - bw];
-        double v;
-        if (heat) {
-          // One Philox call + one Box-Muller per vertex PAIR (l >> 1): the two vertices of a pair are
-          // horizontal neighbours (c, c ^ 1), hence of opposite colour.  The colour-0 phase draws the pair
-          // and parks the partner's normal in LDS; the colour-1 phase picks it up.  Only partners in the
-          // outermost buffer columns (never updated in the first phase) draw the pair themselves.
-          const uint32_t ell = wrap_add(sr, r, Mx) * Mt + wrap_add(sc, c, Mt);
-          const uint32_t cpart = c ^ 1u;
-          double mine;
-          if (colour == 0 || cpart == 0 || cpart == bw - 1) {
-            double n0, n1;
-            rng_normals(skey, ell >> 1, P_GFF_NORMAL, 0, n0, n1);
-            mine = (ell & 1u) ? n1 : n0;
-            if (colour == 0) nrm[r * bw + cpart] = (ell & 1u) ? n0 : n1;
-          } else {
-            mine = nrm[o];
-          }
-          v = fma(Delta, inv_kappa, sigma * mine);
-        } else {
-          v = fma(two_over_kappa, Delta, -phi[o]);  // 2 Delta / kappa - phi without the fp64 division
-        }
-        phi[o] = v;
-      });
+        return Delta;
+      };
+      auto draw_pair = [&](uint32_t r, uint32_t c, bool park) {  // returns this cell's normal
+        const uint32_t ell = wrap_add(sr, r, Mx) * Mt + wrap_add(sc, c, Mt);
+        double n0, n1;
+        rng_normals(skey, ell >> 1, P_GFF_NORMAL, 0, n0, n1);
+        if (park) nrm[r * bw + (c ^ 1u)] = (ell & 1u) ? n0 : n1;
+        return (ell & 1u) ? n1 : n0;
+      };
+      if (!heat) {
+        for_region<NT>(bh - 2, (bw - 2) / 2, [&](uint32_t ri, uint32_t ci) {
+          const uint32_t r = 1 + ri;
+          const uint32_t o = r * bw + 1 + ((r + 1 + colour) & 1u) + 2 * ci;
+          phi[o] = fma(two_over_kappa, stencil(o), -phi[o]);  // 2 Delta / kappa - phi without the fp64 division
+        });
+      } else if (colour == 0) {
+        for_region<NT>(bh - 2, (bw - 2) / 2, [&](uint32_t ri, uint32_t ci) {
+          const uint32_t r = 1 + ri;
+          const uint32_t c = 1 + ((r + 1) & 1u) + 2 * ci;
+          const uint32_t o = r * bw + c;
+          phi[o] = fma(stencil(o), inv_kappa, sigma * draw_pair(r, c, true));
+        });
+      } else {
+        for_region<NT>(bh - 2, (bw - 2) / 2, [&](uint32_t ri, uint32_t ci) {
+          const uint32_t r = 1 + ri;
+          const uint32_t c = 1 + (r & 1u) + 2 * ci;
+          if (c == 1 || c == bw - 2) return;  // boundary partners: next pass
+          const uint32_t o = r * bw + c;
+          phi[o] = fma(stencil(o), inv_kappa, sigma * nrm[o]);
+        });
+        for_region<NT>(bh - 2, 1, [&](uint32_t ri, uint32_t) {
+          const uint32_t r = 1 + ri;
+          const uint32_t c = (r & 1u) ? bw - 2 : 1;  // the colour-1 cell of this row next to an outermost column
+          const uint32_t o = r * bw + c;
+          phi[o] = fma(stencil(o), inv_kappa, sigma * draw_pair(r, c, false));
+        });
+      }
       __syncthreads();
     }
   }
