@@ -9,6 +9,7 @@
 // RNG makes those recomputations bit-identical.  Per sweep HBM sees ~(1 + halo overhead) reads and
 // one write of every entry -- instead of the 4-5 passes of one-kernel-per-colour -- and k fused
 // sweeps divide that by k.
+#include <mutex>
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -1481,6 +1482,8 @@ extern "C" {
 static BesselFill make_bessel_fill(double beta) {
   static BesselFill cached;
   static bool have = false;
+  static std::mutex guard;
+  std::lock_guard<std::mutex> lock(guard);
   if (have && cached.beta == beta) return cached;
   BesselFill P;
   P.beta = beta;
