@@ -270,7 +270,17 @@ def main():
                                       "share_of_step": hb_ms / a.steps / (1e3 * elapsed / a.steps),
                                       "algorithmic_GBps": 16.0 * sites * B * a.n_heatbath * a.steps / (hb_ms * 1e-3) / 1e9,
                                       "note": "fp64 VALU bound (Philox + von Mises rejection sampler), not HBM bound "
-                                              "(SURVEY F9); ~70 % VALU-active in the PMC profile"}
+                                              "(SURVEY F9)"}
+                insts = load_valu(a, B)
+                if insts:
+                    # vector-ALU issue roofline: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz lane-operations/s; every
+                    # fp64 / int32 VALU instruction of a wave64 occupies its SIMD for 4 cycles
+                    hb_s = result["heatbath"]["launch_ms"] * 1e-3
+                    peak = 256 * 4 * 16 * 2.4e9
+                    result["heatbath"]["valu"] = {"bound": "valu", "wave_insts_per_launch": insts,
+                                                  "achieved": insts * 64 / hb_s / 1e12, "peak": peak / 1e12,
+                                                  "unit": "T lane-ops/s", "frac": insts * 64 / hb_s / peak,
+                                                  "source": "SQ_INSTS_VALU, profiles/traffic.json"}
         elif a.workload == "quartic_mlmc":
             result["scaling"] = "strong"
             result["config"] = {"workload": f"quartic MLMC, 5 levels, finest M_lat={size}, a=0.125, nt={a.nt}, one Y sample per "
@@ -310,6 +320,18 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def load_valu(a, B):
+    """VALU wave-instructions per heat-bath launch from the committed SQ counter profile (scaled with the chains)."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        for e in t.get("valu", []):
+            if (e["workload"], e["size"]) == (a.workload, a.size or 1024):
+                return e["SQ_INSTS_VALU_per_launch"] * B / e["chains"]
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
 
 
 def load_traffic(a, B, fuse):
