@@ -81,10 +81,19 @@ def main():
 
     abi.load()  # no CPU fallback: raises when the HIP extension is missing
     assert torch.cuda.is_available(), "bench.py needs a GPU"
+    # MLMCPI_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks (ranks then share
+    # devices and the collectives go through host memory); the driver's runs use RCCL ("nccl"), one GPU per rank.
+    backend = os.environ.get("MLMCPI_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
+    coll_device = "cuda" if backend == "nccl" else "cpu"
     chain0 = rank * B  # global chain indices of this rank: [chain0, chain0 + B)
 
     ev = lambda: torch.cuda.Event(enable_timing=True)
@@ -215,11 +224,11 @@ def main():
     # the one collective: packed per-chain moments of a QoI, summed over ranks (RCCL)
     acc = torch.zeros((B, chains.N_MOMENTS), dtype=torch.float64, device="cuda")
     ops.stats_accumulate(acc, qoi())
-    packed = chains.allreduce_moments(chains.pack_moments(acc))
+    packed = chains.allreduce_moments(chains.pack_moments(acc).to(coll_device))
     if a.workload == "quartic_mlmc":
-        mlmc_q, mlmc_e, mlmc_t = est.estimate(device="cuda")  # the level-table exchange (RCCL when world > 1)
+        mlmc_q, mlmc_e, mlmc_t = est.estimate(device=coll_device)  # the level-table exchange (RCCL when world > 1)
         mlmc_t = mlmc_t.cpu()
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
