@@ -39,6 +39,9 @@ def parse():
     ap.add_argument("--nt", type=int, default=100)
     ap.add_argument("--dt", type=float, default=0.0, help="HMC step size (default: 0.05 rotor, 0.02 quartic)")
     ap.add_argument("--seed", type=int, default=2481317)
+    ap.add_argument("--thermalise", type=int, default=30,
+                    help="untimed sampler draws before the warm-up (sweep workloads): the timed steps run on a "
+                         "thermalised state -- heat-bath rejection rates depend on it -- and at steady clocks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-draws", type=int, default=0)
     return ap.parse_args()
@@ -206,6 +209,9 @@ def main():
             return ops.qoi_susceptibility(x, T_final) if kind == abi.ROTOR else ops.qoi_xsquared(x)
         bytes_per_unit = 32.0  # x, p read and written once per leapfrog step
 
+    if a.workload in ("schwinger", "gff"):
+        for _ in range(a.thermalise):
+            step(False)
     for _ in range(a.warmup):
         step(False)
     torch.cuda.synchronize()
