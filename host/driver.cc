@@ -1,0 +1,126 @@
+// driver.cc -- counterpart of the reference's drivers (driver_qm.cc:98-429, driver_qft.cc:100-459) on device
+// chains: builds lattice, action, QoI factory and sampler factory, runs MonteCarloSingleLevel::evaluate
+// (method singlelevel) or MonteCarloMultiLevel::evaluate (method multilevel) and prints the statistics and, where
+// the reference has one, the analytic value.  Parameters come from the command line (the reference's
+// parameter-file parser is plumbing outside the hot path).
+//   driver --action harmonicoscillator --M_lat 128 --T_final 4 --sampler hmc --n_samples 100000
+//   driver --action schwinger --Mt_lat 16 --beta 1 --sampler heatbath --n_samples 20000
+//   driver --method multilevel --action quarticoscillator --M_lat 256 --T_final 8 --sampler hierarchical --n_level 3 --epsilon 0.02
+//   driver --method multilevel --action schwinger --Mt_lat 16 --beta 2 --coarsening both --coarsesampler heatbath
+//          --sampler hierarchical --n_level 2 --epsilon 0.005
+#include <cstring>
+#include <map>
+
+#include "mlmcpi/multilevel.hh"
+
+using namespace mlmcpi;
+
+int main(int argc, char **argv) {
+  std::map<std::string, std::string> o = {{"action", "harmonicoscillator"}, {"M_lat", "128"}, {"T_final", "4.0"},
+      {"Mt_lat", "16"}, {"m0", "1.0"}, {"mu2", "1.0"}, {"lambda", "1.0"}, {"x0", "1.0"}, {"beta", "1.0"}, {"mass", "10.0"},
+      {"sampler", "hmc"}, {"nt", "100"}, {"dt", "0.1"}, {"n_burnin", "100"}, {"n_samples", "20000"}, {"n_sweep_overrelax", "10"},
+      {"n_sweep_heatbath", "1"}, {"autotune", "1"}, {"window", "20"}, {"method", "singlelevel"}, {"n_level", "3"},
+      {"epsilon", "0.01"}, {"coarsening", "both"}, {"coarsesampler", "hmc"}, {"renormalisation", "none"}, {"n_meas", "200"}};
+  for (int i = 1; i + 1 < argc; i += 2) {
+    if (std::strncmp(argv[i], "--", 2) || !o.count(argv[i] + 2)) fatal(std::string("unknown option ") + argv[i]);
+    o[argv[i] + 2] = argv[i + 1];
+  }
+  auto num = [&](const char *k) { return std::stod(o[k]); };
+  std::shared_ptr<Action> action;
+  std::shared_ptr<QoI> qoi;
+  std::shared_ptr<QoIFactory> qoi_factory;
+  std::shared_ptr<ConditionedFineActionFactory> cfa_factory;
+  double analytic = NAN;
+  const std::string a = o["action"];
+  const RenormalisationType renorm = o["renormalisation"] == "perturbative" ? RenormalisationPerturbative
+                                     : o["renormalisation"] == "exact"      ? RenormalisationNonperturbative
+                                                                            : RenormalisationNone;
+  const std::map<std::string, CoarseningType> coarsenings = {{"both", CoarsenBoth}, {"temporal", CoarsenTemporal},
+      {"spatial", CoarsenSpatial}, {"alternate", CoarsenAlternate}, {"rotate", CoarsenRotate}};
+  if (!coarsenings.count(o["coarsening"])) fatal("unknown coarsening " + o["coarsening"]);
+  if (a == "harmonicoscillator" || a == "quarticoscillator" || a == "rotor") {
+    auto lat = std::make_shared<Lattice1D>((unsigned)num("M_lat"), num("T_final"));
+    if (a == "harmonicoscillator") {
+      auto act = std::make_shared<HarmonicOscillatorAction>(lat, renorm, num("m0"), num("mu2"));
+      analytic = act->Xsquared_analytical();
+      action = act;
+      qoi = std::make_shared<QoIXsquared>(lat);
+      qoi_factory = std::make_shared<QoIXsquaredFactory>();
+      cfa_factory = std::make_shared<GaussianConditionedFineActionFactory>();
+    } else if (a == "quarticoscillator") {
+      action = std::make_shared<QuarticOscillatorAction>(lat, renorm, num("m0"), num("mu2"), num("lambda"), num("x0"));
+      qoi = std::make_shared<QoIXsquared>(lat);
+      qoi_factory = std::make_shared<QoIXsquaredFactory>();
+      cfa_factory = std::make_shared<GaussianConditionedFineActionFactory>();
+    } else {
+      action = std::make_shared<RotorAction>(lat, renorm, num("m0"));
+      qoi = std::make_shared<QoISusceptibility>(lat);
+      qoi_factory = std::make_shared<QoISusceptibilityFactory>();
+      cfa_factory = std::make_shared<RotorConditionedFineActionFactory>();
+    }
+  } else if (a == "schwinger" || a == "gff") {
+    auto lat = std::make_shared<Lattice2D>((unsigned)num("Mt_lat"), (unsigned)num("Mt_lat"), coarsenings.at(o["coarsening"]));
+    if (a == "schwinger") {
+      action = std::make_shared<QuenchedSchwingerAction>(lat, nullptr, renorm, num("beta"));
+      qoi = std::make_shared<QoIAvgPlaquette>(lat);
+      qoi_factory = std::make_shared<QoIAvgPlaquetteFactory>();
+      cfa_factory = std::make_shared<QuenchedSchwingerConditionedFineActionFactory>();
+    } else {
+      action = std::make_shared<GFFAction>(lat, nullptr, num("mass"));
+      qoi = std::make_shared<QoI2DPhiSquared>(lat);
+    }
+  } else {
+    fatal("unknown action " + a);
+  }
+  std::cout << "Action: " << action->info_string() << std::endl;
+  auto basic_factory = [&](const std::string &name) -> std::shared_ptr<SamplerFactory> {
+    if (name == "hmc") {
+      HMCParameters hp;
+      hp.nt = (unsigned)num("nt"); hp.dt = num("dt"); hp.n_burnin = (unsigned)num("n_burnin"); hp.autotune = num("autotune") != 0;
+      return std::make_shared<HMCSamplerFactory>(hp);
+    }
+    if (name != "heatbath") fatal("unknown sampler " + name);
+    OverrelaxedHeatBathParameters hb;
+    hb.n_sweep_overrelax = (unsigned)num("n_sweep_overrelax"); hb.n_sweep_heatbath = (unsigned)num("n_sweep_heatbath");
+    hb.n_burnin = (unsigned)num("n_burnin");
+    return std::make_shared<OverrelaxedHeatBathSamplerFactory>(hb);
+  };
+  std::shared_ptr<SamplerFactory> factory;
+  if (o["sampler"] == "hierarchical") {  // driver_qm.cc:61-75: hierarchical sampler over `coarsesampler`
+    if (!cfa_factory) fatal("no conditioned fine action for action " + a);
+    HierarchicalParameters hier;
+    hier.n_max_level = (unsigned)num("n_level"); hier.n_meas = (unsigned)num("n_meas");
+    factory = std::make_shared<HierarchicalSamplerFactory>(basic_factory(o["coarsesampler"]), cfa_factory, hier);
+  } else {
+    factory = basic_factory(o["sampler"]);
+  }
+  if (o["method"] == "multilevel") {  // driver_qm.cc:340-398
+    if (!cfa_factory || !qoi_factory) fatal("multilevel method is not available for action " + a);
+    MultiLevelMCParameters mlp;
+    mlp.n_level = (unsigned)num("n_level"); mlp.n_burnin = (unsigned)num("n_burnin"); mlp.epsilon = num("epsilon");
+    mlp.n_autocorr_window = (unsigned)num("window"); mlp.n_meas = (unsigned)num("n_meas");
+    MonteCarloMultiLevel mlmc(action, qoi_factory, factory, cfa_factory, mlp);
+    mlmc.evaluate();
+    std::cout << std::endl << "=== Multilevel MC ===" << std::endl;
+    mlmc.show_statistics();
+    if (!std::isnan(analytic))
+      std::cout << std::setprecision(6) << " analytic result = " << analytic << std::endl
+                << " |analytic - numerical| / error = " << std::fabs(analytic - mlmc.numerical_result()) / mlmc.statistical_error()
+                << std::endl;
+    return 0;
+  }
+  if (o["method"] != "singlelevel") fatal("unknown method " + o["method"]);
+  SingleLevelMCParameters mp;
+  mp.n_burnin = (unsigned)num("n_burnin"); mp.n_samples = (unsigned)num("n_samples"); mp.n_autocorr_window = (unsigned)num("window");
+  MonteCarloSingleLevel mc(action, qoi, factory, mp);
+  mc.evaluate();
+  std::cout << std::endl << "=== Single level MC ===" << std::endl;
+  mc.show_statistics();
+  mc.get_sampler()->show_stats();
+  if (!std::isnan(analytic)) {  // driver_qm.cc:411-425
+    auto st = mc.get_statistics();
+    std::cout << std::setprecision(6) << " analytic result = " << analytic << std::endl
+              << " |analytic - numerical| / error = " << std::fabs(analytic - st->average()) / st->error() << std::endl;
+  }
+  return 0;
+}

@@ -50,3 +50,24 @@ def test_host_layer_on_gpu():
     print(r.stdout[-2500:])
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "all checks passed" in r.stdout
+
+
+@pytest.mark.gpu
+def test_driver_multilevel_on_gpu():
+    """host/driver (the counterpart of driver_qm / driver_qft): multilevel method, hierarchical sampler, harmonic
+    oscillator -- the estimate must agree with the closed form the driver prints (driver_qm.cc:411-425)."""
+    import re
+    if not os.path.exists(EXE):
+        build()
+    r = subprocess.run([os.path.join(ROOT, "host", "driver"), "--method", "multilevel", "--action", "harmonicoscillator",
+                        "--M_lat", "64", "--T_final", "4", "--sampler", "hierarchical", "--n_level", "3", "--epsilon", "0.03",
+                        "--nt", "20", "--dt", "0.15", "--n_meas", "50"], capture_output=True, text=True, timeout=600)
+    print(r.stdout[-1500:])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    m = re.search(r"\|analytic - numerical\| / error = ([0-9.eE+-]+)", r.stdout)
+    assert m and float(m.group(1)) < 5.0
+
+
+def test_driver_rejects_unknown_options():
+    r = subprocess.run([os.path.join(ROOT, "host", "driver"), "--no_such_option", "1"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "unknown option" in r.stderr
