@@ -6,6 +6,7 @@
 //   driver --action harmonicoscillator --M_lat 128 --T_final 4 --sampler hmc --n_samples 100000
 //   driver --action schwinger --Mt_lat 16 --beta 1 --sampler heatbath --n_samples 20000
 //   driver --method multilevel --action quarticoscillator --M_lat 256 --T_final 8 --sampler hierarchical --n_level 3 --epsilon 0.02
+//   driver --method twolevel --action quarticoscillator --M_lat 256 --T_final 8 --coarsesampler hmc --n_samples 5000
 //   driver --method multilevel --action schwinger --Mt_lat 16 --beta 2 --coarsening both --coarsesampler heatbath
 //          --sampler hierarchical --n_level 2 --epsilon 0.005
 #include <cstring>
@@ -107,6 +108,17 @@ int main(int argc, char **argv) {
       std::cout << std::setprecision(6) << " analytic result = " << analytic << std::endl
                 << " |analytic - numerical| / error = " << std::fabs(analytic - mlmc.numerical_result()) / mlmc.statistical_error()
                 << std::endl;
+    return 0;
+  }
+  if (o["method"] == "twolevel") {  // driver_qm.cc:313-338
+    if (!cfa_factory || !qoi_factory) fatal("twolevel method is not available for action " + a);
+    TwoLevelMCParameters tp;
+    tp.n_burnin = (unsigned)num("n_burnin"); tp.n_samples = (unsigned)num("n_samples"); tp.n_meas = (unsigned)num("n_meas");
+    tp.n_autocorr_window = (unsigned)num("window");
+    MonteCarloTwoLevel two(action, qoi_factory, basic_factory(o["coarsesampler"]), cfa_factory, tp);
+    two.evaluate_difference();
+    std::cout << std::endl << "=== Two level MC ===" << std::endl;
+    two.show_statistics();
     return 0;
   }
   if (o["method"] != "singlelevel") fatal("unknown method " + o["method"]);

@@ -197,6 +197,18 @@ int main(int argc, char **argv) {
     std::printf(" MLMC <x^2> = %.6f +- %.6f (analytic %.6f)\n", mlmc.numerical_result(), mlmc.statistical_error(), exact);
     EXPECT(std::fabs(mlmc.numerical_result() - exact) < 5 * mlmc.statistical_error(), "MLMC estimate");
     EXPECT(mlmc.level_statistics(0)->variance() < mlmc.level_statistics(2)->variance(), "variance decays towards fine levels");
+    {  // montecarlo/montecarlotwolevel.cc: variance of the fine / coarse QoI and of their difference
+      TwoLevelMCParameters tp;
+      tp.n_burnin = 200; tp.n_samples = 3000; tp.n_meas = 50;
+      MonteCarloTwoLevel two(act, std::make_shared<QoIXsquaredFactory>(), std::make_shared<HMCSamplerFactory>(hp), cfa, tp);
+      two.evaluate_difference();
+      const Statistics &f = two.fine_statistics(), &c = two.coarse_statistics(), &d = two.difference_statistics();
+      std::printf(" two-level MC: Q_fine %.4f (var %.4f), Q_coarse %.4f (var %.4f), difference %.5f (var %.5f)\n", f.average(),
+                  f.variance(), c.average(), c.variance(), d.average(), d.variance());
+      EXPECT(std::fabs(f.average() - exact) < 5 * f.error(), "two-level MC fine average");
+      EXPECT(d.variance() < 0.1 * f.variance(), "two-level MC: the difference has a much smaller variance");
+      EXPECT(std::fabs(d.average() - (f.average() - c.average())) < 1e-12, "two-level MC: difference of averages");
+    }
     // level sharding: two ranks in lockstep, rank r owns the levels l with l % 2 == r; what they
     // exchange per pass is the 3 x 5 table, summed element-wise (the all-reduce of a real two-process run)
     MultiLevelMCParameters p0 = mlp, p1 = mlp;

@@ -6,6 +6,7 @@
 //   QuenchedSchwingerSemiConditionedFineAction (+ factory)  action/qft/quenchedschwingerconditionedfineaction.{hh,cc}
 //   TwoLevelMetropolisStep           montecarlo/twolevelmetropolisstep.{hh,cc}
 //   HierarchicalSampler              sampler/hierarchicalsampler.{hh,cc}
+//   MonteCarloTwoLevel               montecarlo/montecarlotwolevel.{hh,cc}
 //   MonteCarloMultiLevel             montecarlo/montecarlomultilevel.{hh,cc}
 // The two-level step (copy_from_coarse, Gaussian fill-in, three action differences, Metropolis test,
 // copy of accepted states) is one ABI call, mlmcpi_path_twolevel_draw.
@@ -332,6 +333,86 @@ private:
   std::vector<double> t_indep;
   std::vector<unsigned int> n_indep, t_sampler;
   double cost_per_sample_;
+};
+
+/** montecarlo/montecarlotwolevel.hh: parameters */
+struct TwoLevelMCParameters {
+  unsigned int n_burnin = 100, n_samples = 100;
+  unsigned int n_coarse_autocorr_window = 10, n_fine_autocorr_window = 10, n_delta_autocorr_window = 10;
+  unsigned int n_autocorr_window = 20;  // statistics of the coarse sampler (StatisticsParameters)
+  unsigned int n_meas = 200;            // draws timed for the two-level step's cost_per_sample
+};
+
+/** montecarlo/montecarlotwolevel.{hh,cc}: mean and variance of Q_fine, Q_coarse and of their difference over the
+ *  pairs (phi_coarse, phi_fine) a two-level step produces from (nearly) independent coarse samples. */
+class MonteCarloTwoLevel {
+public:
+  MonteCarloTwoLevel(const std::shared_ptr<Action> fine_action_, const std::shared_ptr<QoIFactory> qoi_factory,
+                     const std::shared_ptr<SamplerFactory> sampler_factory, const std::shared_ptr<ConditionedFineActionFactory> cfa_factory,
+                     const TwoLevelMCParameters p)
+      : param(p), fine_action(fine_action_), coarse_action(fine_action_->coarse_action()), qoi_fine(qoi_factory->get(fine_action_)),
+        qoi_coarse(qoi_factory->get(coarse_action)), stats_fine("QoI[fine]", p.n_fine_autocorr_window),
+        stats_coarse("QoI[coarse]", p.n_coarse_autocorr_window), stats_diff("delta QoI", p.n_delta_autocorr_window),
+        stats_coarse_sampler("QoI[coarsesampler]", p.n_autocorr_window) {
+    coarse_action->set_seed(fine_action->get_seed() + 7919, fine_action->get_chain0());
+    coarse_sampler = sampler_factory->get(coarse_action);
+    twolevel_step = std::make_shared<TwoLevelMetropolisStep>(coarse_action, fine_action, cfa_factory->get(fine_action), 1, p.n_meas);
+  }
+
+  /** montecarlotwolevel.cc:39-84 */
+  void evaluate_difference() {
+    auto phi_state = std::make_shared<SampleState>(fine_action->sample_size());
+    auto phi_coarse_state = std::make_shared<SampleState>(coarse_action->sample_size());
+    stats_coarse.hard_reset(); stats_coarse_sampler.hard_reset(); stats_fine.hard_reset(); stats_diff.hard_reset();
+    for (unsigned int k = 0; k < param.n_burnin; ++k) record_pair(phi_coarse_state, phi_state);
+    stats_coarse_sampler.reset();
+    // a hard reset: the variances are what this estimator is after
+    stats_coarse.hard_reset(); stats_fine.hard_reset(); stats_diff.hard_reset();
+    for (unsigned int k = 0; k < param.n_samples; ++k) record_pair(phi_coarse_state, phi_state);
+  }
+  void show_statistics() const {
+    std::cout << stats_fine << std::endl << stats_coarse << std::endl << stats_diff << std::endl << std::endl;
+    std::cout << "=== Coarse level sampler statistics === " << std::endl << stats_coarse_sampler << std::endl;
+    coarse_sampler->show_stats();
+    std::cout << std::endl << "=== Two level sampler statistics === " << std::endl;
+    twolevel_step->show_stats();
+  }
+  const Statistics &fine_statistics() const { return stats_fine; }
+  const Statistics &coarse_statistics() const { return stats_coarse; }
+  const Statistics &difference_statistics() const { return stats_diff; }
+  std::shared_ptr<TwoLevelMetropolisStep> get_twolevel_step() { return twolevel_step; }
+
+private:
+  void record_pair(std::shared_ptr<SampleState> phi_coarse_state, std::shared_ptr<SampleState> phi_state) {
+    draw_coarse_sample(phi_coarse_state);
+    twolevel_step->draw(phi_coarse_state, phi_state);
+    const double qf = qoi_fine->evaluate(phi_state), qc = qoi_coarse->evaluate(phi_coarse_state);
+    stats_fine.record_sample(qf);
+    stats_coarse.record_sample(qc);
+    stats_diff.record_sample(qf - qc);
+  }
+  /** montecarlotwolevel.cc:87-98: ceil(2 tau_int) <= 100 draws of the coarse sampler between uses */
+  void draw_coarse_sample(std::shared_ptr<SampleState> phi_state) {
+    double two_tau_int = std::fmin(100., std::ceil(2. * stats_coarse_sampler.tau_int()));
+    if (!(two_tau_int >= 1.)) two_tau_int = 1.;  // NaN from a degenerate first window
+    while (t_sampler < two_tau_int) {
+      coarse_sampler->draw(phi_state);
+      stats_coarse_sampler.record_sample(qoi_coarse->evaluate(phi_state));
+      t_sampler++;
+    }
+    t_indep = (n_indep * t_indep + t_sampler) / (1.0 + n_indep);
+    n_indep++;
+    t_sampler = 0;
+  }
+
+  const TwoLevelMCParameters param;
+  std::shared_ptr<Action> fine_action, coarse_action;
+  std::shared_ptr<Sampler> coarse_sampler;
+  std::shared_ptr<QoI> qoi_fine, qoi_coarse;
+  std::shared_ptr<TwoLevelMetropolisStep> twolevel_step;
+  double t_indep = 0.0;
+  int n_indep = 0, t_sampler = 0;
+  Statistics stats_fine, stats_coarse, stats_diff, stats_coarse_sampler;
 };
 
 /** montecarlo/montecarlomultilevel.hh: parameters */
