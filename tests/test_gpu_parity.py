@@ -477,6 +477,9 @@ SWEEP_CASES = [
     ("schwinger", 64, 32, dict(beta=1.0), 2),
     ("schwinger", 128, 64, dict(beta=1.0), 2),  # 2 x 2 tiles of the specialised overrelaxation kernel
     ("schwinger", 130, 70, dict(beta=1.0), 1),
+    ("schwinger", 16, 16, dict(beta=0.0), 2),    # flat conditionals: kappa is clamped, the draw is uniform
+    ("schwinger", 16, 16, dict(beta=40.0), 2),   # sharply peaked conditionals (kappa up to 80)
+    ("gff", 16, 16, dict(mass=0.0), 2),          # massless field: kappa = 4
 ]
 
 
