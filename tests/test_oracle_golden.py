@@ -188,3 +188,13 @@ def test_reference_and_device_order_agree_statistically(orc, kind):
     # sweeps decorrelate quickly at these couplings; inflate the naive error by a safe factor 2
     err = 2.0 * np.sqrt(ref.var() / n + dev.var() / n)
     assert abs(ref.mean() - dev.mean()) < 4 * err, (ref.mean(), dev.mean(), err)
+
+
+def test_golden_vectors_are_the_surveys_numbers():
+    """tests/golden/check_provenance.py: every value of survey_known_answers.json occurs in SURVEY.md section 8(c),
+    where the survey recorded it from the compiled reference."""
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(__file__), "golden", "check_provenance.py")
+    r = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout[-1500:]
