@@ -389,6 +389,69 @@ __device__ __forceinline__ double two_pi_i0_scaled(double z) {
   return 2. * kPi * bessel_i0_scaled(z);
 }
 
+// Heat-bath colour phase as a per-lane work queue.  Each thread owns up to S cells of the region
+// (linear index tid + NT m).  Their conditional parameters are set up first (no divergence), every cell
+// gets its first attempt in straight-line code, then every lane runs further rejection attempts on its
+// lowest PENDING cell and moves on as soon as one is accepted, so a wave iterates
+// max-over-lanes(sum of extra attempts) times instead of sum-over-cells(max-over-lanes attempts); the
+// arccosine and the LDS write-back run once per cell afterwards, again without divergence.  Which random numbers a cell consumes is fixed by
+// (site, attempt), so the result does not depend on this scheduling.
+template <int NT, int S, class Setup, class Commit>
+__device__ __forceinline__ void heatbath_cells(uint32_t total, const RngKey &key, Setup setup, Commit commit) {
+  for (uint32_t b0 = 0; b0 < total; b0 += S * NT) {  // uniform trip count: the vote below needs every lane
+    double kap[S], env[S], cen[S], fv[S];
+    uint32_t site[S], off[S];
+    bool neg[S];
+    int n = 0;
+#pragma unroll
+    for (int m = 0; m < S; ++m) {
+      const uint32_t idx = b0 + m * NT + threadIdx.x;
+      kap[m] = 1.0; env[m] = 1.0; cen[m] = 0.0; fv[m] = 1.0; site[m] = 0; off[m] = 0; neg[m] = false;
+      if (idx < total) {
+        double tau;
+        setup(idx, tau, cen[m], site[m], off[m]);
+        kap[m] = vm_clamp(tau);
+        env[m] = vm_envelope(kap[m]);
+        n = m + 1;
+      }
+    }
+    // First attempt of every cell in straight-line code (about 5 in 6 proposals are accepted at once, and
+    // the S independent chains give the scheduler instruction-level parallelism) ...
+    uint32_t pending = 0;
+#pragma unroll
+    for (int m = 0; m < S; ++m) {
+      if (m < n && !vm_attempt(key, site[m], 0, kap[m], env[m], fv[m], neg[m])) pending |= 1u << m;
+    }
+    // ... then the per-lane queue over the cells still pending: every lane retries its lowest pending
+    // cell and moves on when it is accepted.
+    uint32_t attempt = 1;
+    while (__ballot(pending != 0u) != 0ull) {
+      if (pending != 0u) {
+        const int cur = __ffs(pending) - 1;
+        double k_ = kap[0], r_ = env[0];
+        uint32_t s_ = site[0];
+#pragma unroll
+        for (int m = 1; m < S; ++m)
+          if (cur == m) { k_ = kap[m]; r_ = env[m]; s_ = site[m]; }
+        double f;
+        bool ng;
+        if (vm_attempt(key, s_, attempt, k_, r_, f, ng)) {
+#pragma unroll
+          for (int m = 0; m < S; ++m)
+            if (cur == m) { fv[m] = f; neg[m] = ng; }
+          pending &= pending - 1u;
+          attempt = 1;
+        } else {
+          ++attempt;
+        }
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < S; ++m)
+      if (m < n) commit(off[m], mod_2pi_fast(vm_angle(fv[m], neg[m]) + cen[m]));
+  }
+}
+
 // -log of ExpCosDistribution::evaluate(x, x_p, x_m) (distribution/expcosdistribution.cc:7-21)
 __device__ __forceinline__ double expcos_neg_log_pdf(double beta, double x, double x_p, double x_m) {
   double dx = x_p - x_m, z = x - x_m;

@@ -483,23 +483,31 @@ __global__ void __launch_bounds__(256)
     RngKey skey = key;
     skey.step += s;
     for (uint32_t colour = 0; colour < 2; ++colour) {
-      // buffer parity == global parity (g0 is even because o0, halo and M are)
-      for (uint32_t k = 2 - colour + 2 * threadIdx.x; k + 1 < L; k += 2 * blockDim.x) {
-        // k runs over {2,4,..} for colour 0 and {1,3,..} for colour 1
-        const double xm = buf[k - 1], xp = buf[k + 1];
-        double sm, cm, sp, cp;
-        sincos(xm, &sm, &cm);
-        sincos(xp, &sp, &cp);
-        const double x_min = atan2(sp + sm, cp + cm);
-        double xn;
-        if (heat) {
-          const double sigma = 2. * (sig_scale * fabs(cos(0.5 * (xp - xm))));
-          const uint32_t gsite = (uint32_t)(((uint64_t)g0 + k) % M);
-          xn = mod_2pi_fast(x_min + expsin2_draw(skey, gsite, sigma));
-        } else {
-          xn = mod_2pi_fast(2.0 * x_min - buf[k]);
+      // buffer parity == global parity (g0 is even because o0, halo and M are); sites k = k0, k0 + 2, ... < L - 1
+      // with k0 = 2 for colour 0 and 1 for colour 1.  getWminimum (rotoraction.hh:206-213) in closed form:
+      // atan2(sin x+ + sin x-, cos x+ + cos x-) = (x+ + x-)/2 (+ pi when cos((x+ - x-)/2) < 0), so that
+      //   overrelaxation  mod_2pi(2 x0 - x) = mod_2pi(x+ + x- - x)                 (no transcendental at all)
+      //   heat bath       mod_2pi(x0 + ExpSin2(2 W'')),  kappa = W'' = (2 m0/a) |cos((x+ - x-)/2)|  (one cosine)
+      const uint32_t k0 = 2 - colour;
+      const uint32_t count = (L > k0 + 1) ? (L - 1 - k0 + 1) / 2 : 0;
+      if (!heat) {
+        for (uint32_t idx = threadIdx.x; idx < count; idx += blockDim.x) {
+          const uint32_t k = k0 + 2 * idx;
+          buf[k] = mod_2pi_fast(buf[k - 1] + buf[k + 1] - buf[k]);
         }
-        buf[k] = xn;
+      } else {
+        heatbath_cells<256, 4>(
+            count, skey,
+            [&](uint32_t idx, double &tau, double &centre, uint32_t &site, uint32_t &off) {
+              const uint32_t k = k0 + 2 * idx;
+              const double xm = buf[k - 1], xp = buf[k + 1];
+              const double c = cos(0.5 * (xp - xm));
+              tau = sig_scale * fabs(c);
+              centre = 0.5 * (xp + xm) + (c < 0.0 ? kPi : 0.0);
+              site = (uint32_t)(((uint64_t)g0 + k) % M);
+              off = k;
+            },
+            [&](uint32_t off, double angle) { buf[off] = angle; });
       }
       __syncthreads();
     }

@@ -529,11 +529,34 @@ struct ActionO {
 // Device-order sweeps and HMC trajectory.
 // ---------------------------------------------------------------------------------------------
 // One full sweep: colours in ascending order, every entry updated exactly once.
+// Rotor, device order.  With d = (x+ - x-)/2:  sin x+ + sin x- = 2 sin((x+ + x-)/2) cos d  and
+// cos x+ + cos x- = 2 cos((x+ + x-)/2) cos d,  so getWminimum = atan2(...) (rotoraction.hh:206-213) is the mean angle
+// (x+ + x-)/2, shifted by pi when cos d < 0.  The kernels use that closed form (no atan2, no sincos; better conditioned
+// than the quotient of two cancelling sums when cos d -> 0): overrelaxation mod_2pi(2 x0 - x) = mod_2pi(x+ + x- - x),
+// heat bath mod_2pi(x0 + ExpSin2(2 W'')) with the von Mises concentration kappa = W'' = (2 m0 / a) |cos d|.
+// tests/test_oracle_golden.py checks the two forms against each other.
+void rotor_dev_update(const ActionO &A, double *x, unsigned l, bool heat, const DevRng &rng) {
+  const unsigned M = A.M;
+  const double xm = x[(l + M - 1) % M], xp = x[(l + 1) % M];
+  if (!heat) {
+    x[l] = wrap_2pi(xm + xp - x[l]);
+    return;
+  }
+  const double c = std::cos(0.5 * (xp - xm));
+  const double kappa = 2.0 * A.m0 / A.a * std::fabs(c);
+  const double centre = 0.5 * (xp + xm) + (c < 0.0 ? kPi : 0.0);
+  x[l] = wrap_2pi(centre + dev_vonmises(rng, l, kappa));
+}
+
 void dev_sweep(const ActionO &A, double *x, bool heat, const DevRng &rng) {
   unsigned n = A.size();
   for (int c = 0; c < A.n_colours(); ++c)
     for (unsigned l = 0; l < n; ++l) {
       if (A.colour_of(l) != c) continue;
+      if (A.kind == ROTOR) {
+        rotor_dev_update(A, x, l, heat, rng);
+        continue;
+      }
       if (!heat) {
         A.overrelax(x, l);
       } else {

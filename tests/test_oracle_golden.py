@@ -1,6 +1,7 @@
 """CPU: the oracle restatement against the known answers recorded from the compiled reference
 (SURVEY.md 8(c) -> tests/golden/survey_known_answers.json) and published Philox vectors."""
 import json
+import math
 import os
 
 import numpy as np
@@ -198,3 +199,38 @@ def test_golden_vectors_are_the_surveys_numbers():
     script = os.path.join(os.path.dirname(__file__), "golden", "check_provenance.py")
     r = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout[-1500:]
+
+
+def test_rotor_closed_form_equals_reference_formula(orc):
+    """The device-order rotor update uses getWminimum in closed form (mean angle, shifted by pi when
+    cos((x+ - x-)/2) < 0) instead of atan2(sin x+ + sin x-, cos x+ + cos x-) (rotoraction.hh:206-213): both forms
+    must give the same overrelaxation and heat-bath updates, up to the conditioning of the atan2 form."""
+    L = orc.lib()
+    M, T, m0 = 64, 8.0, 0.25
+    A = orc.Action(orc.ROTOR, M=M, T_final=T, m0=m0)
+    rng = np.random.default_rng(17)
+    wrap = lambda v: v - 2 * np.pi * np.floor((v + np.pi) / (2 * np.pi))
+    for trial in range(20):
+        x = rng.uniform(-np.pi, np.pi, M)
+        # overrelaxation, even sites then odd sites: reference formula site by site vs the device-order sweep
+        ref = x.copy()
+        for colour in (0, 1):
+            for l in range(colour, M, 2):
+                A.overrelaxation_update(ref, l)
+        dev = x.copy()
+        A.dev_sweep(dev, False, 5, 0, trial)
+        d = wrap(dev - ref)
+        cond = 1.0 / np.maximum(1e-6, np.abs(np.cos(0.5 * (np.roll(x, -1) - np.roll(x, 1)))))
+        assert np.all(np.abs(d) < 1e-14 * cond + 1e-13), np.max(np.abs(d))
+        # heat bath: atan2 centre + the same von Mises stream vs the device-order sweep
+        ref = x.copy()
+        a = T / M
+        for colour in (0, 1):
+            for l in range(colour, M, 2):
+                xm, xp = ref[(l - 1) % M], ref[(l + 1) % M]
+                x_min = math.atan2(math.sin(xp) + math.sin(xm), math.cos(xp) + math.cos(xm))
+                sigma = 2.0 * (2.0 * m0 / a) * abs(math.cos(0.5 * (xp - xm)))
+                ref[l] = wrap(x_min + L.orc_dev_expsin2_draw(5, 0, trial, l, sigma))
+        dev = x.copy()
+        A.dev_sweep(dev, True, 5, 0, trial)
+        assert np.max(np.abs(wrap(dev - ref))) < 1e-9
