@@ -30,7 +30,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="schwinger", choices=["schwinger", "gff", "rotor_hmc", "quartic_hmc", "ho_hmc", "quartic_mlmc"])
+    ap.add_argument("--workload", default="schwinger", choices=["schwinger", "gff", "rotor_hmc", "quartic_hmc", "ho_hmc", "quartic_mlmc", "rotor_sweep"])
     ap.add_argument("--size", type=int, default=0, help="lattice extent (default: BASELINE size of the workload)")
     ap.add_argument("--chains", type=int, default=0, help="independent chains per GPU (default per workload)")
     ap.add_argument("--fuse", type=int, default=0, help="sweeps fused per launch (0 = library default)")
@@ -50,8 +50,8 @@ def parse():
 def cpu_baseline(a, size):
     """Reference-order oracle on the host cores; run BEFORE this process touches the GPU."""
     wl = {"schwinger": "schwinger", "gff": "gff", "rotor_hmc": "rotor", "quartic_hmc": "quartic", "ho_hmc": "harmonic",
-          "quartic_mlmc": "quartic"}[a.workload]
-    draws = a.cpu_draws or {"schwinger": 5, "gff": 40, "rotor": 30, "quartic": 200, "harmonic": 100000}[wl]
+          "quartic_mlmc": "quartic", "rotor_sweep": "rotor_sweep"}[a.workload]
+    draws = a.cpu_draws or {"schwinger": 5, "gff": 40, "rotor": 30, "quartic": 200, "harmonic": 100000, "rotor_sweep": 150}[wl]
     dt = a.dt or {"rotor": 0.05, "harmonic": 0.0558}.get(wl, 0.02)
     cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--workload", wl, "--size", str(size),
            "--draws", str(draws), "--n-overrelax", str(a.n_overrelax), "--n-heatbath", str(a.n_heatbath),
@@ -70,9 +70,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     size = a.size or {"schwinger": 1024, "gff": 512, "rotor_hmc": 65536, "quartic_hmc": 32768, "ho_hmc": 128,
-                      "quartic_mlmc": 32768}[a.workload]
+                      "quartic_mlmc": 32768, "rotor_sweep": 65536}[a.workload]
     B = a.chains or {"schwinger": 32, "gff": 1024, "rotor_hmc": 1024, "quartic_hmc": 2048, "ho_hmc": 8192,
-                     "quartic_mlmc": 512}[a.workload]
+                     "quartic_mlmc": 512, "rotor_sweep": 1024}[a.workload]
 
     cpu = None
     if world == 1 and a.gpus == 1 and not a.no_cpu_baseline:
@@ -147,6 +147,28 @@ def main():
                 return ops.qoi_avg_plaquette(state["x"], size, size)
             return ops.qoi_phi_squared(state["x"])
         bytes_per_unit = 16.0  # each entry read once and written once per sweep
+    elif a.workload == "rotor_sweep":
+        # OverrelaxedHeatBathSampler::draw on the rotor action, M_lat = 65536, a = 0.125
+        act = abi.path_action(abi.ROTOR, size, size / 8.0, 0.25)
+        x = ops.path_initialise(act, B, a.seed, chain0)
+        scratch = torch.empty_like(x)
+        units_per_step = size * (a.n_overrelax + a.n_heatbath) * B
+        fuse = 1
+        state = {"sweep": 0}
+
+        def step(record):
+            if record:
+                e0, e1 = ev(), ev()
+                e0.record()
+            ops.path_sweep_draw(act, x, scratch, a.n_overrelax, a.n_heatbath, a.seed, chain0, state["sweep"])
+            state["sweep"] += a.n_overrelax + a.n_heatbath
+            if record:
+                e1.record()
+                or_events.append((e0, e1))
+
+        def qoi():
+            return ops.qoi_susceptibility(x, size / 8.0)
+        bytes_per_unit = 16.0
     elif a.workload == "quartic_mlmc":
         # BASELINE configs[4]: quartic double well, 5 levels, finest M_lat = 32768, a = 0.125;
         # level l on rank l % world, every level instance runs B chains; a step = one Y sample per chain on every
@@ -209,7 +231,7 @@ def main():
             return ops.qoi_susceptibility(x, T_final) if kind == abi.ROTOR else ops.qoi_xsquared(x)
         bytes_per_unit = 32.0  # x, p read and written once per leapfrog step
 
-    if a.workload in ("schwinger", "gff"):
+    if a.workload in ("schwinger", "gff", "rotor_sweep"):
         for _ in range(a.thermalise):
             step(False)
     for _ in range(a.warmup):
@@ -296,6 +318,18 @@ def main():
                                                   "achieved": insts * 64 / hb_s / 1e12, "peak": peak / 1e12,
                                                   "unit": "T lane-ops/s", "frac": insts * 64 / hb_s / peak,
                                                   "source": "SQ_INSTS_VALU, profiles/traffic.json"}
+        elif a.workload == "rotor_sweep":
+            launch_ms = or_ms / a.steps
+            alg = bytes_per_unit * units_per_step
+            achieved = alg / (launch_ms * 1e-3) / 1e9
+            result["config"] = {"workload": f"rotor M_lat={size}, {a.n_overrelax} overrelaxation + {a.n_heatbath} heat-bath "
+                                            "sweeps per step, even/odd order", "chains_per_gpu": B, "chains_total": B * world,
+                                "parallelism": f"chains sharded over {world} GPU(s), no data-path collective"}
+            result["roofline"] = {"kernel": "rotor_sweep_kernel (all sweeps of a step)", "bound": "hbm", "achieved": achieved,
+                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                                  "launch_ms": launch_ms, "algorithmic_bytes_per_launch": alg,
+                                  "note": "the heat-bath sweep is VALU bound (von Mises sampler); overrelaxation sweeps are "
+                                          "fused on LDS-resident segments"}
         elif a.workload == "quartic_mlmc":
             result["scaling"] = "strong"
             result["config"] = {"workload": f"quartic MLMC, 5 levels, finest M_lat={size}, a=0.125, nt={a.nt}, one Y sample per "

@@ -29,6 +29,11 @@ def _worker(args):
         units = size * size * (n_or + n_hb)
         s = L.orc_heatbath_new(A.h, n_hb, n_or, 0, 0)
         draw = lambda x: L.orc_heatbath_draw(s, x)
+    elif workload == "rotor_sweep":
+        A = O.Action(O.ROTOR, M=size, T_final=size / 8.0, m0=0.25)
+        units = size * (n_or + n_hb)
+        s = L.orc_heatbath_new(A.h, n_hb, n_or, 0, 0)
+        draw = lambda x: L.orc_heatbath_draw(s, x)
     else:  # HMC, fixed dt (no auto-tune)
         if workload == "quartic":
             A = O.Action(O.QUARTIC, M=size, T_final=size / 8.0, m0=1.0, mu2=1.0, lam=1.0, x0=1.0)
