@@ -2,7 +2,7 @@
 # Secondary workloads (BASELINE configs 2, 3, 5-finest) -- one JSON line each.
 set -o pipefail
 mkdir -p gpurun_out
-for W in rotor_hmc gff quartic_hmc ho_hmc; do
+for W in rotor_hmc gff quartic_hmc ho_hmc rotor_sweep quartic_mlmc; do
   timeout -k 10 400 python bench.py --workload $W --steps 5 --warmup 1 > gpurun_out/bench_$W.json 2> gpurun_out/bench_$W.err || { echo "$W failed"; tail -5 gpurun_out/bench_$W.err; exit 1; }
   python - <<PY
 import json
