@@ -12,6 +12,16 @@ constexpr double kPi = 3.14159265358979323846;
 constexpr double kTwoPi = 6.28318530717958647692;
 constexpr int kWave = 64;
 
+// p * x + c with the polynomial coefficient c in an SGPR pair (v_fma_f64 v, v, v, s[..]).  The compiler's own choice
+// for fma(p, x, constant) is the two-address v_fmac_f64, which needs the constant copied into the destination VGPR
+// pair first (one or two extra VALU instructions per Horner step); with the coefficient on the scalar side the step is
+// a single VALU instruction and the copies become scalar moves, which issue beside the vector pipe.
+__device__ __forceinline__ double fma_k(double p, double x, double c) {
+  double r;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(p), "v"(x), "s"(c));
+  return r;
+}
+
 // common/auxilliary.hh:42-44, operation for operation (used where the VALUE matters: QoIs)
 __device__ __forceinline__ double mod_2pi(double x) { return x - 2. * kPi * floor(0.5 * (x + kPi) / kPi); }
 
@@ -34,15 +44,15 @@ __device__ __forceinline__ double sin_reduced(double d) {
   r = fma(-n, 1.22464679914735317723e-16, r);                   // pi - high part
   const double r2 = r * r;
   double p = -1.9572941063391261231e-20;                        // -1/21!
-  p = fma(p, r2, 8.2206352466243297170e-18);                    //  1/19!
-  p = fma(p, r2, -2.8114572543455207632e-15);                   // -1/17!
-  p = fma(p, r2, 7.6471637318198164759e-13);                    //  1/15!
-  p = fma(p, r2, -1.6059043836821614599e-10);                   // -1/13!
-  p = fma(p, r2, 2.5052108385441718775e-08);                    //  1/11!
-  p = fma(p, r2, -2.7557319223985890653e-06);                   // -1/9!
-  p = fma(p, r2, 1.9841269841269841270e-04);                    //  1/7!
-  p = fma(p, r2, -8.3333333333333333333e-03);                   // -1/5!
-  p = fma(p, r2, 1.6666666666666666667e-01);                    //  1/3!
+  p = fma_k(p, r2, 8.2206352466243297170e-18);                    //  1/19!
+  p = fma_k(p, r2, -2.8114572543455207632e-15);                   // -1/17!
+  p = fma_k(p, r2, 7.6471637318198164759e-13);                    //  1/15!
+  p = fma_k(p, r2, -1.6059043836821614599e-10);                   // -1/13!
+  p = fma_k(p, r2, 2.5052108385441718775e-08);                    //  1/11!
+  p = fma_k(p, r2, -2.7557319223985890653e-06);                   // -1/9!
+  p = fma_k(p, r2, 1.9841269841269841270e-04);                    //  1/7!
+  p = fma_k(p, r2, -8.3333333333333333333e-03);                   // -1/5!
+  p = fma_k(p, r2, 1.6666666666666666667e-01);                    //  1/3!
   const double sr = fma(-r * r2, p, r);                          // r - r^3 (1/3! - r^2/5! + ...)
   // (-1)^n: n is an integer-valued double; its parity is the low bit of the converted integer
   return ((long long)n & 1) ? -sr : sr;
@@ -86,17 +96,17 @@ __device__ __forceinline__ double fast_acos(double x) {
   const bool small = ax < 0.5;
   const double z = small ? x * x : 0.5 * (1.0 - ax);
   double p = 3.47933107596021167570e-05;
-  p = fma(p, z, 7.91534994289814532176e-04);
-  p = fma(p, z, -4.00555345006794114027e-02);
-  p = fma(p, z, 2.01212532134862925881e-01);
-  p = fma(p, z, -3.25565818622400915405e-01);
-  p = fma(p, z, 1.66666666666666657415e-01);
+  p = fma_k(p, z, 7.91534994289814532176e-04);
+  p = fma_k(p, z, -4.00555345006794114027e-02);
+  p = fma_k(p, z, 2.01212532134862925881e-01);
+  p = fma_k(p, z, -3.25565818622400915405e-01);
+  p = fma_k(p, z, 1.66666666666666657415e-01);
   p *= z;
   double q = 7.70381505559019352791e-02;
-  q = fma(q, z, -6.88283971605453293030e-01);
-  q = fma(q, z, 2.02094576023350569471e+00);
-  q = fma(q, z, -2.40339491173441421878e+00);
-  q = fma(q, z, 1.0);
+  q = fma_k(q, z, -6.88283971605453293030e-01);
+  q = fma_k(q, z, 2.02094576023350569471e+00);
+  q = fma_k(q, z, -2.40339491173441421878e+00);
+  q = fma_k(q, z, 1.0);
   const double R = fast_div(p, q);
   const double pio2_hi = 1.57079632679489655800e+00, pio2_lo = 6.12323399573676603587e-17;
   // |x| < 1/2: pi/2 - (x + x R)
@@ -121,15 +131,15 @@ __device__ __forceinline__ double log_unit(double x) {
   const double s = fast_div(m - 1.0, m + 1.0);
   const double z = s * s;
   double p = 1.0 / 19.0;
-  p = fma(p, z, 1.0 / 17.0);
-  p = fma(p, z, 1.0 / 15.0);
-  p = fma(p, z, 1.0 / 13.0);
-  p = fma(p, z, 1.0 / 11.0);
-  p = fma(p, z, 1.0 / 9.0);
-  p = fma(p, z, 1.0 / 7.0);
-  p = fma(p, z, 1.0 / 5.0);
-  p = fma(p, z, 1.0 / 3.0);
-  p = fma(p, z, 1.0);
+  p = fma_k(p, z, 1.0 / 17.0);
+  p = fma_k(p, z, 1.0 / 15.0);
+  p = fma_k(p, z, 1.0 / 13.0);
+  p = fma_k(p, z, 1.0 / 11.0);
+  p = fma_k(p, z, 1.0 / 9.0);
+  p = fma_k(p, z, 1.0 / 7.0);
+  p = fma_k(p, z, 1.0 / 5.0);
+  p = fma_k(p, z, 1.0 / 3.0);
+  p = fma_k(p, z, 1.0);
   return fma((double)e, 0.69314718055994530942, 2.0 * s * p);
 }
 
@@ -141,21 +151,21 @@ __device__ __forceinline__ void sincos_2pi_unit(double v, double &sn, double &cs
   const double x = (0.5 * kPi) * (a - q);  // |x| <= pi/4
   const double x2 = x * x;
   double sp = -7.6471637318198164759e-13;
-  sp = fma(sp, x2, 1.6059043836821614599e-10);
-  sp = fma(sp, x2, -2.5052108385441718775e-08);
-  sp = fma(sp, x2, 2.7557319223985890653e-06);
-  sp = fma(sp, x2, -1.9841269841269841270e-04);
-  sp = fma(sp, x2, 8.3333333333333333333e-03);
-  sp = fma(sp, x2, -1.6666666666666666667e-01);
+  sp = fma_k(sp, x2, 1.6059043836821614599e-10);
+  sp = fma_k(sp, x2, -2.5052108385441718775e-08);
+  sp = fma_k(sp, x2, 2.7557319223985890653e-06);
+  sp = fma_k(sp, x2, -1.9841269841269841270e-04);
+  sp = fma_k(sp, x2, 8.3333333333333333333e-03);
+  sp = fma_k(sp, x2, -1.6666666666666666667e-01);
   const double s0 = fma(x * x2, sp, x);
   double cp = 4.7794773323873852974e-14;
-  cp = fma(cp, x2, -1.1470745597729724714e-11);
-  cp = fma(cp, x2, 2.0876756987868098979e-09);
-  cp = fma(cp, x2, -2.7557319223985890653e-07);
-  cp = fma(cp, x2, 2.4801587301587301587e-05);
-  cp = fma(cp, x2, -1.3888888888888888889e-03);
-  cp = fma(cp, x2, 4.1666666666666666667e-02);
-  cp = fma(cp, x2, -0.5);
+  cp = fma_k(cp, x2, -1.1470745597729724714e-11);
+  cp = fma_k(cp, x2, 2.0876756987868098979e-09);
+  cp = fma_k(cp, x2, -2.7557319223985890653e-07);
+  cp = fma_k(cp, x2, 2.4801587301587301587e-05);
+  cp = fma_k(cp, x2, -1.3888888888888888889e-03);
+  cp = fma_k(cp, x2, 4.1666666666666666667e-02);
+  cp = fma_k(cp, x2, -0.5);
   const double c0 = fma(cp, x2, 1.0);
   const int k = (int)q & 3;  // rotation by k quarter turns
   const double cr = (k & 1) ? -s0 : c0, sr = (k & 1) ? c0 : s0;
@@ -259,21 +269,21 @@ __device__ __forceinline__ double cospi_unit(double u) {
   const double x = kPi * (outer ? 0.5 - at : t);  // |x| <= pi/4
   const double x2 = x * x;
   double sp = -7.6471637318198164759e-13;                 // -1/15!
-  sp = fma(sp, x2, 1.6059043836821614599e-10);             //  1/13!
-  sp = fma(sp, x2, -2.5052108385441718775e-08);            // -1/11!
-  sp = fma(sp, x2, 2.7557319223985890653e-06);             //  1/9!
-  sp = fma(sp, x2, -1.9841269841269841270e-04);            // -1/7!
-  sp = fma(sp, x2, 8.3333333333333333333e-03);             //  1/5!
-  sp = fma(sp, x2, -1.6666666666666666667e-01);            // -1/3!
+  sp = fma_k(sp, x2, 1.6059043836821614599e-10);             //  1/13!
+  sp = fma_k(sp, x2, -2.5052108385441718775e-08);            // -1/11!
+  sp = fma_k(sp, x2, 2.7557319223985890653e-06);             //  1/9!
+  sp = fma_k(sp, x2, -1.9841269841269841270e-04);            // -1/7!
+  sp = fma_k(sp, x2, 8.3333333333333333333e-03);             //  1/5!
+  sp = fma_k(sp, x2, -1.6666666666666666667e-01);            // -1/3!
   const double sinx = fma(x * x2, sp, x);
   double cp = 4.7794773323873852974e-14;                  //  1/16!
-  cp = fma(cp, x2, -1.1470745597729724714e-11);            // -1/14!
-  cp = fma(cp, x2, 2.0876756987868098979e-09);             //  1/12!
-  cp = fma(cp, x2, -2.7557319223985890653e-07);            // -1/10!
-  cp = fma(cp, x2, 2.4801587301587301587e-05);             //  1/8!
-  cp = fma(cp, x2, -1.3888888888888888889e-03);            // -1/6!
-  cp = fma(cp, x2, 4.1666666666666666667e-02);             //  1/4!
-  cp = fma(cp, x2, -0.5);
+  cp = fma_k(cp, x2, -1.1470745597729724714e-11);            // -1/14!
+  cp = fma_k(cp, x2, 2.0876756987868098979e-09);             //  1/12!
+  cp = fma_k(cp, x2, -2.7557319223985890653e-07);            // -1/10!
+  cp = fma_k(cp, x2, 2.4801587301587301587e-05);             //  1/8!
+  cp = fma_k(cp, x2, -1.3888888888888888889e-03);            // -1/6!
+  cp = fma_k(cp, x2, 4.1666666666666666667e-02);             //  1/4!
+  cp = fma_k(cp, x2, -0.5);
   const double cosx = fma(cp, x2, 1.0);
   return outer ? copysign(cosx, t) : sinx;
 }
