@@ -112,7 +112,7 @@ def main():
         x = ops.lattice_initialise(act, B, a.seed, chain0)
         scratch = torch.empty_like(x)
         units_per_step = sites * (a.n_overrelax + a.n_heatbath) * B
-        fuse = a.fuse or 2  # library default
+        fuse = a.fuse or 4  # library default
         state = {"sweep": 0, "x": x, "scratch": scratch}
 
         def step(record):
@@ -290,7 +290,7 @@ def main():
                 launch_ms = or_ms / (a.steps * n_launch)
                 alg = bytes_per_unit * sites * B * fuse  # algorithmic bytes per launch (fuse sweeps)
                 achieved = alg / (launch_ms * 1e-3) / 1e9
-                special = size % 64 == 0 and fuse <= 4
+                special = size % 64 == 0 and fuse <= (6 if a.workload == "schwinger" else 4)
                 kname = (f"schwinger_or_kernel<64,32,{fuse},512>" if a.workload == "schwinger" and special
                          else f"gff_or_kernel<64,32,{fuse},256>" if special else f"{a.workload}_sweep_kernel<false,256>")
                 result["roofline"] = {"kernel": kname + f" ({fuse} fused overrelaxation sweeps per launch)", "bound": "hbm",

@@ -683,6 +683,11 @@ static int init_sweep_kernels() {
   if (int rc = allow_full_lds<true, 512>()) return rc;
   if (int rc = allow_full_lds<false, 1024>()) return rc;
   if (int rc = allow_full_lds<true, 1024>()) return rc;
+  // specialised overrelaxation kernels whose LDS image exceeds the 64 KiB default (K = 5, 6)
+#define MLMCPI_OR_ATTR(KK, NN) MLMCPI_HIP_TRY(hipFuncSetAttribute((const void *)schwinger_or_kernel<64, 32, KK, NN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
+  MLMCPI_OR_ATTR(5, 256); MLMCPI_OR_ATTR(5, 512); MLMCPI_OR_ATTR(5, 1024);
+  MLMCPI_OR_ATTR(6, 256); MLMCPI_OR_ATTR(6, 512); MLMCPI_OR_ATTR(6, 1024);
+#undef MLMCPI_OR_ATTR
   g_lds_attr_set = true;
   return MLMCPI_OK;
 }
@@ -744,7 +749,7 @@ static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, doub
   MLMCPI_REQUIRE(d_phi && d_scratch && d_phi != d_scratch && B > 0, "bad arguments");
   MLMCPI_REQUIRE(act->Mt % 2 == 0 && act->Mx % 2 == 0, "multicolour sweeps need even Mt, Mx (got %u x %u)", act->Mt,
                  act->Mx);
-  if (fuse == 0) fuse = 2;  // library default: best measured trade-off of halo recomputation vs HBM passes
+  if (fuse == 0) fuse = 4;  // library default: best measured whole-step time (tools/scan_fuse.sh)
   if (fuse > kMaxFuse) fuse = kMaxFuse;
   hipStream_t st = as_stream(stream);
   const bool schw = act->kind == MLMCPI_SCHWINGER;
@@ -754,7 +759,11 @@ static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, doub
   double *src = d_phi, *dst = d_scratch;
   uint32_t s = 0;
   while (s < total) {
-    uint32_t n = total - s < fuse ? total - s : fuse;
+    // Only overrelaxation sweeps are fused: they are bound by the passes over the state, and a fused launch trades
+    // halo recomputation (cheap for them) for passes.  A heat-bath sweep is bound by its sampler arithmetic, which a
+    // wider halo would only multiply, so it always gets a launch of its own (halo 2).
+    uint32_t n = 1;
+    if (s < n_overrelax) n = n_overrelax - s < fuse ? n_overrelax - s : fuse;
     SweepGeom g;
     uint32_t kinds = 0;
     for (;;) {  // shrink the fused count until the tile + halo fits in LDS
@@ -769,7 +778,7 @@ static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, doub
     const RngKey key = make_key(seed, chain0, sweep0 + s);
     dim3 grid(g.tg.tiles_x * g.tiles_y, B);
     int rc;
-    if (schw && !kinds && !g.overridden && act->Mt % 64 == 0 && act->Mx % 32 == 0 && n <= 4) {
+    if (schw && !kinds && !g.overridden && act->Mt % 64 == 0 && act->Mx % 32 == 0 && n <= 6) {
       // specialised overrelaxation kernel (bit-identical to the generic one)
       const size_t lds = (size_t)2 * (32 + 4 * n) * (64 + 4 * n + 1) * sizeof(double);
       dim3 sgrid((act->Mt / 64) * (act->Mx / 32), B);
@@ -785,7 +794,9 @@ static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, doub
         case 1: MLMCPI_OR_K(1); break;
         case 2: MLMCPI_OR_K(2); break;
         case 3: MLMCPI_OR_K(3); break;
-        default: MLMCPI_OR_K(4);
+        case 4: MLMCPI_OR_K(4); break;
+        case 5: MLMCPI_OR_K(5); break;
+        default: MLMCPI_OR_K(6);
       }
 #undef MLMCPI_OR_K
 #undef MLMCPI_OR
