@@ -148,8 +148,10 @@ __global__ void __launch_bounds__(NT, (HEAT && NT == 256) ? 4 : 1)
       } else
       for_region<NT>(nr, bw - 1, [&](uint32_t ri, uint32_t c) {
         const uint32_t r = r_first + 2 * ri, o = r * bw + c;
-        const double tp = mod_2pi_fast(th0[o + bw] + th1[o] - th1[o + 1]);
-        const double tm = mod_2pi_fast(th0[o - bw] + th1[o - bw + 1] - th1[o - bw]);
+        // overrelaxation: mod_2pi(theta+ + theta- - theta); the two staple angles need no wrap of their own here
+        // (2 pi-periodicity of the final map), which drops two of the three mod_2pi per update
+        const double tp = th0[o + bw] + th1[o] - th1[o + 1];
+        const double tm = th0[o - bw] + th1[o - bw + 1] - th1[o - bw];
         th0[o] = mod_2pi_fast((tp + tm) - th0[o]);
       });
       __syncthreads();
@@ -173,8 +175,8 @@ __global__ void __launch_bounds__(NT, (HEAT && NT == 256) ? 4 : 1)
       } else
       for_region<NT>(bh - 1, nc, [&](uint32_t r, uint32_t ci) {
         const uint32_t c = c_first + 2 * ci, o = r * bw + c;
-        const double tp = mod_2pi_fast(th0[o] + th1[o + 1] - th0[o + bw]);
-        const double tm = mod_2pi_fast(th0[o + bw - 1] + th1[o - 1] - th0[o - 1]);
+        const double tp = th0[o] + th1[o + 1] - th0[o + bw];
+        const double tm = th0[o + bw - 1] + th1[o - 1] - th0[o - 1];
         th1[o] = mod_2pi_fast((tp + tm) - th1[o]);
       });
       __syncthreads();
@@ -197,7 +199,8 @@ __global__ void __launch_bounds__(NT, (HEAT && NT == 256) ? 4 : 1)
 //     offsets are computed once and kept in registers (M0 + M1 VGPRs);
 //   * LDS rows are padded to an odd number of doubles and the mu = 1 phases run with lanes along
 //     rows, so column-parity phases are bank-conflict free instead of stride-2.
-// Per update that leaves the ~18 fp64 instructions of the update itself (6 adds, 3 mod_2pi).
+// Per update that leaves the ~10 fp64 instructions of the update itself (6 adds, 1 mod_2pi: the staple angles are
+// not wrapped separately, the final mod_2pi takes care of it).
 template <int TW, int TH, int K, int NT>
 __global__ void __launch_bounds__(NT)
     schwinger_or_kernel(uint32_t Mt, uint32_t Mx, const double2 *__restrict__ in, double2 *__restrict__ out,
@@ -247,8 +250,8 @@ __global__ void __launch_bounds__(NT)
           double t1_c = lds_read_f64<P * 8>(a1), t1_r = lds_read_f64<P * 8 + 8>(a1);
           double t1_dc = lds_read_f64<0>(a1), t1_dr = lds_read_f64<8>(a1);
           lds_wait7(t0_up, t0_dn, t0_own, t1_c, t1_r, t1_dc, t1_dr);
-          const double tp = mod_2pi_fast(t0_up + t1_c - t1_r);
-          const double tm = mod_2pi_fast(t0_dn + t1_dr - t1_dc);
+          const double tp = t0_up + t1_c - t1_r;  // staple angles unwrapped: see the generic kernel
+          const double tm = t0_dn + t1_dr - t1_dc;
           th0[o] = mod_2pi_fast((tp + tm) - t0_own);
         }
       }
@@ -265,8 +268,8 @@ __global__ void __launch_bounds__(NT)
           double t0_lu = lds_read_f64<P * 8>(a0), t0_l = lds_read_f64<0>(a0);
           double t1_r = lds_read_f64<16>(a1), t1_l = lds_read_f64<0>(a1), t1_own = lds_read_f64<8>(a1);
           lds_wait7(t0_c, t0_u, t0_lu, t0_l, t1_r, t1_l, t1_own);
-          const double tp = mod_2pi_fast(t0_c + t1_r - t0_u);
-          const double tm = mod_2pi_fast(t0_lu + t1_l - t0_l);
+          const double tp = t0_c + t1_r - t0_u;
+          const double tm = t0_lu + t1_l - t0_l;
           th1[o] = mod_2pi_fast((tp + tm) - t1_own);
         }
       }
