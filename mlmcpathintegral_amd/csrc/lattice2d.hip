@@ -789,7 +789,7 @@ static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, doub
       double2 *out2 = (double2 *)dst;
       // more fused sweeps -> larger LDS image -> fewer resident workgroups: keep the wave count per CU up
       // with wider workgroups (MLMCPI_OR_THREADS overrides: tuning knob)
-      uint32_t nt_or = 512;  // measured best for K = 1..4 (tools/scan_or.sh)
+      uint32_t nt_or = n >= 4 ? 1024 : 512;  // measured best (tools/scan_or.sh): K <= 3: 512, K >= 4: 1024
       if (const char *e = getenv("MLMCPI_OR_THREADS")) { unsigned v = (unsigned)atoi(e); if (v == 256 || v == 512 || v == 1024) nt_or = v; }
 #define MLMCPI_OR(KK, NN) hipLaunchKernelGGL((schwinger_or_kernel<64, 32, KK, NN>), sgrid, dim3(NN), lds, st, act->Mt, act->Mx, in2, out2, act->Mt / 64)
 #define MLMCPI_OR_K(KK) do { if (nt_or == 1024) MLMCPI_OR(KK, 1024); else if (nt_or == 512) MLMCPI_OR(KK, 512); else MLMCPI_OR(KK, 256); } while (0)
