@@ -11,6 +11,7 @@
 // sweeps divide that by k.
 #include <mutex>
 #include <stdio.h>
+#include <string.h>
 #include <stdlib.h>
 
 #include "internal.hpp"
@@ -282,6 +283,155 @@ __global__ void __launch_bounds__(NT)
     const uint32_t o = (r + H) * P + (c + H);
     dst[(size_t)(j0 + r) * Mt + (i0 + c)] = make_double2(th0[o], th1[o]);
   });
+}
+
+// ---- Schwinger overrelaxation, register-tiled ---------------------------------------------------------------
+// The LDS-resident kernel above reads 7 doubles from LDS and writes 1 per link update (64 B): at 128 B/clk per CU that
+// is the bound it runs into (16 waves x 64 LDS instructions x 4 clk per sweep and tile ~ the measured 0.43 ms per
+// 4-sweep launch), not HBM and not the VALU.  Here every thread keeps a 2 x 2 block of vertices -- 8 link angles -- in
+// registers for all K sweeps; LDS only carries what crosses block boundaries: per sweep a thread reads 16 neighbour
+// values (6, 3, 5, 2 in the four colour phases; values that cannot have changed in between are reused) and publishes
+// its 8 updated links, 24 B per update instead of 64.  The LDS image is eight structure-of-arrays planes
+// [mu][row parity][column parity] over blocks, so that consecutive lanes (consecutive blocks of a row) touch
+// consecutive doubles in every access.  Same updates, same order and the same arithmetic as the kernels above (every
+// link whose six staple links lie inside the buffer is updated), hence bit-identical results.
+// One block per thread: (64 + 4K)/2 x (32 + 4K)/2 <= 1024 blocks for K <= 4.
+template <int K>
+__global__ void __launch_bounds__(1024)
+    schwinger_or_patch_kernel(uint32_t Mt, uint32_t Mx, const double2 *__restrict__ in, double2 *__restrict__ out,
+                              uint32_t tiles_x) {
+  constexpr int TW = 64, TH = 32, H = 2 * K, BW = TW + 2 * H, BH = TH + 2 * H, NPX = BW / 2, NPY = BH / 2;
+  constexpr int NP = NPX * NPY;  // blocks per tile = active threads
+  static_assert(NP <= 1024, "one 2 x 2 block per thread");
+  extern __shared__ double lds[];
+  // plane(mu, c, a)[pj][pi]: link mu of vertex (2 pi + a, 2 pj + c)
+  auto plane = [&](int mu, int c, int a) { return lds + ((mu * 2 + c) * 2 + a) * NP; };
+  const uint32_t tile = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
+  const uint32_t i0 = tx * TW, j0 = ty * TH;
+  const bool active = tid < NP;
+  const int pj = active ? (int)tid / NPX : 0, pi = active ? (int)tid - pj * NPX : 0;
+  const double2 *src = in + (size_t)b * Mt * Mx;
+  // global coordinates of the block's lower-left vertex (even, so (gi, gi + 1) never straddles the wrap)
+  const uint32_t gi = (uint32_t)(((uint64_t)i0 + Mt - (H % Mt) + 2 * pi) % Mt);
+  const uint32_t gj0 = (uint32_t)(((uint64_t)j0 + Mx - (H % Mx) + 2 * pj) % Mx);
+  const uint32_t gj1 = gj0 + 1 == Mx ? 0 : gj0 + 1;
+  double t0[2][2] = {{0, 0}, {0, 0}}, t1[2][2] = {{0, 0}, {0, 0}};  // [c][a]
+  if (active) {
+    const double2 v00 = src[(size_t)gj0 * Mt + gi], v01 = src[(size_t)gj0 * Mt + gi + 1];
+    const double2 v10 = src[(size_t)gj1 * Mt + gi], v11 = src[(size_t)gj1 * Mt + gi + 1];
+    t0[0][0] = v00.x; t1[0][0] = v00.y; t0[0][1] = v01.x; t1[0][1] = v01.y;
+    t0[1][0] = v10.x; t1[1][0] = v10.y; t0[1][1] = v11.x; t1[1][1] = v11.y;
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        plane(0, c, a)[tid] = t0[c][a];
+        plane(1, c, a)[tid] = t1[c][a];
+      }
+  }
+  // neighbour blocks, clamped into the buffer (a clamped read feeds only updates that the validity flags switch off)
+  const int me = (int)tid;
+  const int dn = pj > 0 ? me - NPX : me, up = pj + 1 < NPY ? me + NPX : me;
+  const int lf = pi > 0 ? me - 1 : me, rt = pi + 1 < NPX ? me + 1 : me;
+  const int rtdn = (pi + 1 < NPX ? 1 : 0) + (pj > 0 ? -NPX : 0) + me;
+  const int lfup = (pi > 0 ? -1 : 0) + (pj + 1 < NPY ? NPX : 0) + me;
+  const bool has_dn = active && pj > 0, has_up = active && pj + 1 < NPY, has_lf = active && pi > 0, has_rt = active && pi + 1 < NPX;
+  __syncthreads();
+
+  for (int s = 0; s < K; ++s) {
+    // phase 0: mu = 0, even rows (c = 0)
+    double D0 = 0, D1 = 0, E0 = 0, E1 = 0, R0 = 0, RD = 0;
+    if (active) {
+      D0 = plane(0, 1, 0)[dn]; D1 = plane(0, 1, 1)[dn]; E0 = plane(1, 1, 0)[dn]; E1 = plane(1, 1, 1)[dn];
+      R0 = plane(1, 0, 0)[rt]; RD = plane(1, 1, 0)[rtdn];
+    }
+    if (has_dn) {
+      {  // a = 0
+        const double tp = t0[1][0] + t1[0][0] - t1[0][1];
+        const double tm = D0 + E1 - E0;
+        t0[0][0] = mod_2pi_fast((tp + tm) - t0[0][0]);
+        plane(0, 0, 0)[me] = t0[0][0];
+      }
+      if (has_rt) {  // a = 1
+        const double tp = t0[1][1] + t1[0][1] - R0;
+        const double tm = D1 + RD - E1;
+        t0[0][1] = mod_2pi_fast((tp + tm) - t0[0][1]);
+        plane(0, 0, 1)[me] = t0[0][1];
+      }
+    }
+    __syncthreads();
+    // phase 1: mu = 0, odd rows (c = 1)
+    double U0 = 0, U1 = 0, R1 = 0;
+    if (active) {
+      U0 = plane(0, 0, 0)[up]; U1 = plane(0, 0, 1)[up]; R1 = plane(1, 1, 0)[rt];
+    }
+    if (has_up) {
+      {
+        const double tp = U0 + t1[1][0] - t1[1][1];
+        const double tm = t0[0][0] + t1[0][1] - t1[0][0];
+        t0[1][0] = mod_2pi_fast((tp + tm) - t0[1][0]);
+        plane(0, 1, 0)[me] = t0[1][0];
+      }
+      if (has_rt) {
+        const double tp = U1 + t1[1][1] - R1;
+        const double tm = t0[0][1] + R0 - t1[0][1];
+        t0[1][1] = mod_2pi_fast((tp + tm) - t0[1][1]);
+        plane(0, 1, 1)[me] = t0[1][1];
+      }
+    }
+    __syncthreads();
+    // phase 2: mu = 1, even columns (a = 0)
+    double L01 = 0, L11 = 0, M01 = 0, M11 = 0, LU = 0;
+    if (active) {
+      L01 = plane(0, 0, 1)[lf]; L11 = plane(0, 1, 1)[lf]; M01 = plane(1, 0, 1)[lf]; M11 = plane(1, 1, 1)[lf];
+      LU = plane(0, 0, 1)[lfup];
+    }
+    if (has_lf) {
+      {  // c = 0
+        const double tp = t0[0][0] + t1[0][1] - t0[1][0];
+        const double tm = L11 + M01 - L01;
+        t1[0][0] = mod_2pi_fast((tp + tm) - t1[0][0]);
+        plane(1, 0, 0)[me] = t1[0][0];
+      }
+      if (has_up) {  // c = 1
+        const double tp = t0[1][0] + t1[1][1] - U0;
+        const double tm = LU + M11 - L11;
+        t1[1][0] = mod_2pi_fast((tp + tm) - t1[1][0]);
+        plane(1, 1, 0)[me] = t1[1][0];
+      }
+    }
+    __syncthreads();
+    // phase 3: mu = 1, odd columns (a = 1); the right neighbour's mu = 1 links changed in phase 2
+    if (active) {
+      R0 = plane(1, 0, 0)[rt]; R1 = plane(1, 1, 0)[rt];
+    }
+    if (has_rt) {
+      {  // c = 0
+        const double tp = t0[0][1] + R0 - t0[1][1];
+        const double tm = t0[1][0] + t1[0][0] - t0[0][0];
+        t1[0][1] = mod_2pi_fast((tp + tm) - t1[0][1]);
+        plane(1, 0, 1)[me] = t1[0][1];
+      }
+      if (has_up) {  // c = 1
+        const double tp = t0[1][1] + R1 - U1;
+        const double tm = U0 + t1[1][0] - t0[1][0];
+        t1[1][1] = mod_2pi_fast((tp + tm) - t1[1][1]);
+        plane(1, 1, 1)[me] = t1[1][1];
+      }
+    }
+    __syncthreads();
+  }
+
+  // owned vertices: buffer columns [H, H + TW), rows [H, H + TH); H is even, so a block is owned as a whole
+  if (active && pi >= H / 2 && pi < (H + TW) / 2 && pj >= H / 2 && pj < (H + TH) / 2) {
+    double2 *dst = out + (size_t)b * Mt * Mx;
+    const size_t o0 = (size_t)(j0 + 2 * pj - H) * Mt + (i0 + 2 * pi - H);
+    dst[o0] = make_double2(t0[0][0], t1[0][0]);
+    dst[o0 + 1] = make_double2(t0[0][1], t1[0][1]);
+    dst[o0 + Mt] = make_double2(t0[1][0], t1[1][0]);
+    dst[o0 + Mt + 1] = make_double2(t0[1][1], t1[1][1]);
+  }
 }
 
 // ---- GFF sweeps --------------------------------------------------------------------------------------
@@ -789,6 +939,22 @@ static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, doub
       double2 *out2 = (double2 *)dst;
       // more fused sweeps -> larger LDS image -> fewer resident workgroups: keep the wave count per CU up
       // with wider workgroups (MLMCPI_OR_THREADS overrides: tuning knob)
+      static const bool use_patch = [] { const char *e = getenv("MLMCPI_OR_KERNEL"); return !(e && !strcmp(e, "lds")); }();
+      if (use_patch && n <= 4) {  // register-tiled kernel (MLMCPI_OR_KERNEL=lds selects the LDS-resident one)
+        const uint32_t np = ((64 + 4 * n) / 2) * ((32 + 4 * n) / 2);
+        const dim3 pblock((np + 63) / 64 * 64);
+        const size_t plds = (size_t)8 * np * sizeof(double);
+        switch (n) {
+          case 1: hipLaunchKernelGGL((schwinger_or_patch_kernel<1>), sgrid, pblock, plds, st, act->Mt, act->Mx, in2, out2, act->Mt / 64); break;
+          case 2: hipLaunchKernelGGL((schwinger_or_patch_kernel<2>), sgrid, pblock, plds, st, act->Mt, act->Mx, in2, out2, act->Mt / 64); break;
+          case 3: hipLaunchKernelGGL((schwinger_or_patch_kernel<3>), sgrid, pblock, plds, st, act->Mt, act->Mx, in2, out2, act->Mt / 64); break;
+          default: hipLaunchKernelGGL((schwinger_or_patch_kernel<4>), sgrid, pblock, plds, st, act->Mt, act->Mx, in2, out2, act->Mt / 64);
+        }
+        MLMCPI_LAUNCH_CHECK("schwinger_or_patch_kernel");
+        double *tmp2 = src; src = dst; dst = tmp2;
+        s += n;
+        continue;
+      }
       uint32_t nt_or = n >= 4 ? 1024 : 512;  // measured best (tools/scan_or.sh): K <= 3: 512, K >= 4: 1024
       if (const char *e = getenv("MLMCPI_OR_THREADS")) { unsigned v = (unsigned)atoi(e); if (v == 256 || v == 512 || v == 1024) nt_or = v; }
 #define MLMCPI_OR(KK, NN) hipLaunchKernelGGL((schwinger_or_kernel<64, 32, KK, NN>), sgrid, dim3(NN), lds, st, act->Mt, act->Mx, in2, out2, act->Mt / 64)
