@@ -14,7 +14,7 @@ acc=collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$OUT/sq/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         k=row["Kernel_Name"].split("(")[0]
-        if "sweep" in k or "hmc" in k:
+        if "sweep" in k or "hmc" in k or "or_" in k:
             acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k,d in acc.items():
     print(k)
