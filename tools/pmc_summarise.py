@@ -18,7 +18,7 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         res[k][counter] = (sum(v) / len(v), len(v))
 summary = []
 for k, d in res.items():
-    if not any(t in k for t in ("sweep_kernel", "or_kernel", "hmc")):
+    if not any(t in k for t in ("sweep_kernel", "or_kernel", "or_patch_kernel", "hmc")):
         continue
     fetch = d.get("FETCH_SIZE", (0, 0))
     write = d.get("WRITE_SIZE", (0, 0))
