@@ -101,7 +101,7 @@ __device__ __forceinline__ uint32_t wrap_add(uint32_t base, uint32_t off, uint32
 // two sites per side per sweep, so a halo of 2*nsweeps keeps the owned tile exact (tile origins are
 // even, which makes buffer parity equal lattice parity).
 template <bool HEAT, int NT>
-__global__ void __launch_bounds__(NT, (HEAT && NT == 256) ? 4 : 1)
+__global__ void __launch_bounds__(NT, HEAT ? (NT == 256 ? 4 : NT == 512 ? 2 : 1) : 1)
     schwinger_sweep_kernel(uint32_t Mt, uint32_t Mx, double beta, const double2 *__restrict__ in,
                            double2 *__restrict__ out, TileGeom tg, uint32_t nsweeps, uint32_t kinds, RngKey key0) {
   extern __shared__ double lds[];
@@ -130,15 +130,28 @@ __global__ void __launch_bounds__(NT, (HEAT && NT == 256) ? 4 : 1)
     const bool heat = HEAT && ((kinds >> s) & 1u);
     RngKey skey = key;
     skey.step += s;
-    // mu = 0: rows of one parity, r in [1, bh-2], c in [0, bw-2]
+    // Update regions.  In general every link whose staple links lie inside the buffer is updated:
+    //   mu = 0: rows [1, bh-2] of one parity, columns [0, bw-2];   mu = 1: columns [1, bw-2] of one parity, rows [0, bh-2].
+    // The LAST sweep of a launch only has to be right on the owned tile (rows [H, H+oh), columns [H, H+ow)), so each
+    // of its phases is cut down to what later phases still read:
+    //   phase 3 (mu = 1, odd columns)   owned links;
+    //   phase 2 (mu = 1, even columns)  + the column right of the tile (phase 3 reads theta_1(i+1, j));
+    //   phases 0, 1 (mu = 0)            rows [H, H+oh], columns [H-1, H+ow] (phases 2, 3 read theta_0 at (i-1 .. i, j .. j+1)).
+    // For a heat-bath launch (always a single sweep) that is 7 % fewer draws.
+    const bool last = s + 1 == nsweeps;
+    const uint32_t r_hi0 = last ? H + oh : bh - 2;                              // mu = 0 rows: upper end (inclusive)
+    const uint32_t c_lo0 = last ? H - 1 : 0, c_hi0 = last ? H + ow : bw - 2;    // mu = 0 columns
+    const uint32_t r_lo1 = last ? H : 0, r_hi1 = last ? H + oh - 1 : bh - 2;    // mu = 1 rows
     for (uint32_t par = 0; par < 2; ++par) {
-      const uint32_t r_first = par ? 1 : 2;
-      const uint32_t nr = (bh - 2 - r_first) / 2 + 1;
+      // even rows first; H is even, so H + par has the parity of this phase
+      const uint32_t r_first = last ? H + par : (par ? 1 : 2);
+      const uint32_t nr = r_first <= r_hi0 ? (r_hi0 - r_first) / 2 + 1 : 0;
+      const uint32_t ncol = c_hi0 - c_lo0 + 1;
       if (heat) {
         heatbath_region<NT, 5>(
-            nr, bw - 1, skey,
-            [&](uint32_t ri, uint32_t c, double &tau, double &centre, uint32_t &site, uint32_t &o) {
-              const uint32_t r = r_first + 2 * ri;
+            nr, ncol, skey,
+            [&](uint32_t ri, uint32_t ci, double &tau, double &centre, uint32_t &site, uint32_t &o) {
+              const uint32_t r = r_first + 2 * ri, c = c_lo0 + ci;
               o = r * bw + c;
               const double tp = mod_2pi_fast(th0[o + bw] + th1[o] - th1[o + 1]);
               const double tm = mod_2pi_fast(th0[o - bw] + th1[o - bw + 1] - th1[o - bw]);
@@ -147,8 +160,8 @@ __global__ void __launch_bounds__(NT, (HEAT && NT == 256) ? 4 : 1)
             },
             [&](uint32_t o, double v) { th0[o] = v; });
       } else
-      for_region<NT>(nr, bw - 1, [&](uint32_t ri, uint32_t c) {
-        const uint32_t r = r_first + 2 * ri, o = r * bw + c;
+      for_region<NT>(nr, ncol, [&](uint32_t ri, uint32_t ci) {
+        const uint32_t r = r_first + 2 * ri, o = r * bw + c_lo0 + ci;
         // overrelaxation: mod_2pi(theta+ + theta- - theta); the two staple angles need no wrap of their own here
         // (2 pi-periodicity of the final map), which drops two of the three mod_2pi per update
         const double tp = th0[o + bw] + th1[o] - th1[o + 1];
@@ -157,15 +170,17 @@ __global__ void __launch_bounds__(NT, (HEAT && NT == 256) ? 4 : 1)
       });
       __syncthreads();
     }
-    // mu = 1: columns of one parity, c in [1, bw-2], r in [0, bh-2]
     for (uint32_t par = 0; par < 2; ++par) {
-      const uint32_t c_first = par ? 1 : 2;
-      const uint32_t nc = (bw - 2 - c_first) / 2 + 1;
+      const uint32_t c_first = last ? H + par : (par ? 1 : 2);
+      // last sweep: even columns up to H + ow (one past the tile), odd columns up to H + ow - 1
+      const uint32_t c_hi1 = last ? (par ? H + ow - 1 : H + ow) : bw - 2;
+      const uint32_t nc = c_first <= c_hi1 ? (c_hi1 - c_first) / 2 + 1 : 0;
+      const uint32_t nrow = r_hi1 - r_lo1 + 1;
       if (heat) {
         heatbath_region<NT, 5>(
-            bh - 1, nc, skey,
-            [&](uint32_t r, uint32_t ci, double &tau, double &centre, uint32_t &site, uint32_t &o) {
-              const uint32_t c = c_first + 2 * ci;
+            nrow, nc, skey,
+            [&](uint32_t ri, uint32_t ci, double &tau, double &centre, uint32_t &site, uint32_t &o) {
+              const uint32_t r = r_lo1 + ri, c = c_first + 2 * ci;
               o = r * bw + c;
               const double tp = mod_2pi_fast(th0[o] + th1[o + 1] - th0[o + bw]);
               const double tm = mod_2pi_fast(th0[o + bw - 1] + th1[o - 1] - th0[o - 1]);
@@ -174,8 +189,8 @@ __global__ void __launch_bounds__(NT, (HEAT && NT == 256) ? 4 : 1)
             },
             [&](uint32_t o, double v) { th1[o] = v; });
       } else
-      for_region<NT>(bh - 1, nc, [&](uint32_t r, uint32_t ci) {
-        const uint32_t c = c_first + 2 * ci, o = r * bw + c;
+      for_region<NT>(nrow, nc, [&](uint32_t ri, uint32_t ci) {
+        const uint32_t r = r_lo1 + ri, c = c_first + 2 * ci, o = r * bw + c;
         const double tp = th0[o] + th1[o + 1] - th0[o + bw];
         const double tm = th0[o + bw - 1] + th1[o - 1] - th0[o - 1];
         th1[o] = mod_2pi_fast((tp + tm) - th1[o]);
