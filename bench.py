@@ -293,7 +293,8 @@ def main():
                 special = size % 64 == 0 and fuse <= (6 if a.workload == "schwinger" else 4)
                 kname = ((f"schwinger_or_patch_kernel<{fuse}>" if fuse <= 4 and os.environ.get("MLMCPI_OR_KERNEL") != "lds"
                           else f"schwinger_or_kernel<64,32,{fuse},{1024 if fuse >= 4 else 512}>") if a.workload == "schwinger" and special
-                         else f"gff_or_kernel<64,32,{fuse},256>" if special else f"{a.workload}_sweep_kernel<false,256>")
+                         else (f"gff_or_patch_kernel<{fuse}>" if os.environ.get("MLMCPI_OR_KERNEL") != "lds"
+                               else f"gff_or_kernel<64,32,{fuse},256>") if special else f"{a.workload}_sweep_kernel<false,256>")
                 result["roofline"] = {"kernel": kname + f" ({fuse} fused overrelaxation sweeps per launch)", "bound": "hbm",
                                       "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                       "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(a, B, fuse),

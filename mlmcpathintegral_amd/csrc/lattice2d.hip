@@ -601,6 +601,91 @@ __global__ void __launch_bounds__(NT)
   for_region<NT>(TH, TW, [&](uint32_t r, uint32_t c) { dst[(size_t)(j0 + r) * Mt + (i0 + c)] = phi[(r + H) * P + (c + H)]; });
 }
 
+// ---- GFF overrelaxation, register-tiled ---------------------------------------------------------------------------
+// Same idea as schwinger_or_patch_kernel: a thread keeps a 2 x 2 block of sites in registers for all K sweeps and LDS
+// (four structure-of-arrays planes [row parity][column parity] over blocks) carries only the values that cross block
+// boundaries: 4 reads + 2 writes per colour phase for 2 updates (24 B per update; gff_or_kernel moves 48 B).  Same
+// updates, colour order and summation order (+i, -i, +j, -j): bit-identical to the kernels above.
+template <int K>
+__global__ void __launch_bounds__(1024)
+    gff_or_patch_kernel(uint32_t Mt, uint32_t Mx, double mu2, const double *__restrict__ in, double *__restrict__ out,
+                        uint32_t tiles_x) {
+  constexpr int TW = 64, TH = 32, H = 2 * K, BW = TW + 2 * H, BH = TH + 2 * H, NPX = BW / 2, NPY = BH / 2;
+  constexpr int NP = NPX * NPY;
+  static_assert(NP <= 1024, "one 2 x 2 block per thread");
+  extern __shared__ double lds[];
+  auto plane = [&](int c, int a) { return lds + (c * 2 + a) * NP; };  // site (2 pi + a, 2 pj + c)
+  const uint32_t tile = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
+  const uint32_t i0 = tx * TW, j0 = ty * TH;
+  const bool active = tid < NP;
+  const int pj = active ? (int)tid / NPX : 0, pi = active ? (int)tid - pj * NPX : 0;
+  const double *src = in + (size_t)b * Mt * Mx;
+  const double two_over_kappa = 2. / (4. + mu2);
+  const uint32_t gi = (uint32_t)(((uint64_t)i0 + Mt - (H % Mt) + 2 * pi) % Mt);
+  const uint32_t gj0 = (uint32_t)(((uint64_t)j0 + Mx - (H % Mx) + 2 * pj) % Mx);
+  const uint32_t gj1 = gj0 + 1 == Mx ? 0 : gj0 + 1;
+  double p[2][2] = {{0, 0}, {0, 0}};  // [c][a]
+  if (active) {
+    const double2 lo = *(const double2 *)(src + (size_t)gj0 * Mt + gi), hi = *(const double2 *)(src + (size_t)gj1 * Mt + gi);
+    p[0][0] = lo.x; p[0][1] = lo.y; p[1][0] = hi.x; p[1][1] = hi.y;
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int a = 0; a < 2; ++a) plane(c, a)[tid] = p[c][a];
+  }
+  const int me = (int)tid;
+  const int dn = pj > 0 ? me - NPX : me, up = pj + 1 < NPY ? me + NPX : me;
+  const int lf = pi > 0 ? me - 1 : me, rt = pi + 1 < NPX ? me + 1 : me;
+  const bool has_dn = active && pj > 0, has_up = active && pj + 1 < NPY, has_lf = active && pi > 0, has_rt = active && pi + 1 < NPX;
+  __syncthreads();
+
+  for (int s = 0; s < K; ++s) {
+    // colour 0: sites (a, c) = (0, 0) and (1, 1)
+    double e_lf = 0, e_dn = 0, e_rt = 0, e_up = 0;
+    if (active) {
+      e_lf = plane(0, 1)[lf]; e_dn = plane(1, 0)[dn]; e_rt = plane(1, 0)[rt]; e_up = plane(0, 1)[up];
+    }
+    if (has_lf && has_dn) {
+      double Delta = 0.0;
+      Delta += p[0][1]; Delta += e_lf; Delta += p[1][0]; Delta += e_dn;
+      p[0][0] = fma(two_over_kappa, Delta, -p[0][0]);
+      plane(0, 0)[me] = p[0][0];
+    }
+    if (has_rt && has_up) {
+      double Delta = 0.0;
+      Delta += e_rt; Delta += p[1][0]; Delta += e_up; Delta += p[0][1];
+      p[1][1] = fma(two_over_kappa, Delta, -p[1][1]);
+      plane(1, 1)[me] = p[1][1];
+    }
+    __syncthreads();
+    // colour 1: sites (1, 0) and (0, 1)
+    if (active) {
+      e_rt = plane(0, 0)[rt]; e_dn = plane(1, 1)[dn]; e_lf = plane(1, 1)[lf]; e_up = plane(0, 0)[up];
+    }
+    if (has_rt && has_dn) {
+      double Delta = 0.0;
+      Delta += e_rt; Delta += p[0][0]; Delta += p[1][1]; Delta += e_dn;
+      p[0][1] = fma(two_over_kappa, Delta, -p[0][1]);
+      plane(0, 1)[me] = p[0][1];
+    }
+    if (has_lf && has_up) {
+      double Delta = 0.0;
+      Delta += p[1][1]; Delta += e_lf; Delta += e_up; Delta += p[0][0];
+      p[1][0] = fma(two_over_kappa, Delta, -p[1][0]);
+      plane(1, 0)[me] = p[1][0];
+    }
+    __syncthreads();
+  }
+
+  if (active && pi >= H / 2 && pi < (H + TW) / 2 && pj >= H / 2 && pj < (H + TH) / 2) {
+    double *dst = out + (size_t)b * Mt * Mx;
+    const size_t o0 = (size_t)(j0 + 2 * pj - H) * Mt + (i0 + 2 * pi - H);
+    *(double2 *)(dst + o0) = make_double2(p[0][0], p[0][1]);
+    *(double2 *)(dst + o0 + Mt) = make_double2(p[1][0], p[1][1]);
+  }
+}
+
 // ---- streaming kernels: evaluate, force, QoI ----------------------------------------------------------
 enum LatOp { L_GFF_ENERGY = 0, L_PHI2 = 1, L_SCHW_ENERGY = 2, L_PLAQ = 3, L_CHARGE = 4 };
 
@@ -990,6 +1075,22 @@ static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, doub
       const size_t lds = (size_t)(32 + 4 * n) * (64 + 4 * n + 1) * sizeof(double);
       dim3 sgrid((act->Mt / 64) * (act->Mx / 32), B);
       const double mu2 = gff_mu2(*act);
+      static const bool use_gff_patch = [] { const char *e = getenv("MLMCPI_OR_KERNEL"); return !(e && !strcmp(e, "lds")); }();
+      if (use_gff_patch) {  // register-tiled kernel (MLMCPI_OR_KERNEL=lds selects the LDS-resident one)
+        const uint32_t np = ((64 + 4 * n) / 2) * ((32 + 4 * n) / 2);
+        const dim3 pblock((np + 63) / 64 * 64);
+        const size_t plds = (size_t)4 * np * sizeof(double);
+        switch (n) {
+          case 1: hipLaunchKernelGGL((gff_or_patch_kernel<1>), sgrid, pblock, plds, st, act->Mt, act->Mx, mu2, (const double *)src, dst, act->Mt / 64); break;
+          case 2: hipLaunchKernelGGL((gff_or_patch_kernel<2>), sgrid, pblock, plds, st, act->Mt, act->Mx, mu2, (const double *)src, dst, act->Mt / 64); break;
+          case 3: hipLaunchKernelGGL((gff_or_patch_kernel<3>), sgrid, pblock, plds, st, act->Mt, act->Mx, mu2, (const double *)src, dst, act->Mt / 64); break;
+          default: hipLaunchKernelGGL((gff_or_patch_kernel<4>), sgrid, pblock, plds, st, act->Mt, act->Mx, mu2, (const double *)src, dst, act->Mt / 64);
+        }
+        MLMCPI_LAUNCH_CHECK("gff_or_patch_kernel");
+        double *tmp2 = src; src = dst; dst = tmp2;
+        s += n;
+        continue;
+      }
       switch (n) {
         case 1: hipLaunchKernelGGL((gff_or_kernel<64, 32, 1, 256>), sgrid, dim3(256), lds, st, act->Mt, act->Mx, mu2, (const double *)src, dst, act->Mt / 64); break;
         case 2: hipLaunchKernelGGL((gff_or_kernel<64, 32, 2, 256>), sgrid, dim3(256), lds, st, act->Mt, act->Mx, mu2, (const double *)src, dst, act->Mt / 64); break;
