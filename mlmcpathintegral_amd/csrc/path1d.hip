@@ -464,6 +464,7 @@ __global__ void __launch_bounds__(256) path_transfer_kernel(uint32_t Mc, double 
 // by at most two sites per sweep and never reach the owned range.  in != out (halo reads race with
 // the neighbours' writes otherwise).  kinds bit s = 1 -> sweep s is a heat-bath sweep.
 // rotoraction.cc:20-56, rotoraction.hh:195-213.
+template <bool HEAT>  // HEAT = false: overrelaxation-only instantiation (no sampler code, few registers)
 __global__ void __launch_bounds__(256)
     rotor_sweep_kernel(PathP P, const double *__restrict__ in, double *__restrict__ out, uint32_t owned_len,
                        uint32_t nsweeps, uint32_t kinds, RngKey key0) {
@@ -475,11 +476,15 @@ __global__ void __launch_bounds__(256)
   const double *xin = in + (size_t)b * M;
   RngKey key = key0;
   key.chain += b;
-  for (uint32_t k = threadIdx.x; k < L; k += blockDim.x) buf[k] = xin[(uint32_t)(((uint64_t)g0 + k) % M)];
+  for (uint32_t k = threadIdx.x; k < L; k += blockDim.x) {
+    uint32_t g = g0 + k;  // g0 < M and M < 2^31 for every supported lattice: no overflow; no 64-bit modulo per element
+    while (g >= M) g -= M;
+    buf[k] = xin[g];
+  }
   __syncthreads();
   const double sig_scale = 2.0 * P.m0 / P.a;  // W'' = (2 m0 / a) |cos((x+ - x-)/2)|
   for (uint32_t s = 0; s < nsweeps; ++s) {
-    const bool heat = (kinds >> s) & 1u;
+    const bool heat = HEAT && ((kinds >> s) & 1u);
     RngKey skey = key;
     skey.step += s;
     for (uint32_t colour = 0; colour < 2; ++colour) {
@@ -495,16 +500,19 @@ __global__ void __launch_bounds__(256)
           const uint32_t k = k0 + 2 * idx;
           buf[k] = mod_2pi_fast(buf[k - 1] + buf[k + 1] - buf[k]);
         }
-      } else {
+      } else if (HEAT) {
         heatbath_cells<256, 4>(
             count, skey,
             [&](uint32_t idx, double &tau, double &centre, uint32_t &site, uint32_t &off) {
               const uint32_t k = k0 + 2 * idx;
               const double xm = buf[k - 1], xp = buf[k + 1];
-              const double c = cos(0.5 * (xp - xm));
+              // |x+ - x-| / 2 <= pi: cos(d) = cos(pi u), u = |x+ - x-| / (2 pi) in [0, 1] (no libm range reduction)
+              const double c = cospi_unit(fmin(fabs(xp - xm) * (0.5 / kPi), 1.0));
               tau = sig_scale * fabs(c);
               centre = 0.5 * (xp + xm) + (c < 0.0 ? kPi : 0.0);
-              site = (uint32_t)(((uint64_t)g0 + k) % M);
+              uint32_t g = g0 + k;
+              while (g >= M) g -= M;
+              site = g;
               off = k;
             },
             [&](uint32_t off, double angle) { buf[off] = angle; });
@@ -861,10 +869,11 @@ int mlmcpi_path_sweep_draw(const mlmcpi_path_action *act, double *d_x, double *d
   double *src = d_x, *dst = d_scratch;
   uint32_t s = 0;
   while (s < total) {
-    // fuse up to 4 sweeps per launch; overrelaxation sweeps come first (sampler order)
-    uint32_t n = total - s < 4 ? total - s : 4, kinds = 0;
-    for (uint32_t q = 0; q < n; ++q)
-      if (s + q >= n_overrelax) kinds |= 1u << q;
+    // overrelaxation sweeps (they come first, sampler order) are fused up to 8 per launch: in one dimension the halo
+    // of 2 sites per sweep costs next to nothing; a heat-bath sweep gets a launch of its own (sampler-bound)
+    uint32_t n = 1, kinds = 0;
+    if (s < n_overrelax) n = n_overrelax - s < 8 ? n_overrelax - s : 8;
+    else kinds = 1u;
     const uint32_t halo = 2 * n;
     uint32_t owned = 2048 - 2 * halo;  // even
     if (owned > P.M) owned = P.M;
@@ -873,8 +882,12 @@ int mlmcpi_path_sweep_draw(const mlmcpi_path_action *act, double *d_x, double *d
     owned += owned & 1;  // keep segment starts even
     const uint32_t nseg2 = (P.M + owned - 1) / owned;
     const size_t lds = (size_t)(owned + 2 * halo) * sizeof(double);
-    hipLaunchKernelGGL(rotor_sweep_kernel, dim3(nseg2, B), dim3(256), lds, st, P, (const double *)src, dst, owned, n,
-                       kinds, make_key(seed, chain0, sweep0 + s));
+    if (kinds)
+      hipLaunchKernelGGL(rotor_sweep_kernel<true>, dim3(nseg2, B), dim3(256), lds, st, P, (const double *)src, dst, owned, n,
+                         kinds, make_key(seed, chain0, sweep0 + s));
+    else
+      hipLaunchKernelGGL(rotor_sweep_kernel<false>, dim3(nseg2, B), dim3(256), lds, st, P, (const double *)src, dst, owned, n,
+                         kinds, make_key(seed, chain0, sweep0 + s));
     MLMCPI_LAUNCH_CHECK("rotor_sweep_kernel");
     double *tmp = src; src = dst; dst = tmp;
     s += n;
