@@ -75,9 +75,21 @@ __device__ __forceinline__ void stage_region(uint32_t nr, uint32_t nc, Load load
 template <int NT, int S, class Setup, class Commit>
 __device__ __forceinline__ void heatbath_region(uint32_t nr, uint32_t nc, const RngKey &key, Setup setup,
                                                 Commit commit) {
+  // (row, column) of a thread's cells without a division per cell: one division for the first cell, then steps of NT
+  // (heatbath_cells asks for a thread's cells in increasing order: idx = tid, tid + NT, tid + 2 NT, ...)
+  uint32_t cur = threadIdx.x, ri = cur / nc, ci = cur - ri * nc;
+  const uint32_t dr = NT / nc, dc = NT - dr * nc;
   heatbath_cells<NT, S>(nr * nc, key,
                         [&](uint32_t idx, double &tau, double &centre, uint32_t &site, uint32_t &o) {
-                          const uint32_t ri = idx / nc, ci = idx - ri * nc;
+                          while (cur < idx) {
+                            cur += NT;
+                            ri += dr;
+                            ci += dc;
+                            if (ci >= nc) {
+                              ci -= nc;
+                              ++ri;
+                            }
+                          }
                           setup(ri, ci, tau, centre, site, o);
                         },
                         commit);
