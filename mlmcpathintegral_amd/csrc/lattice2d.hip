@@ -516,23 +516,38 @@ __global__ void __launch_bounds__(NT)
         if (park) nrm[r * bw + (c ^ 1u)] = (ell & 1u) ? n0 : n1;
         return (ell & 1u) ? n1 : n0;
       };
+      // Update region of this phase: rows [r_lo, r_lo + nrow), columns [c_lo, c_lo + 2 nhalf), cells of the phase's
+      // colour.  In general everything but the outermost ring of the buffer; the LAST sweep of a launch is cut down to
+      // what is still read afterwards: colour 1 (last phase) the owned tile, colour 0 the tile plus one ring.
+      const bool last = s + 1 == nsweeps;
+      const uint32_t grow = colour == 0 ? 1u : 0u;  // rings around the owned tile in the last sweep
+      const uint32_t r_lo = last ? H - grow : 1, nrow = last ? oh + 2 * grow : bh - 2;
+      const uint32_t c_lo = last ? H - grow : 1, nhalf = last ? (ow + 2 * grow) / 2 : (bw - 2) / 2;
+      auto column = [&](uint32_t r, uint32_t ci) { return c_lo + ((r + c_lo + colour) & 1u) + 2 * ci; };
       if (!heat) {
-        for_region<NT>(bh - 2, (bw - 2) / 2, [&](uint32_t ri, uint32_t ci) {
-          const uint32_t r = 1 + ri;
-          const uint32_t o = r * bw + 1 + ((r + 1 + colour) & 1u) + 2 * ci;
+        for_region<NT>(nrow, nhalf, [&](uint32_t ri, uint32_t ci) {
+          const uint32_t r = r_lo + ri;
+          const uint32_t o = r * bw + column(r, ci);
           phi[o] = fma(two_over_kappa, stencil(o), -phi[o]);  // 2 Delta / kappa - phi without the fp64 division
         });
       } else if (colour == 0) {
-        for_region<NT>(bh - 2, (bw - 2) / 2, [&](uint32_t ri, uint32_t ci) {
-          const uint32_t r = 1 + ri;
-          const uint32_t c = 1 + ((r + 1) & 1u) + 2 * ci;
+        for_region<NT>(nrow, nhalf, [&](uint32_t ri, uint32_t ci) {
+          const uint32_t r = r_lo + ri;
+          const uint32_t c = column(r, ci);
           const uint32_t o = r * bw + c;
           phi[o] = fma(stencil(o), inv_kappa, sigma * draw_pair(r, c, true));
         });
+      } else if (last) {
+        // every colour-1 cell of the tile has its pair partner (c ^ 1, same row) inside the colour-0 region above
+        for_region<NT>(nrow, nhalf, [&](uint32_t ri, uint32_t ci) {
+          const uint32_t r = r_lo + ri;
+          const uint32_t o = r * bw + column(r, ci);
+          phi[o] = fma(stencil(o), inv_kappa, sigma * nrm[o]);
+        });
       } else {
-        for_region<NT>(bh - 2, (bw - 2) / 2, [&](uint32_t ri, uint32_t ci) {
-          const uint32_t r = 1 + ri;
-          const uint32_t c = 1 + (r & 1u) + 2 * ci;
+        for_region<NT>(nrow, nhalf, [&](uint32_t ri, uint32_t ci) {
+          const uint32_t r = r_lo + ri;
+          const uint32_t c = column(r, ci);
           if (c == 1 || c == bw - 2) return;  // boundary partners: next pass
           const uint32_t o = r * bw + c;
           phi[o] = fma(stencil(o), inv_kappa, sigma * nrm[o]);
