@@ -357,13 +357,15 @@ __global__ void __launch_bounds__(1024)
         plane(1, c, a)[tid] = t1[c][a];
       }
   }
-  // neighbour blocks, clamped into the buffer (a clamped read feeds only updates that the validity flags switch off)
+  // Neighbour blocks, clamped into the buffer.  Links on the buffer edge have no complete stencil; the kernels above
+  // leave them alone, here they are updated from the clamped (wrong) neighbours instead -- no predicates in the sweep
+  // loop.  Either way what an edge link holds only ever reaches links that are already outside the exact region
+  // (which shrinks by one block per sweep no matter what its surroundings hold), never the owned tile.
   const int me = (int)tid;
   const int dn = pj > 0 ? me - NPX : me, up = pj + 1 < NPY ? me + NPX : me;
   const int lf = pi > 0 ? me - 1 : me, rt = pi + 1 < NPX ? me + 1 : me;
   const int rtdn = (pi + 1 < NPX ? 1 : 0) + (pj > 0 ? -NPX : 0) + me;
   const int lfup = (pi > 0 ? -1 : 0) + (pj + 1 < NPY ? NPX : 0) + me;
-  const bool has_dn = active && pj > 0, has_up = active && pj + 1 < NPY, has_lf = active && pi > 0, has_rt = active && pi + 1 < NPX;
   __syncthreads();
 
   for (int s = 0; s < K; ++s) {
@@ -373,14 +375,14 @@ __global__ void __launch_bounds__(1024)
       D0 = plane(0, 1, 0)[dn]; D1 = plane(0, 1, 1)[dn]; E0 = plane(1, 1, 0)[dn]; E1 = plane(1, 1, 1)[dn];
       R0 = plane(1, 0, 0)[rt]; RD = plane(1, 1, 0)[rtdn];
     }
-    if (has_dn) {
+    if (active) {
       {  // a = 0
         const double tp = t0[1][0] + t1[0][0] - t1[0][1];
         const double tm = D0 + E1 - E0;
         t0[0][0] = mod_2pi_fast((tp + tm) - t0[0][0]);
         plane(0, 0, 0)[me] = t0[0][0];
       }
-      if (has_rt) {  // a = 1
+      {  // a = 1
         const double tp = t0[1][1] + t1[0][1] - R0;
         const double tm = D1 + RD - E1;
         t0[0][1] = mod_2pi_fast((tp + tm) - t0[0][1]);
@@ -393,14 +395,14 @@ __global__ void __launch_bounds__(1024)
     if (active) {
       U0 = plane(0, 0, 0)[up]; U1 = plane(0, 0, 1)[up]; R1 = plane(1, 1, 0)[rt];
     }
-    if (has_up) {
+    if (active) {
       {
         const double tp = U0 + t1[1][0] - t1[1][1];
         const double tm = t0[0][0] + t1[0][1] - t1[0][0];
         t0[1][0] = mod_2pi_fast((tp + tm) - t0[1][0]);
         plane(0, 1, 0)[me] = t0[1][0];
       }
-      if (has_rt) {
+      {
         const double tp = U1 + t1[1][1] - R1;
         const double tm = t0[0][1] + R0 - t1[0][1];
         t0[1][1] = mod_2pi_fast((tp + tm) - t0[1][1]);
@@ -414,14 +416,14 @@ __global__ void __launch_bounds__(1024)
       L01 = plane(0, 0, 1)[lf]; L11 = plane(0, 1, 1)[lf]; M01 = plane(1, 0, 1)[lf]; M11 = plane(1, 1, 1)[lf];
       LU = plane(0, 0, 1)[lfup];
     }
-    if (has_lf) {
+    if (active) {
       {  // c = 0
         const double tp = t0[0][0] + t1[0][1] - t0[1][0];
         const double tm = L11 + M01 - L01;
         t1[0][0] = mod_2pi_fast((tp + tm) - t1[0][0]);
         plane(1, 0, 0)[me] = t1[0][0];
       }
-      if (has_up) {  // c = 1
+      {  // c = 1
         const double tp = t0[1][0] + t1[1][1] - U0;
         const double tm = LU + M11 - L11;
         t1[1][0] = mod_2pi_fast((tp + tm) - t1[1][0]);
@@ -433,14 +435,14 @@ __global__ void __launch_bounds__(1024)
     if (active) {
       R0 = plane(1, 0, 0)[rt]; R1 = plane(1, 1, 0)[rt];
     }
-    if (has_rt) {
+    if (active) {
       {  // c = 0
         const double tp = t0[0][1] + R0 - t0[1][1];
         const double tm = t0[1][0] + t1[0][0] - t0[0][0];
         t1[0][1] = mod_2pi_fast((tp + tm) - t1[0][1]);
         plane(1, 0, 1)[me] = t1[0][1];
       }
-      if (has_up) {  // c = 1
+      {  // c = 1
         const double tp = t0[1][1] + R1 - U1;
         const double tm = U0 + t1[1][0] - t0[1][0];
         t1[1][1] = mod_2pi_fast((tp + tm) - t1[1][1]);
@@ -664,7 +666,8 @@ __global__ void __launch_bounds__(1024)
   const int me = (int)tid;
   const int dn = pj > 0 ? me - NPX : me, up = pj + 1 < NPY ? me + NPX : me;
   const int lf = pi > 0 ? me - 1 : me, rt = pi + 1 < NPX ? me + 1 : me;
-  const bool has_dn = active && pj > 0, has_up = active && pj + 1 < NPY, has_lf = active && pi > 0, has_rt = active && pi + 1 < NPX;
+  // sites on the buffer edge are updated from clamped neighbours instead of being left alone: see
+  // schwinger_or_patch_kernel (their values never reach the owned tile)
   __syncthreads();
 
   for (int s = 0; s < K; ++s) {
@@ -673,13 +676,13 @@ __global__ void __launch_bounds__(1024)
     if (active) {
       e_lf = plane(0, 1)[lf]; e_dn = plane(1, 0)[dn]; e_rt = plane(1, 0)[rt]; e_up = plane(0, 1)[up];
     }
-    if (has_lf && has_dn) {
+    if (active) {
       double Delta = 0.0;
       Delta += p[0][1]; Delta += e_lf; Delta += p[1][0]; Delta += e_dn;
       p[0][0] = fma(two_over_kappa, Delta, -p[0][0]);
       plane(0, 0)[me] = p[0][0];
     }
-    if (has_rt && has_up) {
+    if (active) {
       double Delta = 0.0;
       Delta += e_rt; Delta += p[1][0]; Delta += e_up; Delta += p[0][1];
       p[1][1] = fma(two_over_kappa, Delta, -p[1][1]);
@@ -690,13 +693,13 @@ __global__ void __launch_bounds__(1024)
     if (active) {
       e_rt = plane(0, 0)[rt]; e_dn = plane(1, 1)[dn]; e_lf = plane(1, 1)[lf]; e_up = plane(0, 0)[up];
     }
-    if (has_rt && has_dn) {
+    if (active) {
       double Delta = 0.0;
       Delta += e_rt; Delta += p[0][0]; Delta += p[1][1]; Delta += e_dn;
       p[0][1] = fma(two_over_kappa, Delta, -p[0][1]);
       plane(0, 1)[me] = p[0][1];
     }
-    if (has_lf && has_up) {
+    if (active) {
       double Delta = 0.0;
       Delta += p[1][1]; Delta += e_lf; Delta += e_up; Delta += p[0][0];
       p[1][0] = fma(two_over_kappa, Delta, -p[1][0]);
