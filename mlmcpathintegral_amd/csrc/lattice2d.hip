@@ -1069,7 +1069,8 @@ static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, doub
       double2 *out2 = (double2 *)dst;
       // more fused sweeps -> larger LDS image -> fewer resident workgroups: keep the wave count per CU up
       // with wider workgroups (MLMCPI_OR_THREADS overrides: tuning knob)
-      static const bool use_patch = [] { const char *e = getenv("MLMCPI_OR_KERNEL"); return !(e && !strcmp(e, "lds")); }();
+      const char *or_env = getenv("MLMCPI_OR_KERNEL");  // read per call: tests flip it
+      const bool use_patch = !(or_env && !strcmp(or_env, "lds"));
       if (use_patch && n <= 4) {  // register-tiled kernel (MLMCPI_OR_KERNEL=lds selects the LDS-resident one)
         const uint32_t np = ((64 + 4 * n) / 2) * ((32 + 4 * n) / 2);
         const dim3 pblock((np + 63) / 64 * 64);
@@ -1105,7 +1106,8 @@ static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, doub
       const size_t lds = (size_t)(32 + 4 * n) * (64 + 4 * n + 1) * sizeof(double);
       dim3 sgrid((act->Mt / 64) * (act->Mx / 32), B);
       const double mu2 = gff_mu2(*act);
-      static const bool use_gff_patch = [] { const char *e = getenv("MLMCPI_OR_KERNEL"); return !(e && !strcmp(e, "lds")); }();
+      const char *or_env = getenv("MLMCPI_OR_KERNEL");
+      const bool use_gff_patch = !(or_env && !strcmp(or_env, "lds"));
       if (use_gff_patch) {  // register-tiled kernel (MLMCPI_OR_KERNEL=lds selects the LDS-resident one)
         const uint32_t np = ((64 + 4 * n) / 2) * ((32 + 4 * n) / 2);
         const dim3 pblock((np + 63) / 64 * 64);

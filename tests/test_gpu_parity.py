@@ -483,7 +483,7 @@ SWEEP_CASES = [
 ]
 
 
-@pytest.mark.parametrize("fuse", [1, 3])
+@pytest.mark.parametrize("fuse", [1, 3, 0])  # 0 = library default (4 overrelaxation sweeps per launch)
 @pytest.mark.parametrize("kind,Mt,Mx,kw,B", SWEEP_CASES)
 def test_lattice_sweeps_match_oracle(gpu_ops, orc, kind, Mt, Mx, kw, B, fuse):
     act, A = make_lattice(orc, kind, Mt, Mx, **kw)
@@ -655,6 +655,17 @@ def test_schwinger_1024_properties(gpu_ops, orc, golden):
     finally:
         del os.environ["MLMCPI_SWEEP_TILE"]
     assert torch.equal(a, gen), "specialised and generic sweep kernels must agree bit for bit"
+    # library default (4 overrelaxation sweeps per launch, register-tiled kernel) and the LDS-resident kernel
+    d4 = x.clone()
+    gpu_ops.lattice_sweep_draw(act, d4, scratch, 4, 2, SEED, 0, 0, fuse=0)
+    assert torch.equal(a, d4), "the default fusion depth must not change the result"
+    os.environ["MLMCPI_OR_KERNEL"] = "lds"
+    try:
+        lds4 = x.clone()
+        gpu_ops.lattice_sweep_draw(act, lds4, scratch, 4, 2, SEED, 0, 0, fuse=4)
+    finally:
+        del os.environ["MLMCPI_OR_KERNEL"]
+    assert torch.equal(a, lds4), "register-tiled and LDS-resident overrelaxation kernels must agree bit for bit"
     single = x[1:2].clone()
     gpu_ops.lattice_sweep_draw(act, single, torch.empty_like(single), 4, 2, SEED, 1, 0, fuse=2)
     assert torch.equal(single[0], a[1]), "a chain's result must not depend on the batch it runs in"
@@ -688,6 +699,13 @@ def test_rotor_65536_and_gff_512_properties(gpu_ops):
     finally:
         del os.environ["MLMCPI_SWEEP_TILE"]
     assert torch.equal(a, gen), "specialised and generic GFF kernels must agree bit for bit"
+    os.environ["MLMCPI_OR_KERNEL"] = "lds"
+    try:
+        lds4 = phi.clone()
+        gpu_ops.lattice_sweep_draw(act, lds4, scratch, 6, 1, SEED, 0, 0, fuse=4)
+    finally:
+        del os.environ["MLMCPI_OR_KERNEL"]
+    assert torch.equal(a, lds4), "register-tiled and LDS-resident GFF overrelaxation kernels must agree bit for bit"
     c = phi.clone()
     gpu_ops.lattice_sweep_draw(act, c, scratch, 6, 0, SEED, 0, 0, fuse=3)
     assert_close(gpu_ops.lattice_evaluate(act, c).cpu().numpy(), S0, tol=1e-11, what="GFF OR conserves S")
