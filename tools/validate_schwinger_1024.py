@@ -1,0 +1,31 @@
+"""One-off validation at the headline size: Schwinger 1024^2, beta = 1, B chains, default sampler (10 OR + 1 HB per
+draw): average plaquette against I1(1)/I0(1) and Q^2/(4 pi^2) against its mean over chains (sanity)."""
+import math, sys, torch
+sys.path.insert(0, ".")
+from scipy import special
+from mlmcpathintegral_amd import abi, ops
+B, n_burn, n = 16, 60, int(sys.argv[1]) if len(sys.argv) > 1 else 300
+act = abi.lattice_action(abi.SCHWINGER, 1024, 1024, beta=1.0)
+x = ops.lattice_initialise(act, B, 99)
+s = torch.empty_like(x)
+sweep = 0
+plaq, chi = [], []
+for k in range(n_burn + n):
+    x, s = ops.lattice_sweep_draw_pingpong(act, x, s, 10, 1, 99, 0, sweep)
+    sweep += 11
+    if k >= n_burn:
+        plaq.append(ops.qoi_avg_plaquette(x, 1024, 1024))
+        chi.append(ops.qoi_2d_susceptibility(x, 1024, 1024))
+P = torch.stack(plaq)          # [n, B]
+cm = P.mean(dim=0)
+m, e = float(cm.mean()), float(cm.std(unbiased=True)) / math.sqrt(B)
+exact = special.i1(1.0) / special.i0(1.0)
+C = torch.stack(chi).mean(dim=0)
+# V chi_t = V/(4 pi^2) * <(sum_P theta_P)^2>/V ... compare with the large-volume value P * Phi(beta): per plaquette
+# variance of the wrapped plaquette angle under exp(beta cos): sum over plaquettes (approximately independent)
+import numpy as np
+th = np.linspace(-np.pi, np.pi, 200001)
+w = np.exp(1.0 * np.cos(th)); w /= w.sum()
+var_theta = float((w * th * th).sum())
+print(f"plaquette {m:.7f} +- {e:.7f} (exact {exact:.7f}, deviation {(m-exact)/e:+.2f} sigma)")
+print(f"Q^2/(4 pi^2) {float(C.mean()):.1f} +- {float(C.std(unbiased=True))/math.sqrt(B):.1f} (independent-plaquette estimate {1024*1024*var_theta/(4*math.pi**2):.1f})")
