@@ -138,6 +138,20 @@ int main(int argc, char **argv) {
     EXPECT(std::fabs(st->average() - exact) < 5 * st->error(), "HO <x^2> %.6f vs %.6f +- %.6f", st->average(), exact, st->error());
     EXPECT(std::fabs(mc.get_sampler()->p_accept() - 0.8) < 0.05, "p_accept %.4f", mc.get_sampler()->p_accept());
   }
+  // ---- HO exact sampler (sampler = 'exact'): independent draws, tau_int = 1 ----------------------------------
+  {
+    auto lat = std::make_shared<Lattice1D>(128, 4.0);
+    auto act = std::make_shared<HarmonicOscillatorAction>(lat, RenormalisationNone, 1.0, 1.0);
+    SingleLevelMCParameters mp;
+    mp.n_burnin = 10; mp.n_samples = 20000;
+    MonteCarloSingleLevel mc(act, std::make_shared<QoIXsquared>(lat), std::make_shared<ExactSamplerFactory>(), mp);
+    mc.evaluate();
+    auto st = mc.get_statistics();
+    std::printf(" exact sampler: <x^2> = %.6f +- %.6f (analytic %.6f), tau_int %.3f\n", st->average(), st->error(),
+                act->Xsquared_analytical(), st->tau_int());
+    EXPECT(std::fabs(st->average() - act->Xsquared_analytical()) < 5 * st->error(), "exact sampler <x^2>");
+    EXPECT(st->tau_int() < 1.2, "exact sampler draws are independent");
+  }
   // ---- Schwinger 16x16: OverrelaxedHeatBathSampler through the estimator loop, batch of chains ---------
   {
     auto lat = std::make_shared<Lattice2D>(16, 16, CoarsenBoth);

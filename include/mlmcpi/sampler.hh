@@ -225,5 +225,49 @@ private:
   const OverrelaxedHeatBathParameters param;
 };
 
+/** The exact sampler of the harmonic oscillator.  In the reference HarmonicOscillatorAction is itself a Sampler
+ *  (harmonicoscillatoraction.hh:83, draw at harmonicoscillatoraction.cc:59-66, Cholesky factor at :38-56) and the
+ *  drivers select it with sampler = 'exact'.  Here the factor is built once on the host and every draw is one fp64
+ *  matrix-core product for the whole batch of chains (mlmcpi_path_exact_draw). */
+class HarmonicOscillatorExactSampler : public Sampler {
+public:
+  HarmonicOscillatorExactSampler(const std::shared_ptr<Action> action_, unsigned int batch = 1)
+      : Sampler(), action(std::dynamic_pointer_cast<HarmonicOscillatorAction>(action_)), B(batch) {
+    if (!action) fatal("exact sampler only for the harmonic oscillator action");
+    const size_t M = action->sample_size();
+    std::vector<double> LT(M * M);
+    check(mlmcpi_ho_cholesky_factor(&action->abi_action(), LT.data()), "ho_cholesky_factor");
+    factor = std::make_shared<DeviceVector>(M * M);
+    check(mlmcpi_copy_h2d(factor->ptr(), LT.data(), M * M * sizeof(double), nullptr), "copy_h2d");
+    state = std::make_shared<SampleState>(M, B);
+  }
+  void draw(std::shared_ptr<SampleState> x_path) override {
+    check(mlmcpi_path_exact_draw(&action->abi_action(), (const double *)factor->ptr(), state->device_mutable(), B,
+                                 action->get_seed() ^ 0x45584143ull, action->get_chain0(), step++, nullptr), "path_exact_draw");
+    accept = true;
+    n_total_samples++;
+    n_accepted_samples++;
+    x_path->data = state->data;
+  }
+  void set_state(std::shared_ptr<SampleState>) override {}  // independent draws: there is no chain state
+
+private:
+  const std::shared_ptr<HarmonicOscillatorAction> action;
+  const unsigned int B;
+  std::shared_ptr<DeviceVector> factor;
+  std::shared_ptr<SampleState> state;
+  uint32_t step = 0;
+};
+
+class ExactSamplerFactory : public SamplerFactory {
+public:
+  explicit ExactSamplerFactory(unsigned int batch_ = 1) : batch(batch_) {}
+  std::shared_ptr<Sampler> get(std::shared_ptr<Action> action) override {
+    return std::make_shared<HarmonicOscillatorExactSampler>(action, batch);
+  }
+private:
+  const unsigned int batch;
+};
+
 }  // namespace mlmcpi
 #endif

@@ -160,6 +160,16 @@ int mlmcpi_path_twolevel_draw(const mlmcpi_path_action *fine, const mlmcpi_path_
  * fine sites are left untouched.  d_fine [B*2*M_coarse], d_coarse [B*M_coarse]. */
 int mlmcpi_path_copy_from_fine(const double *d_fine, double *d_coarse, uint32_t M_coarse, uint32_t B, void *stream);
 int mlmcpi_path_copy_from_coarse(const double *d_coarse, double *d_fine, uint32_t M_coarse, uint32_t B, void *stream);
+/* Exact sampler of the harmonic oscillator (the action is its own Sampler in the reference).
+ * mlmcpi_ho_cholesky_factor: HarmonicOscillatorAction::build_covariance (action/qm/harmonicoscillatoraction.cc:38-56)
+ *   on the host: lower Cholesky factor L of the covariance = inverse of the circulant precision matrix, O(M^3);
+ *   h_LT [M][M] (host memory) receives L^T row-major, h_LT[k*M + j] = L[j][k].  M_lat <= 4096.
+ * mlmcpi_path_exact_draw: HarmonicOscillatorAction::draw (:59-66): d_x[b] = L y[b], y ~ N(0,1)^M from Philox
+ *   (entries 2m, 2m+1 = the Box-Muller pair of site m, purpose P_EXACT, step `step`), for B chains -- a dense
+ *   [B x M] . [M x M] fp64 product on the matrix cores.  d_LT = h_LT copied to the device. */
+int mlmcpi_ho_cholesky_factor(const mlmcpi_path_action *act, double *h_LT);
+int mlmcpi_path_exact_draw(const mlmcpi_path_action *act, const double *d_LT, double *d_x, uint32_t B, uint64_t seed,
+                           uint32_t chain0, uint32_t step, void *stream);
 
 /* ---- 2-D lattices --------------------------------------------------------------------------- */
 int mlmcpi_lattice_state_size(const mlmcpi_lattice_action *act, uint32_t *n); /* Action::sample_size */

@@ -193,6 +193,7 @@ enum Purpose : uint32_t {
   P_FILLIN = 7,   // two-level step: Gaussian fill-in of the fine-only sites
   P_ACCEPT2 = 8,  // two-level step: Metropolis uniform
   P_BESSEL = 9,   // two-level step, Schwinger coarsened in both directions: Bessel-product fill-in, sub = call counter
+  P_EXACT = 10,   // exact Gaussian sampler of the harmonic oscillator: normals of entries (2 m, 2 m + 1) from site m
 };
 
 struct RngKey {

@@ -6,6 +6,9 @@
 //     workgroup per chain segment, halo of nt+1 sites recomputed redundantly, so HBM sees one read
 //     and one write of the path per trajectory instead of 4 x 8 B per site per leapfrog step
 //   * rotor overrelaxation / heat-bath sweeps (even / odd colouring) on LDS-resident segments
+#include <cmath>
+#include <vector>
+
 #include "internal.hpp"
 
 namespace mlmcpi {
@@ -1009,6 +1012,124 @@ int mlmcpi_path_copy_from_coarse(const double *d_coarse, double *d_fine, uint32_
   hipLaunchKernelGGL(path_transfer_kernel, dim3(choose_split(M_coarse, B), B), dim3(256), 0, as_stream(stream), M_coarse,
                      d_fine, (double *)d_coarse, 0);
   MLMCPI_LAUNCH_CHECK("path_transfer_kernel");
+  return MLMCPI_OK;
+}
+
+}  // extern "C"
+
+// =================================================================================================
+// Exact sampler of the harmonic oscillator: HarmonicOscillatorAction::build_covariance / draw
+// (action/qm/harmonicoscillatoraction.cc:38-66).  x = L y with y ~ N(0, 1)^M and L the lower Cholesky factor of the
+// covariance (the inverse of the circulant precision matrix) -- for B chains a dense [B x M] . [M x M] product,
+// the one fp64 matrix-core job of the path: v_mfma_f64_16x16x4_f64, one wave per 16 chains x 16 sites output tile.
+//   A operand: y tile, lane l holds y[chain l & 15][k = k0 + (l >> 4)]      (from LDS; Philox, purpose P_EXACT)
+//   B operand: L^T tile, lane l holds L[site j0 + (l & 15)][k = k0 + (l >> 4)] = LT[k][j] (coalesced along j)
+//   C / D:     lane l, register r holds x[chain (l >> 4) + 4 r][site j0 + (l & 15)]   (f64 map, not the f32 one)
+// L is lower triangular, so a site tile stops at k <= j0 + 15.
+// =================================================================================================
+namespace mlmcpi {
+
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+template <int TJ>  // site tiles per wave
+__global__ void __launch_bounds__(256)
+    ho_exact_draw_kernel(uint32_t M, uint32_t B, const double *__restrict__ LT, double *__restrict__ x, RngKey key0) {
+  constexpr int KC = 64;  // k values generated per round
+  __shared__ double ylds[KC * 16];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t c0 = blockIdx.y * 16u;                  // first chain of this workgroup
+  const uint32_t jw0 = (blockIdx.x * 4u + wave) * TJ * 16u;  // first site of this wave
+  const uint32_t j_hi_block = min(M, (blockIdx.x + 1u) * 4u * TJ * 16u);  // sites of the workgroup end here
+  v4f64 acc[TJ];
+#pragma unroll
+  for (int t = 0; t < TJ; ++t) acc[t] = (v4f64){0., 0., 0., 0.};
+  for (uint32_t k0 = 0; k0 < j_hi_block; k0 += KC) {
+    __syncthreads();
+    // y[chain][k0 .. k0 + KC): 16 chains x KC/2 Box-Muller pairs = 512 pairs for 256 threads
+    for (uint32_t p = threadIdx.x; p < 16u * (KC / 2); p += 256u) {
+      const uint32_t r = p & 15u, q = p >> 4;
+      const uint32_t k = k0 + 2u * q;
+      double n0 = 0.0, n1 = 0.0;
+      if (c0 + r < B && k < M) {
+        RngKey key = key0;
+        key.chain += c0 + r;
+        rng_normals(key, k >> 1, P_EXACT, 0, n0, n1);
+      }
+      ylds[(2u * q) * 16u + r] = n0;
+      ylds[(2u * q + 1u) * 16u + r] = n1;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < TJ; ++t) {
+      const uint32_t j0 = jw0 + t * 16u;
+      if (j0 >= M || k0 > j0 + 15u) continue;             // wave-uniform: tile outside the lattice / above the diagonal
+      const uint32_t j = j0 + (lane & 15u);
+      for (uint32_t kk = 0; kk < (uint32_t)KC && k0 + kk <= j0 + 15u; kk += 4u) {
+        const uint32_t k = k0 + kk + (lane >> 4);
+        const double a = ylds[(kk + (lane >> 4)) * 16u + (lane & 15u)];
+        const double bv = (k < M && j < M) ? LT[(size_t)k * M + j] : 0.0;
+        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, acc[t], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < TJ; ++t) {
+    const uint32_t j = jw0 + t * 16u + (lane & 15u);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const uint32_t chain = c0 + (lane >> 4) + 4u * r;
+      if (chain < B && j < M) x[(size_t)chain * M + j] = acc[t][r];
+    }
+  }
+}
+
+}  // namespace mlmcpi
+
+extern "C" {
+
+// harmonicoscillatoraction.cc:38-56.  The precision matrix Q = circ(d, c, 0, ..., 0, c) is circulant, so its inverse is
+// the circulant with first row C_k = (1/M) sum_m cos(2 pi m k / M) / (d + 2 c cos(2 pi m / M)); then a Cholesky
+// decomposition C = L L^T (Cholesky-Banachiewicz, O(M^3 / 3) on the host, as in the reference).  h_LT receives L^T
+// row-major, i.e. h_LT[k * M + j] = L[j][k], the layout the device product reads.
+int mlmcpi_ho_cholesky_factor(const mlmcpi_path_action *act, double *h_LT) {
+  if (int rc = check_action(act)) return rc;
+  MLMCPI_REQUIRE(h_LT, "h_LT is NULL");
+  if (act->kind != MLMCPI_HARMONIC) return fail(MLMCPI_ERR_UNSUPPORTED, "exact sampler only for the harmonic oscillator action");
+  const uint32_t M = act->M;
+  MLMCPI_REQUIRE(M <= 4096, "exact sampler: M_lat = %u needs a dense %u x %u factor (limit 4096)", M, M, M);
+  const double a = act->T_final / M, d = a * act->m0 * act->mu2 + 2.0 * act->m0 / a, c = -act->m0 / a;
+  std::vector<double> row(M), L((size_t)M * M, 0.0);
+  for (uint32_t k = 0; k < M; ++k) {
+    double s = 0.0;
+    for (uint32_t m = 0; m < M; ++m) s += std::cos(2.0 * kPi * (double)((uint64_t)m * k % M) / M) / (d + 2.0 * c * std::cos(2.0 * kPi * m / M));
+    row[k] = s / M;
+  }
+  auto C = [&](uint32_t i, uint32_t j) { return row[(i + M - j) % M]; };
+  for (uint32_t i = 0; i < M; ++i)
+    for (uint32_t j = 0; j <= i; ++j) {
+      double s = C(i, j);
+      for (uint32_t k = 0; k < j; ++k) s -= L[(size_t)i * M + k] * L[(size_t)j * M + k];
+      if (i == j) {
+        if (!(s > 0.0)) return fail(MLMCPI_ERR_INVALID, "covariance matrix is not positive definite");
+        L[(size_t)i * M + i] = std::sqrt(s);
+      } else {
+        L[(size_t)i * M + j] = s / L[(size_t)j * M + j];
+      }
+    }
+  for (uint32_t j = 0; j < M; ++j)
+    for (uint32_t k = 0; k < M; ++k) h_LT[(size_t)k * M + j] = L[(size_t)j * M + k];
+  return MLMCPI_OK;
+}
+
+int mlmcpi_path_exact_draw(const mlmcpi_path_action *act, const double *d_LT, double *d_x, uint32_t B, uint64_t seed,
+                           uint32_t chain0, uint32_t step, void *stream) {
+  if (int rc = check_action(act)) return rc;
+  MLMCPI_REQUIRE(d_LT && d_x && B > 0, "bad arguments");
+  if (act->kind != MLMCPI_HARMONIC) return fail(MLMCPI_ERR_UNSUPPORTED, "exact sampler only for the harmonic oscillator action");
+  const uint32_t M = act->M;
+  const dim3 grid((M + 127) / 128, (B + 15) / 16);  // 4 waves x 2 site tiles x 16 sites = 128 sites per workgroup
+  hipLaunchKernelGGL(ho_exact_draw_kernel<2>, grid, dim3(256), 0, as_stream(stream), M, B, d_LT, d_x, make_key(seed, chain0, step));
+  MLMCPI_LAUNCH_CHECK("ho_exact_draw_kernel");
   return MLMCPI_OK;
 }
 

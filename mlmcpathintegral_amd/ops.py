@@ -141,6 +141,29 @@ class PathTwoLevelStep:
         return self.accept
 
 
+class HOExactSampler:
+    """HarmonicOscillatorAction::draw (the exact Gaussian sampler) on B device chains: x = L y on the fp64 matrix
+    cores; the Cholesky factor is built once on the host (mlmcpi_ho_cholesky_factor)."""
+
+    def __init__(self, act, B, seed=1, chain0=0, device="cuda"):
+        import numpy as np
+        self.act, self.B, self.seed, self.chain0 = act, B, seed, chain0
+        lt = np.zeros((act.M, act.M))
+        abi.call("mlmcpi_ho_cholesky_factor", C.byref(act), lt.ctypes.data_as(C.c_void_p))
+        self.LT_host = lt
+        self.LT = torch.from_numpy(lt).to(device)
+        self.step = 0
+
+    def draw(self, x=None):
+        if x is None:
+            x = torch.empty((self.B, self.act.M), dtype=torch.float64, device=self.LT.device)
+        _check_state(x, self.act.M)
+        abi.call("mlmcpi_path_exact_draw", C.byref(self.act), _p(self.LT), _p(x), self.B, self.seed, self.chain0, self.step,
+                 _stream())
+        self.step += 1
+        return x
+
+
 class LatticeTwoLevelStep:
     """TwoLevelMetropolisStep on the Schwinger lattice, semi-coarsening (ExpCos fill-in), B device chains."""
 

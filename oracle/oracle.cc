@@ -74,6 +74,7 @@ enum Purpose : uint32_t {
   P_FILLIN = 7,      // two-level step: Gaussian fill-in of fine-only sites (site = fine index)
   P_ACCEPT2 = 8,     // two-level step: Metropolis uniform
   P_BESSEL = 9,      // two-level step, Schwinger coarsened in both directions: Bessel-product fill-in (sub = call counter)
+  P_EXACT = 10,      // exact sampler of the harmonic oscillator: entries (2m, 2m+1) = Box-Muller pair of site m
 };
 
 inline double u01(uint32_t lo, uint32_t hi) {
@@ -1447,6 +1448,55 @@ int orc_dev_lattice_twolevel_draw(void *fine, void *coarse, const double *phi_co
 }
 double orc_expcos_pdf(double beta, double x, double x_p, double x_m) { return expcos_pdf(beta, x, x_p, x_m); }
 double orc_i0_scaled(double z) { return fast_bessel_i0_scaled(z); }
+
+// ---- exact sampler of the harmonic oscillator (harmonicoscillatoraction.cc:38-66) ---------------------------------
+// build_covariance: precision matrix Sigma(i,i) = a m0 mu2 + 2 m0/a, Sigma(i,i+-1) = -m0/a (periodic), L = chol(Sigma^-1).
+// The inverse is taken by Gauss-Jordan elimination here (Eigen's .inverse() in the reference), the factor by the
+// textbook Cholesky recursion.  L row-major [M][M].
+int orc_ho_cholesky(void *action, double *L) {
+  const ActionO &A = *(ActionO *)action;
+  if (A.kind != HARMONIC) return -1;
+  const unsigned M = A.M;
+  const double d = A.a * A.m0 * A.mu2 + 2.0 * A.m0 / A.a, c = -A.m0 / A.a;
+  std::vector<double> Q((size_t)M * M, 0.0), Cinv((size_t)M * M, 0.0);
+  for (unsigned i = 0; i < M; ++i) {
+    Q[(size_t)i * M + i] = d;
+    Q[(size_t)i * M + (i + 1) % M] += c;
+    Q[(size_t)i * M + (i + M - 1) % M] += c;
+    Cinv[(size_t)i * M + i] = 1.0;
+  }
+  for (unsigned col = 0; col < M; ++col) {  // Gauss-Jordan (Q is symmetric positive definite: no pivoting needed)
+    const double piv = Q[(size_t)col * M + col];
+    for (unsigned k = 0; k < M; ++k) { Q[(size_t)col * M + k] /= piv; Cinv[(size_t)col * M + k] /= piv; }
+    for (unsigned r = 0; r < M; ++r) {
+      if (r == col) continue;
+      const double f = Q[(size_t)r * M + col];
+      if (f == 0.0) continue;
+      for (unsigned k = 0; k < M; ++k) { Q[(size_t)r * M + k] -= f * Q[(size_t)col * M + k]; Cinv[(size_t)r * M + k] -= f * Cinv[(size_t)col * M + k]; }
+    }
+  }
+  std::fill(L, L + (size_t)M * M, 0.0);
+  for (unsigned i = 0; i < M; ++i)
+    for (unsigned j = 0; j <= i; ++j) {
+      double s = Cinv[(size_t)i * M + j];
+      for (unsigned k = 0; k < j; ++k) s -= L[(size_t)i * M + k] * L[(size_t)j * M + k];
+      L[(size_t)i * M + j] = (i == j) ? std::sqrt(s) : s / L[(size_t)j * M + j];
+    }
+  return 0;
+}
+// draw, device order: y_k from Philox (site k >> 1, P_EXACT, branch k & 1), x = L y
+void orc_dev_exact_draw(void *action, const double *L, double *x, uint64_t seed, uint32_t chain, uint32_t step) {
+  const ActionO &A = *(ActionO *)action;
+  const unsigned M = A.M;
+  DevRng r{(uint32_t)seed, (uint32_t)(seed >> 32), chain, step};
+  std::vector<double> y(M + 1);
+  for (unsigned m = 0; 2 * m < M; ++m) r.normals(m, P_EXACT, 0, y[2 * m], y[2 * m + 1]);
+  for (unsigned i = 0; i < M; ++i) {
+    double s = 0.0;
+    for (unsigned k = 0; k <= i; ++k) s += L[(size_t)i * M + k] * y[k];
+    x[i] = s;
+  }
+}
 
 // ---- transfers between lattice levels ------------------------------------------------------------------
 void orc_schwinger_copy_from_fine(int Mt, int Mx, int rt, int rx, const double *fine, double *coarse) {

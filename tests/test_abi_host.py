@@ -175,3 +175,31 @@ def test_statistics_match_compiled_reference(ref, orc):
     got = o.get()
     assert list(out) == [got[k] for k in ("average", "variance", "variance_error", "tau_int", "error", "samples")]
     ref.ref_stats_free(r)
+
+
+@pytest.mark.parametrize("M,T,m0,mu2", [(16, 4.0, 1.0, 1.0), (128, 4.0, 1.0, 1.0), (100, 10.0, 0.7, 2.0)])
+def test_ho_cholesky_factor_host(orc, M, T, m0, mu2):
+    """mlmcpi_ho_cholesky_factor runs on the host (no GPU): against the oracle's restatement of
+    HarmonicOscillatorAction::build_covariance (Gauss-Jordan inverse + Cholesky), against the defining property
+    L L^T Q = 1, and against the reference's closed form of <x^2> = (L L^T)_00 (harmonicoscillatoraction.cc:69-74)."""
+    import ctypes as C
+    from mlmcpathintegral_amd import abi
+    act = abi.path_action(abi.HARMONIC, M, T, m0, mu2)
+    LT = np.zeros((M, M))
+    abi.call("mlmcpi_ho_cholesky_factor", C.byref(act), LT.ctypes.data_as(C.c_void_p))
+    L = LT.T
+    assert np.allclose(np.triu(L, 1), 0.0)
+    A = orc.Action(orc.HARMONIC, M=M, T_final=T, m0=m0, mu2=mu2)
+    Lo = np.zeros((M, M))
+    assert orc.lib().orc_ho_cholesky(A.h, Lo.reshape(-1)) == 0
+    assert np.max(np.abs(L - Lo)) < 1e-12
+    a = T / M
+    Q = np.zeros((M, M))
+    for i in range(M):
+        Q[i, i] = a * m0 * mu2 + 2 * m0 / a
+        Q[i, (i + 1) % M] += -m0 / a
+        Q[i, (i - 1) % M] += -m0 / a
+    assert np.max(np.abs(L @ L.T @ Q - np.eye(M))) < 1e-10
+    assert abs((L @ L.T)[0, 0] - orc.lib().orc_ho_xsquared_analytical(M, T, m0, mu2)) < 1e-12
+    with pytest.raises(abi.MlmcpiError, match="only for the harmonic oscillator"):
+        abi.call("mlmcpi_ho_cholesky_factor", C.byref(abi.path_action(abi.ROTOR, M, T, 0.25)), LT.ctypes.data_as(C.c_void_p))

@@ -755,3 +755,23 @@ def test_schwinger_twolevel_step_errors(gpu_ops):
         gpu_ops.LatticeTwoLevelStep(f, abi.lattice_action(4, 16, 16, beta=1.0), 1)
     with pytest.raises(abi.MlmcpiError, match="only the quenched Schwinger"):
         gpu_ops.LatticeTwoLevelStep(abi.lattice_action(3, 16, 16, mass=1.0), abi.lattice_action(3, 8, 8, mass=1.0), 1)
+
+
+@pytest.mark.parametrize("M,B", [(128, 40), (100, 5), (16, 16), (512, 33)])
+def test_ho_exact_sampler_matches_oracle(gpu_ops, orc, M, B):
+    """HarmonicOscillatorAction::draw (x = L y, harmonicoscillatoraction.cc:59-66) on the fp64 matrix cores
+    (v_mfma_f64_16x16x4_f64; ragged chain and site counts included) against the oracle's device-order draw."""
+    from mlmcpathintegral_amd import abi
+    p = dict(M=M, T_final=M / 32.0, m0=1.0, mu2=1.0)
+    act, A = make_path(orc, "harmonic", p)
+    sampler = gpu_ops.HOExactSampler(act, B, seed=SEED, chain0=3)
+    Lo = np.zeros((M, M))
+    assert orc.lib().orc_ho_cholesky(A.h, Lo.reshape(-1)) == 0
+    for step in range(2):
+        x = sampler.draw().cpu().numpy()
+        for b in range(B):
+            want = np.zeros(M)
+            orc.lib().orc_dev_exact_draw(A.h, Lo.reshape(-1), want, SEED, 3 + b, step)
+            assert_close(x[b], want, tol=1e-11, scale=1.0, what=f"exact draw step {step} chain {b}")
+    with pytest.raises(abi.MlmcpiError, match="only for the harmonic oscillator"):
+        gpu_ops.HOExactSampler(abi.path_action(abi.QUARTIC, 64, 8.0, 1.0, 1.0, 1.0, 1.0), 4)

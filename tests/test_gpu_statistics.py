@@ -282,3 +282,27 @@ def test_batched_mlmc_quartic_five_levels_matches_single_level(gpu_ops):
           f"level means {table[:, 1].tolist()}; acceptance {est.p_accept()}")
     assert p_fine > 0.3
     assert abs(q - m) < 4 * math.hypot(e, em)
+
+
+def test_ho_exact_sampler_covariance(gpu_ops):
+    """The exact sampler draws independent paths from N(0, Q^-1): <x^2> against the closed form and the two-point
+    function <x_0 x_k> against the first column of L L^T, from 8192 chains x 8 draws."""
+    from mlmcpathintegral_amd import abi
+    import oracle
+    M, T, B = 128, 4.0, 8192
+    act = abi.path_action(abi.HARMONIC, M, T, 1.0, 1.0)
+    s = gpu_ops.HOExactSampler(act, B, seed=SEED)
+    cov = s.LT_host.T @ s.LT_host          # L L^T
+    x2, c0k = [], []
+    for _ in range(8):
+        x = s.draw()
+        x2.append(gpu_ops.qoi_xsquared(x))
+        c0k.append((x[:, :1] * x).mean(dim=0))
+    x2 = torch.stack(x2).reshape(-1)
+    m, e = float(x2.mean()), float(x2.std(unbiased=True)) / math.sqrt(x2.numel())
+    exact = oracle.lib().orc_ho_xsquared_analytical(M, T, 1.0, 1.0)
+    print(f"exact sampler <x^2> = {m:.6f} +- {e:.6f} (closed form {exact:.6f})")
+    assert abs(m - exact) < 4 * e
+    c = torch.stack(c0k).mean(dim=0).cpu().numpy()
+    err = 4 * math.sqrt(2.0) * cov[0, 0] / math.sqrt(8 * B)   # generous bound on the sampling error of a covariance entry
+    assert np.max(np.abs(c - cov[0])) < err
