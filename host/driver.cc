@@ -80,7 +80,7 @@ int main(int argc, char **argv) {
       hp.nt = (unsigned)num("nt"); hp.dt = num("dt"); hp.n_burnin = (unsigned)num("n_burnin"); hp.autotune = num("autotune") != 0;
       return std::make_shared<HMCSamplerFactory>(hp);
     }
-    if (name == "exact") return std::make_shared<ExactSamplerFactory>();  // driver_qm.cc: sampler = 'exact' (HO only)
+    if (name == "exact") return std::make_shared<ExactSamplerFactory>();  // driver_qm.cc: sampler = 'exact' (harmonic oscillator, GFF)
     if (name != "heatbath") fatal("unknown sampler " + name);
     OverrelaxedHeatBathParameters hb;
     hb.n_sweep_overrelax = (unsigned)num("n_sweep_overrelax"); hb.n_sweep_heatbath = (unsigned)num("n_sweep_heatbath");

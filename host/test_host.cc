@@ -152,6 +152,28 @@ int main(int argc, char **argv) {
     EXPECT(std::fabs(st->average() - act->Xsquared_analytical()) < 5 * st->error(), "exact sampler <x^2>");
     EXPECT(st->tau_int() < 1.2, "exact sampler draws are independent");
   }
+  // ---- GFF 64 x 64: exact sampler (spectral synthesis) and heat-bath sampler started from an exact draw ------------
+  {
+    auto lat = std::make_shared<Lattice2D>(64, 64, CoarsenBoth);
+    auto act = std::make_shared<GFFAction>(lat, nullptr, 10.0);
+    const double exact = gff_phi_squared_analytical(10.0, 64, 64);
+    SingleLevelMCParameters mp;
+    mp.n_burnin = 10; mp.n_samples = 4000;
+    MonteCarloSingleLevel mc(act, std::make_shared<QoI2DPhiSquared>(lat), std::make_shared<ExactSamplerFactory>(), mp);
+    mc.evaluate();
+    auto st = mc.get_statistics();
+    std::printf(" GFF exact sampler: <phi^2> = %.6f +- %.6f (analytic %.6f), tau_int %.3f\n", st->average(), st->error(), exact,
+                st->tau_int());
+    EXPECT(std::fabs(st->average() - exact) < 5 * st->error(), "GFF exact sampler <phi^2>");
+    OverrelaxedHeatBathParameters hb;
+    hb.n_sweep_heatbath = 1; hb.n_sweep_overrelax = 2; hb.n_burnin = 0;   // initialise_state is an exact draw: no burn-in needed
+    mp.n_burnin = 0; mp.n_samples = 3000; mp.n_autocorr_window = 50;
+    MonteCarloSingleLevel mh(act, std::make_shared<QoI2DPhiSquared>(lat), std::make_shared<OverrelaxedHeatBathSamplerFactory>(hb), mp);
+    mh.evaluate();
+    auto sh = mh.get_statistics();
+    std::printf(" GFF heat bath from an exact initial state: <phi^2> = %.6f +- %.6f\n", sh->average(), sh->error());
+    EXPECT(std::fabs(sh->average() - exact) < 5 * std::fmax(sh->error(), 2e-3), "GFF heat bath <phi^2> without burn-in");
+  }
   // ---- Schwinger 16x16: OverrelaxedHeatBathSampler through the estimator loop, batch of chains ---------
   {
     auto lat = std::make_shared<Lattice2D>(16, 16, CoarsenBoth);

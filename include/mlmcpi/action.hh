@@ -158,6 +158,18 @@ public:
   const double mu2, lambda, x0;
 };
 
+/** common/auxilliary.cc:197-209: <phi^2> of the Gaussian free field on the periodic Mt x Mx lattice */
+inline double gff_phi_squared_analytical(const double mass, const int Mt_lat, const int Mx_lat) {
+  const double mu2 = mass * mass / (1.0 * Mt_lat * Mx_lat);
+  double s = 0.0;
+  for (int k1 = 0; k1 < Mt_lat; ++k1)
+    for (int k2 = 0; k2 < Mx_lat; ++k2) {
+      const double s1 = std::sin(M_PI * k1 / Mt_lat), s2 = std::sin(M_PI * k2 / Mx_lat);
+      s += 1. / (4. * (s1 * s1 + s2 * s2) + mu2);
+    }
+  return s / (1.0 * Mt_lat * Mx_lat);
+}
+
 /** common/auxilliary.cc:7-27: ratio of theta-function sums  sum_m m^p exp(-xi m^2/2) / sum_m exp(-xi m^2/2), m in Z
  *  (99 terms on each side, as in the reference) */
 inline double Sigma_hat(const double xi, const unsigned int p) {

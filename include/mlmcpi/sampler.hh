@@ -259,10 +259,43 @@ private:
   uint32_t step = 0;
 };
 
+/** The exact sampler of the Gaussian free field (GFFAction is a Sampler in the reference, gffaction.hh:120,
+ *  draw at gffaction.cc:200-213): spectral synthesis on the device, mlmcpi_lattice_exact_draw. */
+class GFFExactSampler : public Sampler {
+public:
+  GFFExactSampler(const std::shared_ptr<Action> action_, unsigned int batch = 1)
+      : Sampler(), action(std::dynamic_pointer_cast<GFFAction>(action_)), B(batch) {
+    if (!action) fatal("exact sampler only for the GFF action");
+    size_t bytes = 0;
+    check(mlmcpi_lattice_exact_workspace_bytes(&action->abi_action(), B, &bytes), "lattice_exact_workspace_bytes");
+    check(mlmcpi_malloc(&work, bytes), "mlmcpi_malloc");
+    state = std::make_shared<SampleState>(action->sample_size(), B);
+  }
+  ~GFFExactSampler() { mlmcpi_free(work); }
+  void draw(std::shared_ptr<SampleState> phi_state) override {
+    check(mlmcpi_lattice_exact_draw(&action->abi_action(), state->device_mutable(), B, action->get_seed() ^ 0x45584143ull,
+                                    action->get_chain0(), step++, work, nullptr), "lattice_exact_draw");
+    accept = true;
+    n_total_samples++;
+    n_accepted_samples++;
+    phi_state->data = state->data;
+  }
+  void set_state(std::shared_ptr<SampleState>) override {}
+
+private:
+  const std::shared_ptr<GFFAction> action;
+  const unsigned int B;
+  void *work = nullptr;
+  std::shared_ptr<SampleState> state;
+  uint32_t step = 0;
+};
+
+/** sampler = 'exact' (driver_qm.cc / driver_qft.cc): the harmonic oscillator and the GFF are their own samplers */
 class ExactSamplerFactory : public SamplerFactory {
 public:
   explicit ExactSamplerFactory(unsigned int batch_ = 1) : batch(batch_) {}
   std::shared_ptr<Sampler> get(std::shared_ptr<Action> action) override {
+    if (std::dynamic_pointer_cast<GFFAction>(action)) return std::make_shared<GFFExactSampler>(action, batch);
     return std::make_shared<HarmonicOscillatorExactSampler>(action, batch);
   }
 private:

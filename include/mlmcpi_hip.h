@@ -177,9 +177,9 @@ int mlmcpi_lattice_evaluate(const mlmcpi_lattice_action *act, const double *d_ph
                             void *stream);
 int mlmcpi_lattice_force(const mlmcpi_lattice_action *act, const double *d_phi, double *d_f, uint32_t B,
                          void *stream);
-/* Schwinger: U(-pi,pi) per link (quenchedschwingeraction.cc:198-204).  GFF: N(0,1) per vertex (the
- * reference's exact Cholesky draw, gffaction.cc:121-123, needs a dense N x N inverse and is out of
- * scope). */
+/* Schwinger: U(-pi,pi) per link (quenchedschwingeraction.cc:198-204).  GFF: an exact draw from the action's
+ * distribution, as in the reference (gffaction.cc:121-123: initialise_state = draw) -- by spectral synthesis
+ * (see mlmcpi_lattice_exact_draw; its own Philox sub-stream) instead of the reference's sparse Cholesky solve. */
 int mlmcpi_lattice_initialise(const mlmcpi_lattice_action *act, double *d_phi, uint32_t B, uint64_t seed,
                               uint32_t chain0, void *stream);
 /* OverrelaxedHeatBathSampler::draw on a 2-D action: n_overrelax overrelaxation sweeps then
@@ -225,6 +225,15 @@ int mlmcpi_lattice_twolevel_draw(const mlmcpi_lattice_action *fine, const mlmcpi
                                  const double *d_phi_coarse, double *d_theta, uint32_t B, uint64_t seed,
                                  uint32_t chain0, uint32_t step, void *d_work, int32_t *d_accept, double *d_terms,
                                  void *stream);
+/* Exact sampler of the Gaussian free field: GFFAction::draw / initialise_state (action/qft/gffaction.cc:121-123,
+ * 200-213; the reference goes through a sparse Cholesky factor built by Eigen, which it cannot build beyond ~64^2).
+ * On the periodic lattice the precision matrix is diagonal in Fourier space, so the draw is a spectral synthesis:
+ *   phi(x) = Re sum_k (n0_k + i n1_k) e^{+i k x} / sqrt(N lambda(k)),  lambda(k) = 4 + mu2 - 2 cos(2 pi k_t/Mt) - 2 cos(2 pi k_x/Mx),
+ * normals of mode l = k_x Mt + k_t from Philox (site l, purpose P_EXACT, step `step`); batched 2-D inverse FFT (hipFFT).
+ * d_work: mlmcpi_lattice_exact_workspace_bytes (one complex field per chain). */
+int mlmcpi_lattice_exact_workspace_bytes(const mlmcpi_lattice_action *act, uint32_t B, size_t *bytes);
+int mlmcpi_lattice_exact_draw(const mlmcpi_lattice_action *act, double *d_phi, uint32_t B, uint64_t seed, uint32_t chain0,
+                              uint32_t step, void *d_work, void *stream);
 /* QoI2DPhiSquared (qoi/qft/qoi2dphisquared.cc:8-15), QoIAvgPlaquette (qoi/qft/qoiavgplaquette.cc:8-27),
  * QoI2DSusceptibility (qoi/qft/qoi2dsusceptibility.cc:8-27); d_out[b]. */
 int mlmcpi_qoi_phi_squared(const double *d_phi, uint32_t n_vertices, uint32_t B, double *d_out, void *stream);

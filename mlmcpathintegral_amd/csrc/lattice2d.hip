@@ -9,7 +9,10 @@
 // RNG makes those recomputations bit-identical.  Per sweep HBM sees ~(1 + halo overhead) reads and
 // one write of every entry -- instead of the 4-5 passes of one-kernel-per-colour -- and k fused
 // sweeps divide that by k.
+#include <algorithm>
 #include <mutex>
+
+#include <hipfft/hipfft.h>
 #include <stdio.h>
 #include <string.h>
 #include <stdlib.h>
@@ -1011,10 +1014,14 @@ int mlmcpi_lattice_force(const mlmcpi_lattice_action *act, const double *d_phi, 
   return MLMCPI_OK;
 }
 
+static int gff_initialise_exact(const mlmcpi_lattice_action *act, double *d_phi, uint32_t B, uint64_t seed, uint32_t chain0,
+                                hipStream_t st);
+
 int mlmcpi_lattice_initialise(const mlmcpi_lattice_action *act, double *d_phi, uint32_t B, uint64_t seed,
                               uint32_t chain0, void *stream) {
   if (int rc = check_lattice(act)) return rc;
   MLMCPI_REQUIRE(d_phi && B > 0, "bad arguments");
+  if (act->kind == MLMCPI_GFF) return gff_initialise_exact(act, d_phi, B, seed, chain0, as_stream(stream));
   uint32_t n = 0;
   mlmcpi_lattice_state_size(act, &n);
   uint32_t nb = (n + 255) / 256;
@@ -1843,6 +1850,113 @@ int mlmcpi_lattice_twolevel_draw(const mlmcpi_lattice_action *fine, const mlmcpi
   hipLaunchKernelGGL(lattice_twolevel_accept_kernel, dim3(nb, B), dim3(256), 0, st, (uint32_t)nf, d_theta,
                      (const double *)theta_prime, (const double *)en4, (const double *)cfa, nblk, B, d_accept, d_terms, key);
   MLMCPI_LAUNCH_CHECK("lattice_twolevel_accept_kernel");
+  return MLMCPI_OK;
+}
+
+}  // extern "C"
+
+// =================================================================================================
+// Exact sampler of the Gaussian free field: GFFAction::draw / initialise_state (action/qft/gffaction.cc:121-123,
+// 200-213).  The reference solves with a sparse Cholesky factor of the precision matrix Q = (4 + mu2) 1 - A built by
+// Eigen (infeasible beyond ~64^2).  On the periodic lattice Q is diagonal in Fourier space,
+//   lambda(k) = 4 + mu2 - 2 cos(2 pi k_t / Mt) - 2 cos(2 pi k_x / Mx),
+// so a draw from N(0, Q^-1) is  phi(x) = Re sum_k w_k e^{+i k x} / sqrt(N lambda(k))  with w_k = n0 + i n1 complex
+// white noise (E |w|^2 = 2; then E phi(x) phi(y) = (1/N) sum_k cos(k (x - y)) / lambda(k) = (Q^-1)_xy): one kernel
+// fills the spectrum from Philox (site = mode index, purpose P_EXACT), hipFFT does the batched 2-D inverse
+// transform in place, one kernel keeps the real part.  O(N log N) per chain at any lattice size.
+// =================================================================================================
+namespace mlmcpi {
+
+__global__ void __launch_bounds__(256)
+    gff_spectrum_kernel(uint32_t Mt, uint32_t Mx, double mu2, double2 *__restrict__ w_all, RngKey key0, uint32_t sub) {
+  const uint32_t b = blockIdx.y, n = Mt * Mx;
+  RngKey key = key0;
+  key.chain += b;
+  double2 *w = w_all + (size_t)b * n;
+  const double inv_n = 1.0 / (double)n;
+  for (uint32_t l = blockIdx.x * blockDim.x + threadIdx.x; l < n; l += gridDim.x * blockDim.x) {
+    const uint32_t kx = l / Mt, kt = l - kx * Mt;  // same layout as the field: mode (kt, kx) at kx * Mt + kt
+    const double lambda = 4.0 + mu2 - 2.0 * cos(kTwoPi * kt / Mt) - 2.0 * cos(kTwoPi * kx / Mx);
+    double n0, n1;
+    rng_normals(key, l, P_EXACT, sub, n0, n1);
+    const double s = sqrt(inv_n / lambda);
+    w[l] = make_double2(s * n0, s * n1);
+  }
+}
+
+__global__ void __launch_bounds__(256)
+    gff_real_part_kernel(uint32_t n, const double2 *__restrict__ w_all, double *__restrict__ phi_all) {
+  const uint32_t b = blockIdx.y;
+  const double2 *w = w_all + (size_t)b * n;
+  double *phi = phi_all + (size_t)b * n;
+  for (uint32_t l = blockIdx.x * blockDim.x + threadIdx.x; l < n; l += gridDim.x * blockDim.x) phi[l] = w[l].x;
+}
+
+}  // namespace mlmcpi
+
+extern "C" {
+
+int mlmcpi_lattice_exact_workspace_bytes(const mlmcpi_lattice_action *act, uint32_t B, size_t *bytes) {
+  if (int rc = check_lattice(act)) return rc;
+  MLMCPI_REQUIRE(bytes && B > 0, "bad arguments");
+  if (act->kind != MLMCPI_GFF) return fail(MLMCPI_ERR_UNSUPPORTED, "exact sampler only for the GFF action");
+  *bytes = (size_t)B * act->Mt * act->Mx * sizeof(double2);
+  return MLMCPI_OK;
+}
+
+// one batch of chains: spectrum -> inverse FFT (in place, d_work) -> real part
+static int gff_exact_batch(const mlmcpi_lattice_action *act, double *d_phi, uint32_t B, uint64_t seed, uint32_t chain0,
+                           uint32_t step, uint32_t sub, void *d_work, hipStream_t st) {
+  const uint32_t n = act->Mt * act->Mx;
+  // one cached plan per (Mt, Mx, B): plan creation costs milliseconds
+  static std::mutex guard;
+  static hipfftHandle plan = 0;
+  static uint32_t p_mt = 0, p_mx = 0, p_b = 0;
+  std::lock_guard<std::mutex> lock(guard);
+  if (!plan || p_mt != act->Mt || p_mx != act->Mx || p_b != B) {
+    if (plan) hipfftDestroy(plan);
+    plan = 0;
+    int dims[2] = {(int)act->Mx, (int)act->Mt};  // slowest index first
+    if (hipfftPlanMany(&plan, 2, dims, nullptr, 1, (int)n, nullptr, 1, (int)n, HIPFFT_Z2Z, (int)B) != HIPFFT_SUCCESS) {
+      plan = 0;
+      return fail(MLMCPI_ERR_HIP, "hipfftPlanMany failed for %u x %u x %u", act->Mt, act->Mx, B);
+    }
+    p_mt = act->Mt; p_mx = act->Mx; p_b = B;
+  }
+  if (hipfftSetStream(plan, st) != HIPFFT_SUCCESS) return fail(MLMCPI_ERR_HIP, "hipfftSetStream failed");
+  uint32_t nb = (n + 255) / 256;
+  if (nb > 1024) nb = 1024;
+  hipLaunchKernelGGL(gff_spectrum_kernel, dim3(nb, B), dim3(256), 0, st, act->Mt, act->Mx, gff_mu2(*act), (double2 *)d_work,
+                     make_key(seed, chain0, step), sub);
+  MLMCPI_LAUNCH_CHECK("gff_spectrum_kernel");
+  if (hipfftExecZ2Z(plan, (hipfftDoubleComplex *)d_work, (hipfftDoubleComplex *)d_work, HIPFFT_BACKWARD) != HIPFFT_SUCCESS)
+    return fail(MLMCPI_ERR_HIP, "hipfftExecZ2Z failed");
+  hipLaunchKernelGGL(gff_real_part_kernel, dim3(nb, B), dim3(256), 0, st, n, (const double2 *)d_work, d_phi);
+  MLMCPI_LAUNCH_CHECK("gff_real_part_kernel");
+  return MLMCPI_OK;
+}
+
+int mlmcpi_lattice_exact_draw(const mlmcpi_lattice_action *act, double *d_phi, uint32_t B, uint64_t seed, uint32_t chain0,
+                              uint32_t step, void *d_work, void *stream) {
+  if (int rc = check_lattice(act)) return rc;
+  MLMCPI_REQUIRE(d_phi && d_work && B > 0, "bad arguments");
+  if (act->kind != MLMCPI_GFF) return fail(MLMCPI_ERR_UNSUPPORTED, "exact sampler only for the GFF action");
+  return gff_exact_batch(act, d_phi, B, seed, chain0, step, 0, d_work, as_stream(stream));
+}
+
+// GFFAction::initialise_state = draw (gffaction.cc:121-123): the exact sampler with its own Philox sub-stream, in
+// batches of chains that keep the library scratch below 256 MiB
+static int gff_initialise_exact(const mlmcpi_lattice_action *act, double *d_phi, uint32_t B, uint64_t seed, uint32_t chain0,
+                                hipStream_t st) {
+  const size_t per_chain = (size_t)act->Mt * act->Mx * sizeof(double2);
+  uint32_t chunk = (uint32_t)std::max<size_t>(1, ((size_t)256 << 20) / per_chain);
+  if (chunk > B) chunk = B;
+  void *work = nullptr;
+  if (int rc = scratch((size_t)chunk * per_chain, &work)) return rc;
+  for (uint32_t b0 = 0; b0 < B; b0 += chunk) {
+    const uint32_t nb = std::min(chunk, B - b0);
+    if (int rc = gff_exact_batch(act, d_phi + (size_t)b0 * act->Mt * act->Mx, nb, seed, chain0 + b0, 0, 1, work, st)) return rc;
+  }
   return MLMCPI_OK;
 }
 

@@ -164,6 +164,26 @@ class HOExactSampler:
         return x
 
 
+class GFFExactSampler:
+    """GFFAction::draw (exact Gaussian sampler) on B device chains by spectral synthesis (batched 2-D FFT)."""
+
+    def __init__(self, act, B, seed=1, chain0=0, device="cuda"):
+        self.act, self.B, self.seed, self.chain0 = act, B, seed, chain0
+        nbytes = C.c_size_t(0)
+        abi.call("mlmcpi_lattice_exact_workspace_bytes", C.byref(act), B, C.byref(nbytes))
+        self.work = torch.empty(nbytes.value, dtype=torch.uint8, device=device)
+        self.step = 0
+
+    def draw(self, phi=None):
+        if phi is None:
+            phi = torch.empty((self.B, self.act.Mt * self.act.Mx), dtype=torch.float64, device=self.work.device)
+        _check_state(phi, self.act.Mt * self.act.Mx)
+        abi.call("mlmcpi_lattice_exact_draw", C.byref(self.act), _p(phi), self.B, self.seed, self.chain0, self.step,
+                 _p(self.work), _stream())
+        self.step += 1
+        return phi
+
+
 class LatticeTwoLevelStep:
     """TwoLevelMetropolisStep on the Schwinger lattice, semi-coarsening (ExpCos fill-in), B device chains."""
 

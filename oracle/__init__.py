@@ -82,6 +82,7 @@ _SIGS = {
     "orc_i0_scaled": (_d, [_d]),
     "orc_ho_cholesky": (_i, [_vp, _dp]),
     "orc_dev_exact_draw": (None, [_vp, _dp, _dp, _u64, _u32, _u32]),
+    "orc_dev_gff_exact_draw": (None, [_vp, _dp, _u64, _u32, _u32]),
     "orc_schwinger_copy_from_fine": (None, [_i, _i, _i, _i, _dp, _dp]),
     "orc_schwinger_copy_from_coarse": (None, [_i, _i, _i, _i, _dp, _dp]),
     "orc_gff_transfer": (None, [_i, _i, _i, _i, _dp, _dp, _i]),

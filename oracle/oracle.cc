@@ -1077,6 +1077,34 @@ int dev_schwinger_twolevel_draw(const ActionO &F, const ActionO &Cc, const doubl
   return twolevel_decide(dS_fine, dS_coarse, dS_trial, rng, tp, theta, terms);
 }
 
+// Exact draw of the Gaussian free field by spectral synthesis, device order (include/mlmcpi_hip.h): direct O(N^2)
+// evaluation of phi(x) = Re sum_k w_k e^{+i k x} / sqrt(N lambda(k)); only for small lattices.  sub = 0: draws,
+// sub = 1: initialise_state (gffaction.cc:121-123: the initial state is an exact draw).
+void dev_gff_exact(const ActionO &A, double *phi, uint64_t seed, uint32_t chain, uint32_t step, uint32_t sub) {
+  const int Mt = A.g.Mt, Mx = A.g.Mx, N = Mt * Mx;
+  DevRng r{(uint32_t)seed, (uint32_t)(seed >> 32), chain, step};
+  std::vector<double> wr(N), wi(N);
+  for (int l = 0; l < N; ++l) {
+    const int kx = l / Mt, kt = l - kx * Mt;
+    const double lambda = 4.0 + A.gff_mu2 - 2.0 * std::cos(2. * kPi * kt / Mt) - 2.0 * std::cos(2. * kPi * kx / Mx);
+    double n0, n1;
+    r.normals((uint32_t)l, P_EXACT, sub, n0, n1);
+    const double s = std::sqrt(1.0 / ((double)N * lambda));
+    wr[l] = s * n0;
+    wi[l] = s * n1;
+  }
+  for (int j = 0; j < Mx; ++j)
+    for (int i = 0; i < Mt; ++i) {
+      double acc = 0.0;
+      for (int l = 0; l < N; ++l) {
+        const int kx = l / Mt, kt = l - kx * Mt;
+        const double ph = 2. * kPi * ((double)((kt * i) % Mt) / Mt + (double)((kx * j) % Mx) / Mx);
+        acc += wr[l] * std::cos(ph) - wi[l] * std::sin(ph);
+      }
+      phi[j * Mt + i] = acc;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Reference-order samplers.
 // ---------------------------------------------------------------------------------------------
@@ -1419,6 +1447,10 @@ int orc_dev_hmc_trajectory(void *action, double *x, unsigned nt, double dt, uint
 // N(0,1) for GFF, zeros for HO / quartic.
 void orc_dev_initialise(void *action, double *x, uint64_t seed, uint32_t chain) {
   ActionO *A = (ActionO *)action;
+  if (A->kind == GFF) {
+    dev_gff_exact(*A, x, seed, chain, 0, 1);
+    return;
+  }
   DevRng r{(uint32_t)seed, (uint32_t)(seed >> 32), chain, 0};
   for (unsigned l = 0; l < A->size(); ++l) {
     if (A->kind == ROTOR || A->kind == SCHWINGER) {
@@ -1496,6 +1528,10 @@ void orc_dev_exact_draw(void *action, const double *L, double *x, uint64_t seed,
     for (unsigned k = 0; k <= i; ++k) s += L[(size_t)i * M + k] * y[k];
     x[i] = s;
   }
+}
+
+void orc_dev_gff_exact_draw(void *action, double *phi, uint64_t seed, uint32_t chain, uint32_t step) {
+  dev_gff_exact(*(ActionO *)action, phi, seed, chain, step, 0);
 }
 
 // ---- transfers between lattice levels ------------------------------------------------------------------

@@ -775,3 +775,20 @@ def test_ho_exact_sampler_matches_oracle(gpu_ops, orc, M, B):
             assert_close(x[b], want, tol=1e-11, scale=1.0, what=f"exact draw step {step} chain {b}")
     with pytest.raises(abi.MlmcpiError, match="only for the harmonic oscillator"):
         gpu_ops.HOExactSampler(abi.path_action(abi.QUARTIC, 64, 8.0, 1.0, 1.0, 1.0, 1.0), 4)
+
+
+@pytest.mark.parametrize("Mt,mass,B", [(4, 2.0, 3), (8, 10.0, 2), (16, 1.0, 2)])
+def test_gff_exact_sampler_matches_oracle(gpu_ops, orc, Mt, mass, B):
+    """GFFAction::draw by spectral synthesis (batched 2-D FFT) against the oracle's direct O(N^2) evaluation of the
+    same Fourier sum with the same Philox normals."""
+    from mlmcpathintegral_amd import abi
+    act, A = make_lattice(orc, "gff", Mt, Mt, mass=mass)
+    s = gpu_ops.GFFExactSampler(act, B, seed=SEED, chain0=2)
+    for step in range(2):
+        phi = s.draw().cpu().numpy()
+        for b in range(B):
+            want = np.zeros(Mt * Mt)
+            orc.lib().orc_dev_gff_exact_draw(A.h, want, SEED, 2 + b, step)
+            assert_close(phi[b], want, tol=1e-12, scale=float(np.max(np.abs(want))), what=f"GFF exact draw {step} chain {b}")
+    with pytest.raises(abi.MlmcpiError, match="only for the GFF"):
+        gpu_ops.GFFExactSampler(abi.lattice_action(4, 8, 8, beta=1.0), 1)

@@ -306,3 +306,28 @@ def test_ho_exact_sampler_covariance(gpu_ops):
     c = torch.stack(c0k).mean(dim=0).cpu().numpy()
     err = 4 * math.sqrt(2.0) * cov[0, 0] / math.sqrt(8 * B)   # generous bound on the sampling error of a covariance entry
     assert np.max(np.abs(c - cov[0])) < err
+
+
+@pytest.mark.parametrize("M,mass,B", [(16, 10.0, 4096), (64, 10.0, 256), (512, 10.0, 16)])
+def test_gff_exact_sampler_and_sweeps_share_the_distribution(gpu_ops, M, mass, B):
+    """<phi^2> of exact draws against gff_phi_squared_analytical (the reference's closed form, restated in the oracle),
+    up to the BASELINE size 512^2 where the reference's own exact sampler cannot be built -- and the
+    overrelaxed heat-bath sweeps must leave that distribution invariant: <phi^2> after 3 x (2 OR + 1 HB) sweeps on the
+    exact draws agrees as well (a check of the sweep kernels at 512^2 that needs no thermalisation)."""
+    from mlmcpathintegral_amd import abi
+    import oracle
+    act = abi.lattice_action(abi.GFF, M, M, mass=mass)
+    s = gpu_ops.GFFExactSampler(act, B, seed=SEED)
+    exact = oracle.lib().orc_gff_phi_squared_analytical(mass, M, M)
+    draws = torch.stack([gpu_ops.qoi_phi_squared(s.draw()) for _ in range(8)]).reshape(-1)
+    m, e = float(draws.mean()), float(draws.std(unbiased=True)) / math.sqrt(draws.numel())
+    phi = s.draw()
+    scratch = torch.empty_like(phi)
+    gpu_ops.lattice_sweep_draw(act, phi, scratch, 2, 1, SEED, 0, 0)
+    gpu_ops.lattice_sweep_draw(act, phi, scratch, 2, 1, SEED, 0, 3)
+    gpu_ops.lattice_sweep_draw(act, phi, scratch, 2, 1, SEED, 0, 6)
+    q = gpu_ops.qoi_phi_squared(phi)
+    ms, es = float(q.mean()), float(q.std(unbiased=True)) / math.sqrt(q.numel())
+    print(f"GFF {M}^2: <phi^2> exact draws {m:.6f} +- {e:.6f}, after sweeps {ms:.6f} +- {es:.6f}, closed form {exact:.6f}")
+    assert abs(m - exact) < 4 * e
+    assert abs(ms - exact) < 4 * es
