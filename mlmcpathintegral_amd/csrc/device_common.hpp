@@ -259,73 +259,102 @@ __device__ __forceinline__ double rng_normal0(const RngKey &k, uint32_t site, ui
 // 1024^2 x batch sweep some link always has kappa ~ 1e-8 (~1e4 attempts) and stalls the whole
 // launch.  The device samples the SAME distribution with the wrapped-Cauchy envelope of Best &
 // Fisher (Appl. Statist. 28 (1979) 152-157): acceptance >= 0.65 for every kappa, one cosine per
-// attempt, one arccosine per draw.  Attempt t uses Philox counter word 3 = P_VONMISES<<24 | t.
-// cos(pi u) for u in [0, 1]: cos(pi u) = sin(pi t), t = 1/2 - u.  Both Taylor kernels on
-// |x| <= pi/4 are evaluated and one is selected (no divergence, no double-double range reduction:
-// ~25 fp64 instructions against ~175 for the general cos()).  Truncation error < 1e-17.
+// attempt, one arccosine per draw.
+//
+// Arithmetic.  Best & Fisher's envelope parameter r = (1 + rho^2) / (2 rho) simplifies to r = (1 + s) / (2 kappa) with
+// s = sqrt(1 + 4 kappa^2); everything is written in R = kappa r = (1 + s) / 2 (one square root, no division, finite as
+// kappa -> 0):   z = cos(pi u1),  f = cos(theta) = (kappa + R z) / (R + kappa z),  c = R - kappa f in (1/2, R + kappa],
+// accept with probability c exp(1 - c).
+//
+// Random numbers.  ONE Philox call (counter word 3 = P_VONMISES << 24 | sub0 | t, t = 0, 1, ...) feeds TWO attempts,
+// 2t from words (x, y) and 2t + 1 from (z, w).  Of the 64 bits v = hi:lo of an attempt
+//     bits 12..63  u1 = (v >> 12) 2^-52           the proposal,
+//     bit  0       the sign of the angle,
+//     bits 1..11   b                               the leading 11 bits of the acceptance uniform u2 = (b + u2') / 2048.
+// b alone decides the test unless c exp(1 - c) falls into [b, b + 1) / 2048 (about one attempt in 10^3); only then is
+// the tail u2' (53 bits) taken from a second call (word 3 | kVmRefine), and the decision is the exact fp64 one
+// (c (2 - c) > u2 or log(c / u2) + 1 - c >= 0).  The screening test runs in fp32 (hardware exp) with a guard band that
+// covers the fp32 rounding, so whichever tier decides, the decision is the one the exact test would take.
+
+// cos(pi u) for u in [0, 1]: cos(pi u) = sin(x), x = pi (1/2 - u), |x| <= pi/2; degree-21 Taylor polynomial
+// (truncation < 1.3e-18).  15 fp64 instructions against ~175 for the general cos().
 __device__ __forceinline__ double cospi_unit(double u) {
-  const double t = 0.5 - u;
-  const double at = fabs(t);
-  const bool outer = at > 0.25;
-  const double x = kPi * (outer ? 0.5 - at : t);  // |x| <= pi/4
+  const double x = kPi * (0.5 - u);
   const double x2 = x * x;
-  double sp = -7.6471637318198164759e-13;                 // -1/15!
-  sp = fma_k(sp, x2, 1.6059043836821614599e-10);             //  1/13!
-  sp = fma_k(sp, x2, -2.5052108385441718775e-08);            // -1/11!
-  sp = fma_k(sp, x2, 2.7557319223985890653e-06);             //  1/9!
-  sp = fma_k(sp, x2, -1.9841269841269841270e-04);            // -1/7!
-  sp = fma_k(sp, x2, 8.3333333333333333333e-03);             //  1/5!
-  sp = fma_k(sp, x2, -1.6666666666666666667e-01);            // -1/3!
-  const double sinx = fma(x * x2, sp, x);
-  double cp = 4.7794773323873852974e-14;                  //  1/16!
-  cp = fma_k(cp, x2, -1.1470745597729724714e-11);            // -1/14!
-  cp = fma_k(cp, x2, 2.0876756987868098979e-09);             //  1/12!
-  cp = fma_k(cp, x2, -2.7557319223985890653e-07);            // -1/10!
-  cp = fma_k(cp, x2, 2.4801587301587301587e-05);             //  1/8!
-  cp = fma_k(cp, x2, -1.3888888888888888889e-03);            // -1/6!
-  cp = fma_k(cp, x2, 4.1666666666666666667e-02);             //  1/4!
-  cp = fma_k(cp, x2, -0.5);
-  const double cosx = fma(cp, x2, 1.0);
-  return outer ? copysign(cosx, t) : sinx;
+  double p = -1.9572941063391261231e-20;                        // -1/21!
+  p = fma_k(p, x2, 8.2206352466243297170e-18);                    //  1/19!
+  p = fma_k(p, x2, -2.8114572543455207632e-15);                   // -1/17!
+  p = fma_k(p, x2, 7.6471637318198164759e-13);                    //  1/15!
+  p = fma_k(p, x2, -1.6059043836821614599e-10);                   // -1/13!
+  p = fma_k(p, x2, 2.5052108385441718775e-08);                    //  1/11!
+  p = fma_k(p, x2, -2.7557319223985890653e-06);                   // -1/9!
+  p = fma_k(p, x2, 1.9841269841269841270e-04);                    //  1/7!
+  p = fma_k(p, x2, -8.3333333333333333333e-03);                   // -1/5!
+  p = fma_k(p, x2, 1.6666666666666666667e-01);                    //  1/3!
+  return fma(-x * x2, p, x);                                     // x - x^3 (1/3! - x^2/5! + ...)
+}
+
+// cos(d / 2) for any |d| < 2^30: d / (4 pi) reduced to t in [-1/2, 1/2], cos(2 pi t) = cos(pi * 2|t|)
+__device__ __forceinline__ double cos_half(double d) {
+  const double v = d * (0.25 / kPi);
+  const double t = v - rint(v);
+  return cospi_unit(2.0 * fabs(t));
 }
 
 // The sampler in three pieces so that callers can run the (divergent) attempt loop as a per-lane
-// work queue: vm_envelope once per draw, vm_attempt until it returns true, vm_angle once.
+// work queue: vm_envelope once per draw, vm_attempt_pair until it returns true, vm_angle once.
 __device__ __forceinline__ double vm_clamp(double kappa) {
   return fmax(kappa, 1e-12);  // also maps NaN to a finite concentration: every wave reaches its exit
 }
 
-__device__ __forceinline__ double vm_envelope(double kappa) {  // kappa already clamped
-  const double s = fast_sqrt(1. + 4. * kappa * kappa);
-  const double a = 1. + s;
-  const double w = a + fast_sqrt(2. * a);
-  // r = (1 + b^2) / (2 b) with b = (a - sqrt(2a)) / (2 kappa) = 2 kappa / w, in one division
-  return fast_div(w * w + 4. * kappa * kappa, 4. * kappa * w);
+__device__ __forceinline__ double vm_envelope(double kappa) {  // R = kappa r = (1 + sqrt(1 + 4 kappa^2)) / 2
+  return fma(0.5, fast_sqrt(fma(4. * kappa, kappa, 1.)), 0.5);
 }
 
-constexpr uint32_t kMaxVmAttempts = 1024u;
+constexpr uint32_t kMaxVmPairs = 512u;     // attempt bound (2 x 512 attempts): every lane leaves the loop
+constexpr uint32_t kVmFillin = 1u << 23;   // sub0 of the two-level fill-in draws (sweeps: 0)
+constexpr uint32_t kVmRefine = 1u << 22;   // the call that supplies the tails u2' of a pair's acceptance uniforms
 
-// one proposal; returns true when accepted (or when the attempt bound is hit).  f = cos(theta).
-// sub0 separates streams that share (site, chain, step): 0 for sweeps, kVmFillin for two-level fill-ins.
-constexpr uint32_t kVmFillin = 1u << 23;
-__device__ __forceinline__ bool vm_attempt(const RngKey &k, uint32_t site, uint32_t attempt, double kappa, double r,
-                                           double &f, bool &negative, uint32_t sub0 = 0) {
-  const U4 q = philox4x32_10(site, k.chain, k.step, (P_VONMISES << 24) | sub0 | attempt, k.k0, k.k1);
-  const double u1 = u01(q.x, q.y), u2 = u01(q.z, q.w);
-  negative = (q.x & 1u) != 0;  // bit 0 does not enter u1 (u01 drops the low 11 bits)
-  const double z = cospi_unit(u1);
-  f = fast_div(1. + r * z, r + z);
-  const double c = kappa * (r - f);
-  if (c * (2. - c) - u2 > 0.) return true;
-  // Exact test: log(c / u2) + 1 - c >= 0.  Squeeze in fp32 (hardware log) with a guard band that
-  // covers the fp32 rounding of c, u2 and of the logarithm; only draws inside the band (~1e-5 of
-  // them) pay for the fp64 logarithm, and the decision is always the fp64 one.
+// proposal uniform: the top 52 bits of hi:lo as the mantissa of a double in [1, 2), minus 1
+__device__ __forceinline__ double u01_52(uint32_t lo, uint32_t hi) {
+  return __hiloint2double((int)((hi >> 12) | 0x3FF00000u), (int)__builtin_amdgcn_alignbit(hi, lo, 12)) - 1.0;
+}
+
+// One attempt from the word pair (lo, hi): proposal f = cos(theta), c, and the screening decision:
+// 1 accepted, 0 rejected, -1 open (the 11 leading bits of u2 do not decide).
+__device__ __forceinline__ int vm_try(uint32_t lo, uint32_t hi, double kappa, double R, double &f, double &c) {
+  const double z = cospi_unit(u01_52(lo, hi));
+  f = fast_div(fma(R, z, kappa), fma(kappa, z, R));
+  c = fma(-kappa, f, R);
   const float cf = (float)c;
-  const float lf = __logf(cf / (float)u2) + 1.0f - cf;
-  const float band = 2e-5f * (1.0f + cf);
-  if (lf > band) return true;
-  if (lf >= -band && log(c / u2) + 1. - c >= 0.) return true;
-  return attempt + 1 >= kMaxVmAttempts;
+  const float af = cf * __expf(1.0f - cf);              // acceptance probability c exp(1 - c), fp32
+  const float band = af * (1e-5f * (1.0f + cf));        // >> its fp32 error (~4e-7 (1 + c) relative)
+  const float lo_s = (float)((lo >> 1) & 0x7FFu) * (1.0f / 2048.0f), hi_s = lo_s + (1.0f / 2048.0f);  // u2 in [lo_s, hi_s)
+  return hi_s <= af - band ? 1 : (lo_s >= af + band ? 0 : -1);
+}
+
+// the exact test with the full acceptance uniform u2 = (b + tail) / 2048
+__device__ __forceinline__ int vm_exact(uint32_t lo, double tail, double c) {
+  const double u2 = ((double)((lo >> 1) & 0x7FFu) + tail) * (1.0 / 2048.0);
+  return (c * (2. - c) - u2 > 0. || log(c / u2) + 1. - c >= 0.) ? 1 : 0;
+}
+
+// Attempts 2 pair and 2 pair + 1; returns true when one of them is accepted (or when the attempt bound is hit).
+// f = cos(theta).  sub0 separates streams that share (site, chain, step): 0 for sweeps, kVmFillin for two-level fill-ins.
+__device__ __forceinline__ bool vm_attempt_pair(const RngKey &k, uint32_t site, uint32_t pair, double kappa, double R,
+                                                double &f, bool &negative, uint32_t sub0 = 0) {
+  const uint32_t w3 = (P_VONMISES << 24) | sub0 | pair;
+  const U4 q = philox4x32_10(site, k.chain, k.step, w3, k.k0, k.k1);
+  double fa, ca, fb, cb;
+  int sa = vm_try(q.x, q.y, kappa, R, fa, ca), sb = vm_try(q.z, q.w, kappa, R, fb, cb);
+  if (sa < 0 || (sa == 0 && sb < 0)) {  // a decision that matters is open: fetch the tails
+    const U4 e = philox4x32_10(site, k.chain, k.step, w3 | kVmRefine, k.k0, k.k1);
+    if (sa < 0) sa = vm_exact(q.x, u01(e.x, e.y), ca);
+    if (sa == 0 && sb < 0) sb = vm_exact(q.z, u01(e.z, e.w), cb);
+  }
+  f = sa == 1 ? fa : fb;
+  negative = ((sa == 1 ? q.x : q.z) & 1u) != 0;
+  return sa == 1 || sb == 1 || pair + 1 >= kMaxVmPairs;
 }
 
 __device__ __forceinline__ double vm_angle(double f, bool negative) {
@@ -335,22 +364,22 @@ __device__ __forceinline__ double vm_angle(double f, bool negative) {
 
 __device__ __forceinline__ double vonmises_draw(const RngKey &k, uint32_t site, double kappa, uint32_t sub0 = 0) {
   kappa = vm_clamp(kappa);
-  const double r = vm_envelope(kappa);
+  const double R = vm_envelope(kappa);
   double f = 1.0;
   bool negative = false;
-  for (uint32_t attempt = 0; !vm_attempt(k, site, attempt, kappa, r, f, negative, sub0); ++attempt) {
+  for (uint32_t pair = 0; !vm_attempt_pair(k, site, pair, kappa, R, f, negative, sub0); ++pair) {
   }
   return vm_angle(f, negative);
 }
 
-// quenchedschwingeraction.cc:46-54 -> expcosdistribution.hh:51-65: the draw is centred on the mean
-// staple angle, shifted by pi when the staples are more than pi apart
-// concentration and centre of the ExpCos conditional for staples x_p, x_m in [-pi, pi]
+// quenchedschwingeraction.cc:46-54 -> expcosdistribution.hh:51-65: the conditional of a link between staple angles
+// x_p, x_m is exp(beta [cos(x - x_p) + cos(x - x_m)]) = exp(2 beta cos((x_m - x_p)/2) cos(x - (x_p + x_m)/2)): a von Mises
+// law around the mean staple angle, shifted by pi when the cosine is negative.  The identity holds for any real
+// x_p, x_m, so the staple sums need no mod_2pi of their own (the reference wraps them and tests |dx| > pi; same angle).
 __device__ __forceinline__ void expcos_params(double beta, double x_p, double x_m, double &tau, double &centre) {
-  const double dx = x_m - x_p;
-  // |dx / 2| <= pi: cos(dx/2) = cos(pi u) with u = |dx| / (2 pi) in [0, 1]
-  tau = 2. * beta * fabs(cospi_unit(fmin(fabs(dx) * (0.5 / kPi), 1.0)));
-  centre = 0.5 * (x_p + x_m) + (fabs(dx) > kPi ? kPi : 0.0);
+  const double ch = cos_half(x_m - x_p);
+  tau = 2. * beta * fabs(ch);
+  centre = fma(0.5, x_p + x_m, ch < 0.0 ? kPi : 0.0);
 }
 
 __device__ __forceinline__ double expcos_draw(const RngKey &k, uint32_t site, double beta, double x_p,
@@ -403,7 +432,7 @@ __device__ __forceinline__ double two_pi_i0_scaled(double z) {
 // Heat-bath colour phase as a per-lane work queue.  Each thread owns up to S cells of the region
 // (linear index tid + NT m).  Their conditional parameters are set up first (no divergence), every cell
 // gets its first attempt in straight-line code, then every lane runs further rejection attempts on its
-// lowest PENDING cell and moves on as soon as one is accepted, so a wave iterates
+// lowest PENDING cell (two attempts per iteration) and moves on as soon as one is accepted, so a wave iterates
 // max-over-lanes(sum of extra attempts) times instead of sum-over-cells(max-over-lanes attempts); the
 // arccosine and the LDS write-back run once per cell afterwards, again without divergence.  Which random numbers a cell consumes is fixed by
 // (site, attempt), so the result does not depend on this scheduling.
@@ -426,12 +455,13 @@ __device__ __forceinline__ void heatbath_cells(uint32_t total, const RngKey &key
         n = m + 1;
       }
     }
-    // First attempt of every cell in straight-line code (about 5 in 6 proposals are accepted at once, and
-    // the S independent chains give the scheduler instruction-level parallelism) ...
+    // First pair of attempts of every cell in straight-line code (about 5 in 6 proposals are accepted, so 97 % of the
+    // cells are done after their first Philox call; the S independent chains give the scheduler instruction-level
+    // parallelism) ...
     uint32_t pending = 0;
 #pragma unroll
     for (int m = 0; m < S; ++m) {
-      if (m < n && !vm_attempt(key, site[m], 0, kap[m], env[m], fv[m], neg[m])) pending |= 1u << m;
+      if (m < n && !vm_attempt_pair(key, site[m], 0, kap[m], env[m], fv[m], neg[m])) pending |= 1u << m;
     }
     // ... then the per-lane queue over the cells still pending: every lane retries its lowest pending
     // cell and moves on when it is accepted.
@@ -446,7 +476,7 @@ __device__ __forceinline__ void heatbath_cells(uint32_t total, const RngKey &key
           if (cur == m) { k_ = kap[m]; r_ = env[m]; s_ = site[m]; }
         double f;
         bool ng;
-        if (vm_attempt(key, s_, attempt, k_, r_, f, ng)) {
+        if (vm_attempt_pair(key, s_, attempt, k_, r_, f, ng)) {
 #pragma unroll
           for (int m = 0; m < S; ++m)
             if (cur == m) { fv[m] = f; neg[m] = ng; }

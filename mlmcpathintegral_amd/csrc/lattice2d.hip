@@ -168,8 +168,8 @@ __global__ void __launch_bounds__(NT, HEAT ? (NT == 256 ? 4 : NT == 512 ? 2 : 1)
             [&](uint32_t ri, uint32_t ci, double &tau, double &centre, uint32_t &site, uint32_t &o) {
               const uint32_t r = r_first + 2 * ri, c = c_lo0 + ci;
               o = r * bw + c;
-              const double tp = mod_2pi_fast(th0[o + bw] + th1[o] - th1[o + 1]);
-              const double tm = mod_2pi_fast(th0[o - bw] + th1[o - bw + 1] - th1[o - bw]);
+              const double tp = th0[o + bw] + th1[o] - th1[o + 1];  // staple angles, unwrapped (expcos_params)
+              const double tm = th0[o - bw] + th1[o - bw + 1] - th1[o - bw];
               expcos_params(beta, tp, tm, tau, centre);
               site = 2 * (wrap_add(sr, r, Mx) * Mt + wrap_add(sc, c, Mt));
             },
@@ -197,8 +197,8 @@ __global__ void __launch_bounds__(NT, HEAT ? (NT == 256 ? 4 : NT == 512 ? 2 : 1)
             [&](uint32_t ri, uint32_t ci, double &tau, double &centre, uint32_t &site, uint32_t &o) {
               const uint32_t r = r_lo1 + ri, c = c_first + 2 * ci;
               o = r * bw + c;
-              const double tp = mod_2pi_fast(th0[o] + th1[o + 1] - th0[o + bw]);
-              const double tm = mod_2pi_fast(th0[o + bw - 1] + th1[o - 1] - th0[o - 1]);
+              const double tp = th0[o] + th1[o + 1] - th0[o + bw];
+              const double tm = th0[o + bw - 1] + th1[o - 1] - th0[o - 1];
               expcos_params(beta, tp, tm, tau, centre);
               site = 2 * (wrap_add(sr, r, Mx) * Mt + wrap_add(sc, c, Mt)) + 1;
             },

@@ -161,25 +161,38 @@ double expcos_draw(Src &src, double beta, double x_p, double x_m) {
 // envelope of Best & Fisher (Appl. Statist. 28 (1979) 152-157), whose acceptance rate is >= 0.65
 // for every concentration.  Equality in distribution with the reference's samplers is a test
 // (tests/test_distributions.py), not an assumption.
+//
+// Arithmetic and random-number layout follow the device (mlmcpathintegral_amd/csrc/device_common.hpp, "heat-bath angle
+// draws"): Best & Fisher's r = (1 + rho^2)/(2 rho) equals (1 + s)/(2 kappa), s = sqrt(1 + 4 kappa^2); with
+// R = kappa r = (1 + s)/2:  z = cos(pi u1), f = cos(theta) = (kappa + R z)/(R + kappa z), c = R - kappa f, accept when
+// u2 <= c exp(1 - c).  One Philox call (word 3 = P_VONMISES << 24 | sub0 | t) feeds attempts 2t (words 0, 1) and 2t + 1
+// (words 2, 3); of an attempt's 64 bits v = hi:lo, u1 = (v >> 12) 2^-52, bit 0 is the sign of the angle, bits 1..11 are
+// the leading bits b of u2 = (b + u2') / 2048, and the tail u2' (53 bits) comes from the call with word 3 | kVmRefine.
+// The device consults the tail only when b does not decide; the decision is the same either way.
 constexpr uint32_t kVmFillin = 1u << 23;  // sub-stream of the two-level fill-in draws
+constexpr uint32_t kVmRefine = 1u << 22;  // the call holding the tails of a pair's acceptance uniforms
+constexpr uint32_t kMaxVmPairs = 512u;
 inline double dev_vonmises(const DevRng &rng, uint32_t site, double kappa, uint32_t sub0 = 0) {
   kappa = std::fmax(kappa, 1e-12);  // also maps NaN to a finite concentration: the loop always ends
-  const double s = std::sqrt(1. + 4. * kappa * kappa);
-  const double a = 1. + s;
-  const double w = a + std::sqrt(2. * a);
-  // r = (1 + b^2)/(2 b) with b = (a - sqrt(2a))/(2 kappa) = 2 kappa / w (cancellation free), one division
-  const double r = (w * w + 4. * kappa * kappa) / (4. * kappa * w);
+  const double R = 0.5 + 0.5 * std::sqrt(1. + 4. * kappa * kappa);
   double f = 1.0;
   bool negative = false;
-  for (uint32_t attempt = 0; attempt < 1024u; ++attempt) {
-    Philox4 w = rng.raw(site, P_VONMISES, sub0 | attempt);
-    const double u1 = u01(w.v[0], w.v[1]), u2 = u01(w.v[2], w.v[3]);
-    negative = (w.v[0] & 1u) != 0;  // bit 0 is not part of u1 (u01 drops the low 11 bits)
-    const double z = std::cos(kPi * u1);
-    f = (1. + r * z) / (r + z);
-    const double c = kappa * (r - f);
-    if (c * (2. - c) - u2 > 0.) break;
-    if (std::log(c / u2) + 1. - c >= 0.) break;
+  for (uint32_t pair = 0; pair < kMaxVmPairs; ++pair) {
+    const Philox4 w = rng.raw(site, P_VONMISES, sub0 | pair);
+    const Philox4 e = rng.raw(site, P_VONMISES, sub0 | kVmRefine | pair);
+    bool accepted = false;
+    for (int h = 0; h < 2 && !accepted; ++h) {
+      const uint32_t lo = w.v[2 * h], hi = w.v[2 * h + 1];
+      const uint64_t v = ((uint64_t)hi << 32) | lo;
+      const double u1 = (double)(v >> 12) * (1.0 / 4503599627370496.0);  // 52 bits
+      negative = (lo & 1u) != 0;
+      const double u2 = ((double)((lo >> 1) & 0x7FFu) + u01(e.v[2 * h], e.v[2 * h + 1])) * (1.0 / 2048.0);
+      const double z = std::cos(kPi * u1);
+      f = (kappa + R * z) / (R + kappa * z);
+      const double c = R - kappa * f;
+      accepted = (c * (2. - c) - u2 > 0.) || (std::log(c / u2) + 1. - c >= 0.);
+    }
+    if (accepted) break;
   }
   f = std::fmin(1.0, std::fmax(-1.0, f));
   const double theta = std::acos(f);
