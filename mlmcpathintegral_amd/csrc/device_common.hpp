@@ -429,67 +429,78 @@ __device__ __forceinline__ double two_pi_i0_scaled(double z) {
   return 2. * kPi * bessel_i0_scaled(z);
 }
 
-// Heat-bath colour phase as a per-lane work queue.  Each thread owns up to S cells of the region
-// (linear index tid + NT m).  Their conditional parameters are set up first (no divergence), every cell
-// gets its first attempt in straight-line code, then every lane runs further rejection attempts on its
-// lowest PENDING cell (two attempts per iteration) and moves on as soon as one is accepted, so a wave iterates
-// max-over-lanes(sum of extra attempts) times instead of sum-over-cells(max-over-lanes attempts); the
-// arccosine and the LDS write-back run once per cell afterwards, again without divergence.  Which random numbers a cell consumes is fixed by
-// (site, attempt), so the result does not depend on this scheduling.
+// Heat-bath colour phase.  Each thread owns up to S cells of the region (linear index tid + NT m).  Their conditional
+// parameters are set up first (no divergence) and every cell gets its first PAIR of attempts (one Philox call) in
+// straight-line code; about 97 % of the cells are done then.  What is left is a geometric tail: a few cells per wave
+// that need one more call, a few per workgroup that need two.  Retrying them where they sit makes every wave run the
+// whole attempt code with one or two live lanes, several times over.  Instead the leftovers of the whole workgroup are
+// pushed into a small LDS pool (HbPool: concentration, centre, Philox site, LDS offset), and after a barrier ONE wave
+// finishes them, one entry per lane, and writes the angles straight to their cells.  Entries that do not fit (the pool
+// holds `cap` of them; expected ~40 per 1280 cells at beta = 1) are retried by their own lane on the spot.  Cells
+// accepted at once are written back at once (cells of one colour phase are not in each other's stencils), so nothing
+// but the loop state lives across cells.  Which random numbers a cell consumes is fixed by (site, attempt), so the
+// result does not depend on any of this scheduling.
+struct HbPool {
+  double *base;            // kap[cap] | cen[cap] | site[cap] | off[cap] | count[2]
+  uint32_t cap, use;       // capacity (0: no pool); number of uses so far (uniform over the workgroup)
+  // pushes of use u go to count[u & 1]; the other counter is cleared meanwhile
+  static __host__ __device__ constexpr size_t bytes(uint32_t cap) { return (size_t)cap * 24 + 8; }
+  __device__ double *kap() const { return base; }
+  __device__ double *cen() const { return base + cap; }
+  __device__ uint32_t *site() const { return (uint32_t *)(base + 2 * cap); }
+  __device__ uint32_t *off() const { return (uint32_t *)(base + 2 * cap) + cap; }
+  __device__ uint32_t *count() const { return (uint32_t *)(base + 2 * cap) + 2 * cap; }
+  __device__ static HbPool carve(double *lds, uint32_t cap) {  // call from every thread; thread 0 clears the counters
+    HbPool p{lds, cap, 0u};
+    if (cap && threadIdx.x == 0) p.count()[0] = p.count()[1] = 0;  // visible after the caller's next barrier
+    return p;
+  }
+};
+
 template <int NT, int S, class Setup, class Commit>
-__device__ __forceinline__ void heatbath_cells(uint32_t total, const RngKey &key, Setup setup, Commit commit) {
-  for (uint32_t b0 = 0; b0 < total; b0 += S * NT) {  // uniform trip count: the vote below needs every lane
-    double kap[S], env[S], cen[S], fv[S];
-    uint32_t site[S], off[S];
-    bool neg[S];
-    int n = 0;
+__device__ __forceinline__ void heatbath_cells(uint32_t total, const RngKey &key, HbPool &pool, Setup setup, Commit commit) {
+  for (uint32_t b0 = 0; b0 < total; b0 += S * NT) {  // uniform trip count: the barrier below needs every thread
+    uint32_t *cnt = pool.count() + (pool.use & 1u);
 #pragma unroll
     for (int m = 0; m < S; ++m) {
       const uint32_t idx = b0 + m * NT + threadIdx.x;
-      kap[m] = 1.0; env[m] = 1.0; cen[m] = 0.0; fv[m] = 1.0; site[m] = 0; off[m] = 0; neg[m] = false;
       if (idx < total) {
-        double tau;
-        setup(idx, tau, cen[m], site[m], off[m]);
-        kap[m] = vm_clamp(tau);
-        env[m] = vm_envelope(kap[m]);
-        n = m + 1;
+        double tau, cen, f = 1.0;
+        uint32_t site, off;
+        bool neg = false;
+        setup(idx, tau, cen, site, off);
+        const double kap = vm_clamp(tau), env = vm_envelope(kap);
+        bool done = vm_attempt_pair(key, site, 0, kap, env, f, neg);
+        if (!done && pool.cap) {
+          const uint32_t slot = atomicAdd(cnt, 1u);
+          if (slot < pool.cap) {
+            pool.kap()[slot] = kap; pool.cen()[slot] = cen; pool.site()[slot] = site; pool.off()[slot] = off;
+            continue;  // wave 0 finishes this cell after the barrier
+          }
+        }
+        // no pool, or pool full: retry here
+        for (uint32_t pair = 1; !done; ++pair) done = vm_attempt_pair(key, site, pair, kap, env, f, neg);
+        commit(off, mod_2pi_fast(vm_angle(f, neg) + cen));
       }
     }
-    // First pair of attempts of every cell in straight-line code (about 5 in 6 proposals are accepted, so 97 % of the
-    // cells are done after their first Philox call; the S independent chains give the scheduler instruction-level
-    // parallelism) ...
-    uint32_t pending = 0;
-#pragma unroll
-    for (int m = 0; m < S; ++m) {
-      if (m < n && !vm_attempt_pair(key, site[m], 0, kap[m], env[m], fv[m], neg[m])) pending |= 1u << m;
-    }
-    // ... then the per-lane queue over the cells still pending: every lane retries its lowest pending
-    // cell and moves on when it is accepted.
-    uint32_t attempt = 1;
-    while (__ballot(pending != 0u) != 0ull) {
-      if (pending != 0u) {
-        const int cur = __ffs(pending) - 1;
-        double k_ = kap[0], r_ = env[0];
-        uint32_t s_ = site[0];
-#pragma unroll
-        for (int m = 1; m < S; ++m)
-          if (cur == m) { k_ = kap[m]; r_ = env[m]; s_ = site[m]; }
-        double f;
-        bool ng;
-        if (vm_attempt_pair(key, s_, attempt, k_, r_, f, ng)) {
-#pragma unroll
-          for (int m = 0; m < S; ++m)
-            if (cur == m) { fv[m] = f; neg[m] = ng; }
-          pending &= pending - 1u;
-          attempt = 1;
-        } else {
-          ++attempt;
+    if (pool.cap) {
+      __syncthreads();
+      // the other counter: last read before the barrier that ended its use, next written after the one that ends this use
+      if (threadIdx.x == 0) pool.count()[(pool.use + 1u) & 1u] = 0;
+      if (threadIdx.x < kWave) {  // wave 0 finishes the pooled cells, one per lane
+        const uint32_t filled = min(*cnt, pool.cap);
+        for (uint32_t e = threadIdx.x; e < filled; e += kWave) {
+          const double k_ = pool.kap()[e], c_ = pool.cen()[e], r_ = vm_envelope(k_);
+          const uint32_t s_ = pool.site()[e], o_ = pool.off()[e];
+          double f = 1.0;
+          bool ng = false;
+          for (uint32_t pair = 1; !vm_attempt_pair(key, s_, pair, k_, r_, f, ng); ++pair) {
+          }
+          commit(o_, mod_2pi_fast(vm_angle(f, ng) + c_));
         }
       }
+      ++pool.use;
     }
-#pragma unroll
-    for (int m = 0; m < S; ++m)
-      if (m < n) commit(off[m], mod_2pi_fast(vm_angle(fv[m], neg[m]) + cen[m]));
   }
 }
 

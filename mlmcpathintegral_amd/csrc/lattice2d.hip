@@ -76,13 +76,13 @@ __device__ __forceinline__ void stage_region(uint32_t nr, uint32_t nc, Load load
 
 // region given as nr x nc with a runtime nc (generic kernels)
 template <int NT, int S, class Setup, class Commit>
-__device__ __forceinline__ void heatbath_region(uint32_t nr, uint32_t nc, const RngKey &key, Setup setup,
+__device__ __forceinline__ void heatbath_region(uint32_t nr, uint32_t nc, const RngKey &key, HbPool &pool, Setup setup,
                                                 Commit commit) {
   // (row, column) of a thread's cells without a division per cell: one division for the first cell, then steps of NT
   // (heatbath_cells asks for a thread's cells in increasing order: idx = tid, tid + NT, tid + 2 NT, ...)
   uint32_t cur = threadIdx.x, ri = cur / nc, ci = cur - ri * nc;
   const uint32_t dr = NT / nc, dc = NT - dr * nc;
-  heatbath_cells<NT, S>(nr * nc, key,
+  heatbath_cells<NT, S>(nr * nc, key, pool,
                         [&](uint32_t idx, double &tau, double &centre, uint32_t &site, uint32_t &o) {
                           while (cur < idx) {
                             cur += NT;
@@ -118,7 +118,8 @@ __device__ __forceinline__ uint32_t wrap_add(uint32_t base, uint32_t off, uint32
 template <bool HEAT, int NT>
 __global__ void __launch_bounds__(NT, HEAT ? (NT == 256 ? 4 : NT == 512 ? 2 : 1) : 1)
     schwinger_sweep_kernel(uint32_t Mt, uint32_t Mx, double beta, const double2 *__restrict__ in,
-                           double2 *__restrict__ out, TileGeom tg, uint32_t nsweeps, uint32_t kinds, RngKey key0) {
+                           double2 *__restrict__ out, TileGeom tg, uint32_t nsweeps, uint32_t kinds, RngKey key0,
+                           uint32_t pool_cap) {
   extern __shared__ double lds[];
   const uint32_t H = 2 * nsweeps;
   const uint32_t tile = blockIdx.x, b = blockIdx.y;
@@ -127,6 +128,8 @@ __global__ void __launch_bounds__(NT, HEAT ? (NT == 256 ? 4 : NT == 512 ? 2 : 1)
   const uint32_t ow = min(tg.TW, Mt - i0), oh = min(tg.TH, Mx - j0);
   const uint32_t bw = ow + 2 * H, bh = oh + 2 * H;
   double *th0 = lds, *th1 = lds + (size_t)bw * bh;
+  // retry pool of the heat-bath phases, behind the tile image (the host sizes the allocation for tg.TW x tg.TH tiles)
+  HbPool pool = HbPool::carve(lds + (size_t)2 * (tg.TW + 2 * H) * (tg.TH + 2 * H), HEAT ? pool_cap : 0u);
   const uint32_t sc = (uint32_t)(((uint64_t)i0 + Mt - (H % Mt)) % Mt);  // lattice column of buffer column 0
   const uint32_t sr = (uint32_t)(((uint64_t)j0 + Mx - (H % Mx)) % Mx);
   const double2 *src = in + (size_t)b * Mt * Mx;
@@ -164,7 +167,7 @@ __global__ void __launch_bounds__(NT, HEAT ? (NT == 256 ? 4 : NT == 512 ? 2 : 1)
       const uint32_t ncol = c_hi0 - c_lo0 + 1;
       if (heat) {
         heatbath_region<NT, 5>(
-            nr, ncol, skey,
+            nr, ncol, skey, pool,
             [&](uint32_t ri, uint32_t ci, double &tau, double &centre, uint32_t &site, uint32_t &o) {
               const uint32_t r = r_first + 2 * ri, c = c_lo0 + ci;
               o = r * bw + c;
@@ -193,7 +196,7 @@ __global__ void __launch_bounds__(NT, HEAT ? (NT == 256 ? 4 : NT == 512 ? 2 : 1)
       const uint32_t nrow = r_hi1 - r_lo1 + 1;
       if (heat) {
         heatbath_region<NT, 5>(
-            nrow, nc, skey,
+            nrow, nc, skey, pool,
             [&](uint32_t ri, uint32_t ci, double &tau, double &centre, uint32_t &site, uint32_t &o) {
               const uint32_t r = r_lo1 + ri, c = c_first + 2 * ci;
               o = r * bw + c;
@@ -932,9 +935,22 @@ static SweepGeom choose_geometry(uint32_t Mt, uint32_t Mx, uint32_t nsweeps, uin
 template <bool SCHW, bool HEAT, int NT>
 static void launch_sweep_nt(const SweepGeom &g, dim3 grid, hipStream_t st, uint32_t Mt, uint32_t Mx, double coupling,
                             const double *src, double *dst, uint32_t n, uint32_t kinds, RngKey key) {
-  if (SCHW)
-    hipLaunchKernelGGL((schwinger_sweep_kernel<HEAT, NT>), grid, dim3(NT), g.lds_bytes, st, Mt, Mx, coupling,
-                       (const double2 *)src, (double2 *)dst, g.tg, n, kinds, key);
+  if (SCHW) {
+    // heat-bath launches: room for the retry pool behind the tile image, as many entries as still keep the workgroup's
+    // LDS footprint within a quarter of the CU's 160 KiB (4 workgroups per CU), at least one wave's worth
+    uint32_t cap = 0;
+    size_t lds = g.lds_bytes;
+    if (HEAT) {
+      const size_t quarter = 40 * 1024;
+      cap = 64;
+      if (lds + HbPool::bytes(cap) <= quarter) cap = (uint32_t)((quarter - lds - 8) / 24);
+      if (cap > 1024) cap = 1024;
+      lds += HbPool::bytes(cap);
+      if (lds > 160 * 1024) { cap = 0; lds = g.lds_bytes; }
+    }
+    hipLaunchKernelGGL((schwinger_sweep_kernel<HEAT, NT>), grid, dim3(NT), lds, st, Mt, Mx, coupling,
+                       (const double2 *)src, (double2 *)dst, g.tg, n, kinds, key, cap);
+  }
   else
     hipLaunchKernelGGL((gff_sweep_kernel<HEAT, NT>), grid, dim3(NT), g.lds_bytes, st, Mt, Mx, coupling, src, dst, g.tg, n,
                        kinds, key);

@@ -470,9 +470,10 @@ __global__ void __launch_bounds__(256) path_transfer_kernel(uint32_t Mc, double 
 template <bool HEAT>  // HEAT = false: overrelaxation-only instantiation (no sampler code, few registers)
 __global__ void __launch_bounds__(256)
     rotor_sweep_kernel(PathP P, const double *__restrict__ in, double *__restrict__ out, uint32_t owned_len,
-                       uint32_t nsweeps, uint32_t kinds, RngKey key0) {
+                       uint32_t nsweeps, uint32_t kinds, RngKey key0, uint32_t pool_cap) {
   extern __shared__ double buf[];
   const uint32_t b = blockIdx.y, seg = blockIdx.x, M = P.M, halo = 2 * nsweeps;
+  HbPool pool = HbPool::carve(buf + owned_len + 2 * halo, HEAT ? pool_cap : 0u);  // behind the segment image
   const uint32_t o0 = seg * owned_len, olen = min(owned_len, M - o0);
   const uint32_t L = olen + 2 * halo;
   const uint32_t g0 = (uint32_t)(((uint64_t)o0 + M - (halo % M)) % M);
@@ -505,7 +506,7 @@ __global__ void __launch_bounds__(256)
         }
       } else if (HEAT) {
         heatbath_cells<256, 4>(
-            count, skey,
+            count, skey, pool,
             [&](uint32_t idx, double &tau, double &centre, uint32_t &site, uint32_t &off) {
               const uint32_t k = k0 + 2 * idx;
               const double xm = buf[k - 1], xp = buf[k + 1];
@@ -885,12 +886,13 @@ int mlmcpi_path_sweep_draw(const mlmcpi_path_action *act, double *d_x, double *d
     owned += owned & 1;  // keep segment starts even
     const uint32_t nseg2 = (P.M + owned - 1) / owned;
     const size_t lds = (size_t)(owned + 2 * halo) * sizeof(double);
+    const uint32_t pool_cap = 256;  // retry pool of the heat-bath phases (device_common.hpp, heatbath_cells)
     if (kinds)
-      hipLaunchKernelGGL(rotor_sweep_kernel<true>, dim3(nseg2, B), dim3(256), lds, st, P, (const double *)src, dst, owned, n,
-                         kinds, make_key(seed, chain0, sweep0 + s));
+      hipLaunchKernelGGL(rotor_sweep_kernel<true>, dim3(nseg2, B), dim3(256), lds + HbPool::bytes(pool_cap), st, P,
+                         (const double *)src, dst, owned, n, kinds, make_key(seed, chain0, sweep0 + s), pool_cap);
     else
       hipLaunchKernelGGL(rotor_sweep_kernel<false>, dim3(nseg2, B), dim3(256), lds, st, P, (const double *)src, dst, owned, n,
-                         kinds, make_key(seed, chain0, sweep0 + s));
+                         kinds, make_key(seed, chain0, sweep0 + s), 0u);
     MLMCPI_LAUNCH_CHECK("rotor_sweep_kernel");
     double *tmp = src; src = dst; dst = tmp;
     s += n;
