@@ -6,13 +6,17 @@
          --master-port P bench.py --gpus N --steps K --warmup W
 
 Workload (default): BASELINE.json configs[3], the configuration the north-star target is quoted on --
-quenched Schwinger model, 1024 x 1024, beta = 1, one "step" = one OverrelaxedHeatBathSampler::draw
-= 10 overrelaxation + 1 heat-bath sweep (parameters_qft_template.in) over `chains` independent
-chains per GPU.  Chains are sharded over ranks by global chain index (weak scaling: fixed chains per
-GPU); the only collective is the packed statistics all-reduce after the timed region.
+quenched Schwinger model, 1024 x 1024, beta = 1.  One "step" is one pass of the reference's sampling loop
+(montecarlo/montecarlosinglelevel.cc:59-77) over `chains` independent chains per GPU:
+    sampler->draw      10 overrelaxation + 1 heat-bath sweep (parameters_qft_template.in)
+    qoi->evaluate      average plaquette, one reduction pass over the state
+    record_sample      per-chain moment sums (mlmcpi_stats_accumulate)
+Chains are sharded over ranks by global chain index (weak scaling: fixed chains per GPU); the only collective is
+the packed statistics all-reduce after the timed region.  `--gpus N` without a launcher starts the N ranks itself.
 One JSON line is printed by rank 0.
 """
 import argparse
+import hashlib
 import json
 import os
 import subprocess
@@ -22,7 +26,14 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy ceiling 6290 GB/s
+HBM_PEAK_GBS = 8000.0    # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy ceiling 6290 GB/s
+VALU_PEAK_WAVE_INSTS = 256 * 4 * 2.4e9 / 4   # 256 CUs x 4 SIMDs, one fp64-class wave64 instruction per 4 cycles, 2.4 GHz
+
+WORKLOADS = ["schwinger", "gff", "rotor_hmc", "quartic_hmc", "ho_hmc", "quartic_mlmc", "rotor_sweep"]
+DEFAULT_SIZE = {"schwinger": 1024, "gff": 512, "rotor_hmc": 65536, "quartic_hmc": 32768, "ho_hmc": 128,
+                "quartic_mlmc": 32768, "rotor_sweep": 65536}
+DEFAULT_CHAINS = {"schwinger": 32, "gff": 1024, "rotor_hmc": 1024, "quartic_hmc": 2048, "ho_hmc": 8192,
+                  "quartic_mlmc": 512, "rotor_sweep": 1024}
 
 
 def parse():
@@ -30,7 +41,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="schwinger", choices=["schwinger", "gff", "rotor_hmc", "quartic_hmc", "ho_hmc", "quartic_mlmc", "rotor_sweep"])
+    ap.add_argument("--workload", default="schwinger", choices=WORKLOADS)
     ap.add_argument("--size", type=int, default=0, help="lattice extent (default: BASELINE size of the workload)")
     ap.add_argument("--chains", type=int, default=0, help="independent chains per GPU (default per workload)")
     ap.add_argument("--fuse", type=int, default=0, help="sweeps fused per launch (0 = library default)")
@@ -43,8 +54,48 @@ def parse():
                     help="untimed sampler draws before the warm-up (sweep workloads): the timed steps run on a "
                          "thermalised state -- heat-bath rejection rates depend on it -- and at steady clocks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-points", action="store_true",
+                    help="skip the single-chain and 128-chain side measurements of the default workload")
     ap.add_argument("--cpu-draws", type=int, default=0)
     return ap.parse_args()
+
+
+def spawn_ranks(a):
+    """`python bench.py --gpus N` without a launcher: start the N ranks (one process per GPU) before this process
+    touches a GPU, pass their output through, exit with their status.  Never prints an n_gpus that did not run."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def build_id():
+    """Identifies the kernel build the committed PMC figures belong to: hash of the kernel sources."""
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "mlmcpathintegral_amd", "csrc")
+    for f in ("device_common.hpp", "internal.hpp", "lattice2d.hip", "path1d.hip", "runtime.hip"):
+        with open(os.path.join(d, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:12]
+
+
+def pmc_entry(section, **match):
+    """Per-launch PMC figures (profiles/traffic.json) of the CURRENT kernel build, else None: a figure measured on an
+    older build is not quoted."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    except (OSError, ValueError):
+        return None
+    bid = build_id()
+    for e in t.get(section, []):
+        if e.get("build") == bid and all(e.get(k) == v for k, v in match.items()):
+            return e
+    return None
 
 
 def cpu_baseline(a, size):
@@ -60,22 +111,102 @@ def cpu_baseline(a, size):
     if out.returncode != 0:
         return {"value": None, "error": out.stderr[-300:]}
     r = json.loads(out.stdout.strip().splitlines()[-1])
-    return {"value": r["value"], "unit": "updates/s", "cores": r["cores"], "kind": "port",
-            "per_core": r["per_core"], "sample": r["sample"] + " (reference-order sequential sweeps, mt19937_64)"}
+    return {"value": r["value"], "unit": "updates/s", "cores": r["cores"], "cores_available": r.get("cores_available"),
+            "kind": "port", "per_core": r["per_core"],
+            "sample": r["sample"] + " (reference-order sequential sweeps, mt19937_64)",
+            "note": "the port runs ~2.8x faster per core than the reference itself measured in SURVEY 6.2 "
+                    "(12 M link-updates/s/core for 10 OR + 1 HB), so gpu_over_cpu understates the gap to the reference"}
+
+
+class SweepWorkload:
+    """OverrelaxedHeatBathSampler::draw + QoI + record_sample on a 2-D lattice action, B chains."""
+
+    def __init__(self, a, torch, abi, ops, kind, size, B, chain0):
+        self.a, self.torch, self.ops, self.kind, self.size, self.B, self.chain0 = a, torch, ops, kind, size, B, chain0
+        if kind == "schwinger":
+            self.act = abi.lattice_action(abi.SCHWINGER, size, size, beta=1.0)
+            self.sites = 2 * size * size
+        else:
+            self.act = abi.lattice_action(abi.GFF, size, size, mass=10.0)
+            self.sites = size * size
+        self.x = ops.lattice_initialise(self.act, B, a.seed, chain0)
+        self.scratch = torch.empty_like(self.x)
+        self.acc = torch.zeros((B, 5), dtype=torch.float64, device="cuda")
+        self.fuse = a.fuse or 4  # library default
+        self.sweep = 0
+        self.n_full = (a.n_overrelax // self.fuse) * self.fuse
+        self.ev = {"or": [], "hb": [], "qoi": []}
+
+    def qoi(self):
+        if self.kind == "schwinger":
+            return self.ops.qoi_avg_plaquette(self.x, self.size, self.size)
+        return self.ops.qoi_phi_squared(self.x)
+
+    def step(self, record):
+        a, ops, s = self.a, self.ops, self.sweep
+        E = lambda: self.torch.cuda.Event(enable_timing=True)
+        if record:
+            e = [E() for _ in range(5)]
+            e[0].record()
+        # same arithmetic as one call with (n_overrelax, n_heatbath); split only to time the kernels (ping-pong form:
+        # the buffers swap roles instead of being copied back).  Overrelaxation sweeps: full launches of `fuse` sweeps
+        # (timed as one kernel) + a remainder launch.
+        cur, oth = ops.lattice_sweep_draw_pingpong(self.act, self.x, self.scratch, self.n_full, 0, a.seed, self.chain0,
+                                                   s, self.fuse)
+        if record:
+            e[1].record()
+        if a.n_overrelax - self.n_full:
+            cur, oth = ops.lattice_sweep_draw_pingpong(self.act, cur, oth, a.n_overrelax - self.n_full, 0, a.seed,
+                                                       self.chain0, s + self.n_full, self.fuse)
+        if record:
+            e[2].record()
+        self.x, self.scratch = ops.lattice_sweep_draw_pingpong(self.act, cur, oth, 0, a.n_heatbath, a.seed, self.chain0,
+                                                               s + a.n_overrelax, self.fuse)
+        if record:
+            e[3].record()
+        ops.stats_accumulate(self.acc, self.qoi())  # qoi->evaluate + record_sample
+        if record:
+            e[4].record()
+            self.ev["or"].append((e[0], e[1]))
+            self.ev["hb"].append((e[2], e[3]))
+            self.ev["qoi"].append((e[3], e[4]))
+        self.sweep = s + a.n_overrelax + a.n_heatbath
+
+
+def time_steps(torch, dist, world, step, steps, warmup):
+    for _ in range(warmup):
+        step(False)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step(True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0
 
 
 def main():
     a = parse()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and a.gpus > 1:
+        sys.exit(spawn_ranks(a))
     rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(env_world or "1")
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    size = a.size or {"schwinger": 1024, "gff": 512, "rotor_hmc": 65536, "quartic_hmc": 32768, "ho_hmc": 128,
-                      "quartic_mlmc": 32768, "rotor_sweep": 65536}[a.workload]
-    B = a.chains or {"schwinger": 32, "gff": 1024, "rotor_hmc": 1024, "quartic_hmc": 2048, "ho_hmc": 8192,
-                     "quartic_mlmc": 512, "rotor_sweep": 1024}[a.workload]
+    if world != a.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {a.gpus} but the launcher started {world} rank(s)", file=sys.stderr)
+        sys.exit(2)
+    size = a.size or DEFAULT_SIZE[a.workload]
+    B = a.chains or DEFAULT_CHAINS[a.workload]
 
     cpu = None
-    if world == 1 and a.gpus == 1 and not a.no_cpu_baseline:
+    if world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(a, size)
 
     import torch
@@ -89,6 +220,9 @@ def main():
     backend = os.environ.get("MLMCPI_BENCH_BACKEND", "nccl")
     if backend != "nccl":
         local = local % torch.cuda.device_count()
+    elif local >= torch.cuda.device_count():
+        print(f"bench.py: rank {rank} has no GPU (local rank {local}, {torch.cuda.device_count()} device(s))", file=sys.stderr)
+        sys.exit(2)
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -100,58 +234,22 @@ def main():
     chain0 = rank * B  # global chain indices of this rank: [chain0, chain0 + B)
 
     ev = lambda: torch.cuda.Event(enable_timing=True)
-    or_events, hb_events = [], []
+    events = []
+    extra = {}
 
     if a.workload in ("schwinger", "gff"):
-        if a.workload == "schwinger":
-            act = abi.lattice_action(abi.SCHWINGER, size, size, beta=1.0)
-            sites = 2 * size * size
-        else:
-            act = abi.lattice_action(abi.GFF, size, size, mass=10.0)
-            sites = size * size
-        x = ops.lattice_initialise(act, B, a.seed, chain0)
-        scratch = torch.empty_like(x)
-        units_per_step = sites * (a.n_overrelax + a.n_heatbath) * B
-        fuse = a.fuse or 4  # library default
-        state = {"sweep": 0, "x": x, "scratch": scratch}
-
-        def step(record):
-            s = state["sweep"]
-            if record:
-                e0, e1, e2 = ev(), ev(), ev()
-                e0.record()
-            # same arithmetic as one call with (n_overrelax, n_heatbath); split only to time the two kernels
-            # (ping-pong form: the buffers swap roles instead of being copied back).  The overrelaxation
-            # sweeps are issued as full launches of `fuse` sweeps (timed: the dominant kernel) + a remainder.
-            n_full = (a.n_overrelax // fuse) * fuse
-            cur, oth = ops.lattice_sweep_draw_pingpong(act, state["x"], state["scratch"], n_full, 0, a.seed,
-                                                       chain0, s, fuse)
-            if record:
-                e1.record()
-            if a.n_overrelax - n_full:
-                cur, oth = ops.lattice_sweep_draw_pingpong(act, cur, oth, a.n_overrelax - n_full, 0, a.seed, chain0,
-                                                           s + n_full, fuse)
-            if record:
-                e1b = ev()
-                e1b.record()
-            state["x"], state["scratch"] = ops.lattice_sweep_draw_pingpong(act, cur, oth, 0, a.n_heatbath, a.seed, chain0,
-                                                                           s + a.n_overrelax, fuse)
-            if record:
-                e2.record()
-                or_events.append((e0, e1))
-                hb_events.append((e1b, e2))
-            state["sweep"] = s + a.n_overrelax + a.n_heatbath
-
-        def qoi():
-            if a.workload == "schwinger":
-                return ops.qoi_avg_plaquette(state["x"], size, size)
-            return ops.qoi_phi_squared(state["x"])
-        bytes_per_unit = 16.0  # each entry read once and written once per sweep
+        W = SweepWorkload(a, torch, abi, ops, a.workload, size, B, chain0)
+        for _ in range(a.thermalise):
+            W.step(False)
+        units_per_step = W.sites * (a.n_overrelax + a.n_heatbath) * B
+        step, fuse = W.step, W.fuse
+        acc_of = lambda: W.acc
     elif a.workload == "rotor_sweep":
         # OverrelaxedHeatBathSampler::draw on the rotor action, M_lat = 65536, a = 0.125
         act = abi.path_action(abi.ROTOR, size, size / 8.0, 0.25)
         x = ops.path_initialise(act, B, a.seed, chain0)
         scratch = torch.empty_like(x)
+        acc = torch.zeros((B, 5), dtype=torch.float64, device="cuda")
         units_per_step = size * (a.n_overrelax + a.n_heatbath) * B
         fuse = 1
         state = {"sweep": 0}
@@ -164,22 +262,21 @@ def main():
             state["sweep"] += a.n_overrelax + a.n_heatbath
             if record:
                 e1.record()
-                or_events.append((e0, e1))
-
-        def qoi():
-            return ops.qoi_susceptibility(x, size / 8.0)
-        bytes_per_unit = 16.0
+                events.append((e0, e1))
+            ops.stats_accumulate(acc, ops.qoi_susceptibility(x, size / 8.0))
+        for _ in range(a.thermalise):
+            step(False)
+        acc_of = lambda: acc
     elif a.workload == "quartic_mlmc":
-        # BASELINE configs[4]: quartic double well, 5 levels, finest M_lat = 32768, a = 0.125;
-        # level l on rank l % world, every level instance runs B chains; a step = one Y sample per chain on every
-        # level instance (2 trajectories of the level's sampler + the two-level step).
+        # BASELINE configs[4]: quartic double well, 5 levels, finest M_lat = 32768, a = 0.125.
+        # The (level, chain) instances are cut into `world` contiguous shares of equal cost (mlmc.partition); a step =
+        # one Y sample per chain of every instance (2 trajectories of the level's sampler + the two-level step).
         from mlmcpathintegral_amd import mlmc
         n_level = 5
         est = mlmc.PathMLMC(abi.QUARTIC, size, size / 8.0, n_level, B, nt=a.nt, dt0=a.dt or 0.02, seed=a.seed, rank=rank,
                             world=world, n_sub=2, params=dict(lam=1.0, x0=1.0))
         est.thermalise(64)
-        # site-steps per step, all levels (the same on every rank count): HMC of the feeding level + two-level pass
-        units_per_step = 0
+        units_per_step = 0  # site-steps per step over all ranks: HMC of the feeding level + two-level pass
         for l in range(n_level):
             src = l if l == n_level - 1 else l + 1
             units_per_step += (2 * (a.nt + 1) * (size >> src) + (0 if l == n_level - 1 else (size >> l))) * B
@@ -189,21 +286,18 @@ def main():
             if record:
                 e0, e1 = ev(), ev()
                 e0.record()
-            est.pass_(1)
+            est.pass_(1)  # sampler draws, two-level steps, QoIs and record_sample of every owned instance
             if record:
                 e1.record()
-                or_events.append((e0, e1))
-
-        def qoi():
-            lv = est.levels[min(est.levels)]
-            return ops.qoi_xsquared(lv.x)
-        bytes_per_unit = 32.0
+                events.append((e0, e1))
+        acc_of = lambda: est.packed_finest()
     else:
         kind = {"rotor_hmc": abi.ROTOR, "quartic_hmc": abi.QUARTIC, "ho_hmc": abi.HARMONIC}[a.workload]
         # a = 0.125 at the BASELINE sizes; config 1 (HO, M_lat = 128) keeps T_final = 4
         T_final = 4.0 if a.workload == "ho_hmc" else size / 8.0
         act = abi.path_action(kind, size, T_final, 0.25 if kind == abi.ROTOR else 1.0, 1.0, 1.0, 1.0)
         x = ops.path_initialise(act, B, a.seed, chain0)
+        acc = torch.zeros((B, 5), dtype=torch.float64, device="cuda")
         dt = a.dt or {abi.ROTOR: 0.05, abi.HARMONIC: 0.0558}.get(kind, 0.02)
         draws_per_step = 10 if a.workload == "ho_hmc" else 1  # short paths: several draws per launch
         hmc = ops.PathHMC(act, B, a.nt, dt, seed=a.seed, chain0=chain0)
@@ -221,38 +315,35 @@ def main():
                 q, cnt = ops.path_hmc_run(hmc, x, draws_per_step, 1)  # draws + QoIs in one launch
                 hmc.n_total += draws_per_step
                 hmc.n_accepted += cnt
+                if record:
+                    e1.record()
+                ops.stats_accumulate(acc, q[:, -1].contiguous() if q.dim() > 1 else q)
             else:
                 hmc.draw(x)
+                if record:
+                    e1.record()
+                ops.stats_accumulate(acc, ops.qoi_susceptibility(x, T_final) if kind == abi.ROTOR else ops.qoi_xsquared(x))
             if record:
-                e1.record()
-                or_events.append((e0, e1))
+                events.append((e0, e1))
+        acc_of = lambda: acc
 
-        def qoi():
-            return ops.qoi_susceptibility(x, T_final) if kind == abi.ROTOR else ops.qoi_xsquared(x)
-        bytes_per_unit = 32.0  # x, p read and written once per leapfrog step
+    elapsed = time_steps(torch, dist, world, step, a.steps, a.warmup)
 
-    if a.workload in ("schwinger", "gff", "rotor_sweep"):
-        for _ in range(a.thermalise):
-            step(False)
-    for _ in range(a.warmup):
-        step(False)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step(True)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    # side measurements of the default workload (same kernels, other batch sizes), after the timed region
+    if a.workload == "schwinger" and not a.no_extra_points and a.chains == 0:
+        for name, b_extra, k_extra in (("single_chain", 1, max(a.steps, 20)), ("chains_128", 128, max(2, a.steps // 4))):
+            Wx = SweepWorkload(a, torch, abi, ops, "schwinger", size, b_extra, rank * b_extra)
+            for _ in range(min(a.thermalise, 10)):
+                Wx.step(False)
+            el = time_steps(torch, dist, 1, Wx.step, k_extra, 2)
+            extra[name] = {"chains_per_gpu": b_extra, "steps": k_extra, "ms_per_step": 1e3 * el / k_extra,
+                           "value_per_gpu": Wx.sites * (a.n_overrelax + a.n_heatbath) * b_extra * k_extra / el,
+                           "unit": "updates/s"}
+            del Wx
+        extra["single_chain"]["note"] = "BASELINE configs[3] read literally: one chain per GPU (16 MiB state, cache resident)"
 
-    # the one collective: packed per-chain moments of a QoI, summed over ranks (RCCL)
-    acc = torch.zeros((B, chains.N_MOMENTS), dtype=torch.float64, device="cuda")
-    ops.stats_accumulate(acc, qoi())
-    packed = chains.allreduce_moments(chains.pack_moments(acc).to(coll_device))
+    # the one collective: packed per-chain moments of the QoI, summed over ranks (RCCL)
+    packed = chains.allreduce_moments(chains.pack_moments(acc_of()).to(coll_device))
     if a.workload == "quartic_mlmc":
         mlmc_q, mlmc_e, mlmc_t = est.estimate(device=coll_device)  # the level-table exchange (RCCL when world > 1)
         mlmc_t = mlmc_t.cpu()
@@ -260,12 +351,12 @@ def main():
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
-    qoi_mean = float(packed[1] / packed[0])
+    qoi_mean = float(packed[1] / packed[0]) if float(packed[0]) > 0 else None
 
     if rank == 0:
         total_units = units_per_step * a.steps * (1 if a.workload == "quartic_mlmc" else world)
         ms = lambda pairs: sum(p[0].elapsed_time(p[1]) for p in pairs)
-        or_ms = ms(or_events)
+        step_ms = 1e3 * elapsed / a.steps
         result = {
             "metric": "lattice-site-updates/sec",
             "value": total_units / elapsed,
@@ -273,96 +364,57 @@ def main():
             "n_gpus": world,
             "steps": a.steps,
             "warmup": a.warmup,
-            "ms_per_step": 1e3 * elapsed / a.steps,
+            "ms_per_step": step_ms,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
+            "step_includes": ["sampler->draw", "qoi->evaluate", "stats->record_sample"],
+            "kernel_build": build_id(),
         }
         if a.workload in ("schwinger", "gff"):
-            n_launch = a.n_overrelax // fuse  # full launches of `fuse` overrelaxation sweeps
-            result["config"] = {"workload": f"{a.workload} {size}x{size}, {a.n_overrelax} overrelaxation + "
-                                            f"{a.n_heatbath} heat-bath sweeps per step, multicolour order",
-                                "chains_per_gpu": B, "chains_total": B * world, "fuse": fuse,
-                                "parallelism": f"chains sharded over {world} GPU(s), no data-path collective"}
-            if n_launch:
-                launch_ms = or_ms / (a.steps * n_launch)
-                alg = bytes_per_unit * sites * B * fuse  # algorithmic bytes per launch (fuse sweeps)
-                achieved = alg / (launch_ms * 1e-3) / 1e9
-                special = size % 64 == 0 and fuse <= (6 if a.workload == "schwinger" else 4)
-                kname = ((f"schwinger_or_patch_kernel<{fuse}>" if fuse <= 4 and os.environ.get("MLMCPI_OR_KERNEL") != "lds"
-                          else f"schwinger_or_kernel<64,32,{fuse},{1024 if fuse >= 4 else 512}>") if a.workload == "schwinger" and special
-                         else (f"gff_or_patch_kernel<{fuse}>" if os.environ.get("MLMCPI_OR_KERNEL") != "lds"
-                               else f"gff_or_kernel<64,32,{fuse},256>") if special else f"{a.workload}_sweep_kernel<false,256>")
-                result["roofline"] = {"kernel": kname + f" ({fuse} fused overrelaxation sweeps per launch)", "bound": "hbm",
-                                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                      "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(a, B, fuse),
-                                      "launch_ms": launch_ms, "algorithmic_bytes_per_launch": alg,
-                                      "updates_per_s": sites * B * fuse / (launch_ms * 1e-3)}
-            hb_ms = ms(hb_events)
-            if n_launch:
-                result["roofline"]["share_of_step"] = or_ms / a.steps / (1e3 * elapsed / a.steps)
-            if a.n_heatbath:
-                result["heatbath"] = {"launch_ms": hb_ms / (a.steps * a.n_heatbath),
-                                      "updates_per_s": sites * B * a.n_heatbath * a.steps / (hb_ms * 1e-3),
-                                      "share_of_step": hb_ms / a.steps / (1e3 * elapsed / a.steps),
-                                      "algorithmic_GBps": 16.0 * sites * B * a.n_heatbath * a.steps / (hb_ms * 1e-3) / 1e9,
-                                      "note": "fp64 VALU bound (Philox + von Mises rejection sampler), not HBM bound "
-                                              "(SURVEY F9)"}
-                insts = load_valu(a, B)
-                if insts:
-                    # vector-ALU issue roofline: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz lane-operations/s; every
-                    # fp64 / int32 VALU instruction of a wave64 occupies its SIMD for 4 cycles
-                    hb_s = result["heatbath"]["launch_ms"] * 1e-3
-                    peak = 256 * 4 * 16 * 2.4e9
-                    result["heatbath"]["valu"] = {"bound": "valu", "wave_insts_per_launch": insts,
-                                                  "achieved": insts * 64 / hb_s / 1e12, "peak": peak / 1e12,
-                                                  "unit": "T lane-ops/s", "frac": insts * 64 / hb_s / peak,
-                                                  "source": "SQ_INSTS_VALU, profiles/traffic.json"}
+            report_sweeps(result, a, W, size, B, world, step_ms, ms)
         elif a.workload == "rotor_sweep":
-            launch_ms = or_ms / a.steps
-            alg = bytes_per_unit * units_per_step
-            achieved = alg / (launch_ms * 1e-3) / 1e9
+            launch_ms = ms(events) / a.steps
+            floor = 16.0 * size * B * (1 + (a.n_overrelax + 7) // 8)  # one read + one write of the state per launch
             result["config"] = {"workload": f"rotor M_lat={size}, {a.n_overrelax} overrelaxation + {a.n_heatbath} heat-bath "
                                             "sweeps per step, even/odd order", "chains_per_gpu": B, "chains_total": B * world,
                                 "parallelism": f"chains sharded over {world} GPU(s), no data-path collective"}
-            result["roofline"] = {"kernel": "rotor_sweep_kernel (all sweeps of a step)", "bound": "hbm", "achieved": achieved,
-                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                                  "launch_ms": launch_ms, "algorithmic_bytes_per_launch": alg,
-                                  "note": "the heat-bath sweep is VALU bound (von Mises sampler); overrelaxation sweeps are "
-                                          "fused on LDS-resident segments"}
+            result["roofline"] = register_resident_roofline(
+                "rotor_sweep_kernel<true> + rotor_sweep_kernel<false> (all sweeps of a step)", launch_ms, floor,
+                16.0 * units_per_step, pmc_entry("valu", workload=a.workload, size=size, chains=B),
+                "overrelaxation sweeps are fused 8 per launch on LDS-resident segments; the heat-bath sweep is "
+                "VALU bound (von Mises sampler)")
         elif a.workload == "quartic_mlmc":
             result["scaling"] = "strong"
             result["config"] = {"workload": f"quartic MLMC, 5 levels, finest M_lat={size}, a=0.125, nt={a.nt}, one Y sample per "
                                             "chain and level per step (2 sampler trajectories + two-level step)",
-                                "chains_per_level": B, "levels_on_rank0": sorted(est.levels),
-                                "parallelism": f"level l on rank l % {world}; per pass one all-reduce of the [5, 5] level table"}
+                                "chains_per_level": B, "instances_on_rank0": est.describe(),
+                                "parallelism": f"(level, chain) instances cut into {world} equal-cost shares; per pass one "
+                                               "all-reduce of the [5, 7] level table"}
             result["mlmc"] = {"estimate": mlmc_q, "error": mlmc_e, "level_means": mlmc_t[:, 1].tolist(),
                               "level_variances": mlmc_t[:, 2].tolist(),
                               "acceptance_rank0": {str(k): v for k, v in est.p_accept().items()}}
-            launch_ms = or_ms / a.steps
-            alg = bytes_per_unit * units_per_step / world
-            achieved = alg / (launch_ms * 1e-3) / 1e9
-            result["roofline"] = {"kernel": "hmc_trajectory_kernel (the level samplers; > 99 % of the site-steps)", "bound": "hbm",
-                                  "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                                  "traffic": None, "launch_ms": launch_ms, "algorithmic_bytes_per_launch": alg,
-                                  "note": "one step of all level instances of rank 0; states and momenta stay in "
-                                          "registers for a whole trajectory, so frac may exceed 1"}
+            launch_ms = ms(events) / a.steps
+            floor = 16.0 * est.state_entries() * 2  # every owned state read and written once per trajectory, 2 per step
+            result["roofline"] = register_resident_roofline(
+                "hmc_trajectory_kernel (the level samplers; > 99 % of the site-steps)", launch_ms, floor,
+                32.0 * units_per_step / world, pmc_entry("valu", workload=a.workload, size=size, chains=B),
+                "one step of all level instances of rank 0")
         else:
-            launch_ms = or_ms / a.steps
-            alg = bytes_per_unit * units_per_step
-            achieved = alg / (launch_ms * 1e-3) / 1e9
+            launch_ms = ms(events) / a.steps
+            floor = 16.0 * size * B * draws_per_step  # the state read and written once per trajectory
             result["p_accept"] = float(hmc.n_accepted.double().mean()) / max(1, hmc.n_total)
             result["config"] = {"workload": f"{a.workload} M_lat={size}, nt={a.nt}, dt={hmc.dt}, fused trajectories",
                                 "chains_per_gpu": B, "chains_total": B * world,
                                 "parallelism": f"chains sharded over {world} GPU(s), no data-path collective"}
-            result["roofline"] = {"kernel": "hmc_trajectory_kernel", "bound": "hbm", "achieved": achieved,
-                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                                  "traffic": None, "launch_ms": launch_ms, "algorithmic_bytes_per_launch": alg,
-                                  "note": "state and momenta stay in registers for the whole trajectory: HBM "
-                                          "sees 16 B per site per trajectory, so frac may exceed 1"}
+            result["roofline"] = register_resident_roofline(
+                "hmc_chain_kernel" if draws_per_step > 1 else "hmc_trajectory_kernel", launch_ms, floor,
+                32.0 * units_per_step, pmc_entry("valu", workload=a.workload, size=size, chains=B),
+                "state and momenta stay in registers for the whole trajectory")
         result["qoi_mean"] = qoi_mean
+        result.update(extra)
         if cpu is not None:
             result["cpu_baseline"] = cpu
             if cpu.get("value"):
@@ -373,29 +425,106 @@ def main():
         dist.destroy_process_group()
 
 
-def load_valu(a, B):
-    """VALU wave-instructions per heat-bath launch from the committed SQ counter profile (scaled with the chains)."""
-    try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        for e in t.get("valu", []):
-            if (e["workload"], e["size"]) == (a.workload, a.size or 1024):
-                return e["SQ_INSTS_VALU_per_launch"] * B / e["chains"]
-    except (OSError, ValueError, KeyError):
-        pass
-    return None
+def register_resident_roofline(kernel, launch_ms, floor_bytes, streaming_bytes, valu, note):
+    """Roofline record of a kernel that keeps its state in registers / LDS across many updates.  HBM sees the state
+    once per launch (`floor_bytes`), so the HBM fraction is small by construction and the binding limit is vector
+    issue; the 32 (16) B-per-unit streaming model of SURVEY 8(d) is quoted as a rate, never as a fraction."""
+    achieved = floor_bytes / (launch_ms * 1e-3) / 1e9
+    r = {"kernel": kernel, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "launch_ms": launch_ms,
+         "algorithmic_bytes_per_launch": floor_bytes, "limited_by": "valu",
+         "streaming_model_GBps": streaming_bytes / (launch_ms * 1e-3) / 1e9,
+         "note": note + "; `achieved` counts the bytes an ideal implementation of this launch must move (state read "
+                        "and written once); streaming_model_GBps is SURVEY 8(d)'s per-unit figure x units / time, a "
+                        "rate for comparison with streaming implementations, not a fraction of any roofline"}
+    if valu:
+        insts = valu["SQ_INSTS_VALU_per_launch"]
+        r["valu"] = {"wave_insts_per_launch": insts, "achieved": insts / (launch_ms * 1e-3) / 1e9,
+                     "peak": VALU_PEAK_WAVE_INSTS / 1e9, "unit": "G wave-insts/s",
+                     "frac": insts / (launch_ms * 1e-3) / VALU_PEAK_WAVE_INSTS, "source": valu.get("source")}
+        r["valu_frac"] = r["valu"]["frac"]
+    return r
 
 
-def load_traffic(a, B, fuse):
-    """HBM bytes per launch from the committed PMC profile of the same configuration, else None."""
-    path = os.path.join(ROOT, "profiles", "traffic.json")
-    try:
-        t = json.load(open(path))
-        for e in t.get("entries", []):
-            if (e["workload"], e["size"], e["chains"], e["fuse"]) == (a.workload, a.size or 1024, B, fuse):
-                return e["hbm_bytes_per_launch"]
-    except (OSError, ValueError, KeyError):
-        pass
-    return None
+def report_sweeps(result, a, W, size, B, world, step_ms, ms):
+    """Per-kernel records and the roofline of the dominant kernel for the 2-D sweep workloads."""
+    fuse, sites = W.fuse, W.sites
+    state_rw = 16.0 * sites * B          # one read + one write of the whole state: the HBM floor of ANY launch
+    n_launch = a.n_overrelax // fuse     # full launches of `fuse` overrelaxation sweeps
+    rem = a.n_overrelax - n_launch * fuse
+    special = size % 64 == 0 and fuse <= (6 if a.workload == "schwinger" else 4)
+    lds_kernel = os.environ.get("MLMCPI_OR_KERNEL") == "lds"
+    if a.workload == "schwinger":
+        or_name = (f"schwinger_or_patch_kernel<{fuse}>" if fuse <= 4 and not lds_kernel
+                   else f"schwinger_or_kernel<64,32,{fuse},{1024 if fuse >= 4 else 512}>") if special else "schwinger_sweep_kernel<false,256>"
+        hb_name = "schwinger_sweep_kernel<true,256>"
+    else:
+        or_name = (f"gff_or_patch_kernel<{fuse}>" if not lds_kernel else f"gff_or_kernel<64,32,{fuse},256>") if special else "gff_sweep_kernel<false,256>"
+        hb_name = "gff_sweep_kernel<true,256>"
+    result["config"] = {"workload": f"{a.workload} {size}x{size}, {a.n_overrelax} overrelaxation + {a.n_heatbath} heat-bath "
+                                    "sweeps + QoI + record_sample per step, multicolour order",
+                        "chains_per_gpu": B, "chains_total": B * world, "fuse": fuse,
+                        "parallelism": f"chains sharded over {world} GPU(s), no data-path collective"}
+    kernels = []
+
+    def record(name, role, pairs, launches, sweeps, floor_bytes, traffic, valu):
+        launch_ms = ms(pairs) / (a.steps * launches)
+        alg = 16.0 * sites * B * sweeps  # SURVEY 8(d): 16 B per update x updates of one launch
+        k = {"kernel": name, "role": role, "launches_per_step": launches, "sweeps_per_launch": sweeps, "launch_ms": launch_ms,
+             "share_of_step": launch_ms * launches / step_ms, "updates_per_s": sites * B * sweeps / (launch_ms * 1e-3),
+             "algorithmic_bytes_per_launch": alg, "algorithmic_GBps": alg / (launch_ms * 1e-3) / 1e9,
+             # the bound: bytes this launch cannot avoid moving (state in, state out) against the HBM peak
+             "hbm_floor_bytes_per_launch": floor_bytes, "hbm_floor_GBps": floor_bytes / (launch_ms * 1e-3) / 1e9,
+             "hbm_frac": floor_bytes / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+             "traffic": traffic["hbm_bytes_per_launch"] if traffic else None}
+        if traffic:
+            k["traffic_over_floor"] = traffic["hbm_bytes_per_launch"] / floor_bytes
+            k["traffic_GBps"] = traffic["hbm_bytes_per_launch"] / (launch_ms * 1e-3) / 1e9
+        if valu:
+            insts = valu["SQ_INSTS_VALU_per_launch"] * B / valu["chains"]
+            k["valu_wave_insts_per_launch"] = insts
+            k["valu_insts_per_update"] = insts * 64 / (sites * B * sweeps)
+            k["valu_frac"] = insts / (launch_ms * 1e-3) / VALU_PEAK_WAVE_INSTS
+        kernels.append(k)
+        return k
+
+    wl = dict(workload=a.workload, size=size)
+    if n_launch:
+        record(or_name, f"{fuse} fused overrelaxation sweeps", W.ev["or"], n_launch, fuse, state_rw,
+               pmc_entry("entries", chains=B, fuse=fuse, kind="overrelax", **wl), pmc_entry("valu", kind="overrelax", fuse=fuse, **wl))
+    if a.n_heatbath:
+        record(hb_name, "heat-bath sweep", W.ev["hb"], a.n_heatbath, 1, state_rw,
+               pmc_entry("entries", chains=B, fuse=1, kind="heatbath", **wl), pmc_entry("valu", kind="heatbath", **wl))
+    qk = record("lattice_reduce_kernel (QoI) + stats_accumulate_kernel", "qoi->evaluate + record_sample", W.ev["qoi"], 1, 1,
+                0.5 * state_rw, None, None)
+    del qk["updates_per_s"], qk["algorithmic_bytes_per_launch"], qk["algorithmic_GBps"], qk["sweeps_per_launch"]
+    result["kernels"] = kernels
+    # roofline: the kernel with the largest share of the step.  `achieved` = algorithmic bytes (16 B x the updates of one
+    # launch) / launch time; for a single-sweep launch that equals the HBM floor, for a fused launch the floor is used
+    # (a fused launch shares one HBM round trip among its sweeps, so the per-update model is not a bound for it).
+    dom = max(kernels[:-1], key=lambda k: k["share_of_step"])
+    roof = {"kernel": f"{dom['kernel']} ({dom['role']})", "bound": "hbm",
+            "achieved": dom["hbm_floor_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["hbm_frac"],
+            "hbm_frac": dom["hbm_frac"], "traffic": dom["traffic"], "launch_ms": dom["launch_ms"],
+            "algorithmic_bytes_per_launch": dom["hbm_floor_bytes_per_launch"], "share_of_step": dom["share_of_step"],
+            "updates_per_s": dom["updates_per_s"]}
+    if "valu_frac" in dom:
+        roof["valu_frac"] = dom["valu_frac"]
+        roof["valu_insts_per_update"] = dom["valu_insts_per_update"]
+    if dom["role"] == "heat-bath sweep" and a.workload == "schwinger":
+        roof["limited_by"] = "valu"
+        roof["note"] = ("fp64 vector-issue bound (Philox + von Mises rejection sampler, ~25-45 flop/B, SURVEY A.2): hbm_frac is "
+                        "what the contract asks for, valu_frac (SQ_INSTS_VALU x 4 cycles / 2.4 GHz / 1024 SIMDs) is the "
+                        "binding one")
+    result["roofline"] = roof
+    # whole step: 16 B x every update of the step against the step time, and the bytes the step's launches cannot avoid
+    alg_step = 16.0 * sites * B * (a.n_overrelax + a.n_heatbath)
+    floor_step = state_rw * (n_launch + (1 if rem else 0) + a.n_heatbath) + 0.5 * state_rw
+    result["whole_step"] = {"algorithmic_bytes": alg_step, "algorithmic_GBps": alg_step / (step_ms * 1e-3) / 1e9,
+                            "algorithmic_frac_of_peak": alg_step / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "hbm_floor_bytes": floor_step, "hbm_floor_GBps": floor_step / (step_ms * 1e-3) / 1e9,
+                            "hbm_floor_frac": floor_step / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "kernel_ms_sum": sum(k["launch_ms"] * k["launches_per_step"] for k in kernels)}
 
 
 if __name__ == "__main__":

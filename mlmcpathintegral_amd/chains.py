@@ -97,3 +97,56 @@ def combine_levels(table):
     """montecarlomultilevel.cc:255-271: telescoping sum and its statistical error."""
     n, mean, var, tau = table[:, 0], table[:, 1], table[:, 2], table[:, 3]
     return float(mean.sum()), float(torch.sqrt((tau * var / n).sum()))
+
+
+# ---- (level, chain) instances cut into equal-cost shares (BASELINE configs[4]: "level instances sharded over 8 GPUs") ---
+# Level cost is dominated by the finest two levels (cost ~ M_lat), so "level l on rank l % world" leaves most ranks idle
+# and cannot use more ranks than levels.  The unit that shards is the level INSTANCE = (level, block of chains): the
+# list of all (level, chain) pairs, level-major, is cut into `world` contiguous shares of equal cost; a rank owns, per
+# level, one contiguous chain block (possibly empty).  Chain indices are global Philox words, so the estimator does not
+# depend on the cut.  What the ranks exchange per pass is additive: per level
+#   [n, sum y, sum y^2, chains, sum m_c, sum m_c^2, site-steps]     (m_c = mean of chain c)
+# summed by ONE all-reduce of [n_level, 7] doubles; mean, variance, tau_int (scatter of the independent chain means
+# against the naive error) and cost per sample follow identically on every rank (finish_level_sums).
+N_LEVEL_SUMS = 7
+
+
+def partition_instances(costs, n_chains, world):
+    """costs[l] = cost of one sample of one chain of level l.  Returns shares[rank] = {level: (chain0, count)}; every
+    (level, chain) pair belongs to the rank whose share of the cumulative cost contains the pair's midpoint."""
+    total = float(sum(c * n_chains for c in costs))
+    shares = [dict() for _ in range(world)]
+    cum = 0.0
+    for level, c in enumerate(costs):
+        owner = [min(world - 1, int((cum + (b + 0.5) * c) * world / total)) for b in range(n_chains)]
+        for r in sorted(set(owner)):
+            first = owner.index(r)
+            shares[r][level] = (first, owner.count(r))
+        cum += c * n_chains
+    return shares
+
+
+def level_sums(n_level, rows, device="cpu"):
+    """rows: {level: the 7 additive sums of this rank's chain block of that level}."""
+    t = torch.zeros((n_level, N_LEVEL_SUMS), dtype=torch.float64, device=device)
+    for level, row in rows.items():
+        t[level] = torch.as_tensor(row, dtype=torch.float64, device=device)
+    return t
+
+
+def finish_level_sums(sums):
+    """[n_level, 7] reduced sums -> the [n_level, 5] table (samples, mean, variance, tau_int, cost) of level_table."""
+    s = sums.double().cpu()
+    out = torch.zeros((s.shape[0], N_LEVEL_FIELDS), dtype=torch.float64)
+    for l in range(s.shape[0]):
+        n, s1, s2, nc, m1, m2, work = (float(v) for v in s[l])
+        if n < 2:
+            continue
+        mean = s1 / n
+        var = n / (n - 1.0) * max(s2 / n - mean * mean, 0.0)
+        tau = 1.0
+        if nc > 1 and var > 0:
+            var_c = max(m2 - m1 * m1 / nc, 0.0) / (nc - 1.0)   # scatter of the chain means
+            tau = max((var_c / nc) / (var / n), 1e-3)
+        out[l] = torch.tensor([n, mean, var, tau, work / n], dtype=torch.float64)
+    return out

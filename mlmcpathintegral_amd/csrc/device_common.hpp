@@ -301,6 +301,14 @@ __device__ __forceinline__ double cos_half(double d) {
   return cospi_unit(2.0 * fabs(t));
 }
 
+// cos(x) for |x| < 2^30 (plaquette angles: |x| <= 4 pi): x / (2 pi) reduced to t in [-1/2, 1/2], cos(2 pi t) = cos(pi * 2|t|).
+// Absolute error ~|x| 2e-16 + 1e-16: ~25 instructions against ~130 for the general cos() with its Payne-Hanek path.
+__device__ __forceinline__ double cos_reduced(double x) {
+  const double v = x * (0.5 / kPi);
+  const double t = v - rint(v);
+  return cospi_unit(2.0 * fabs(t));
+}
+
 // The sampler in three pieces so that callers can run the (divergent) attempt loop as a per-lane
 // work queue: vm_envelope once per draw, vm_attempt_pair until it returns true, vm_angle once.
 __device__ __forceinline__ double vm_clamp(double kappa) {

@@ -765,8 +765,8 @@ __global__ void __launch_bounds__(256) lattice_reduce_kernel(uint32_t Mt, uint32
     for (uint32_t j = blockIdx.x; j < Mx; j += gridDim.x)
       for (uint32_t i = threadIdx.x; i < Mt; i += blockDim.x) {
         const double th = plaquette_angle(t, Mt, Mx, i, j);
-        if (OP == L_SCHW_ENERGY) acc[0] += 1. - cos(th);
-        if (OP == L_PLAQ) acc[0] += cos(th);
+        if (OP == L_SCHW_ENERGY) acc[0] += 1. - cos_reduced(th);
+        if (OP == L_PLAQ) acc[0] += cos_reduced(th);
         if (OP == L_CHARGE) acc[0] += mod_2pi(th);
       }
   }
@@ -817,9 +817,9 @@ __global__ void __launch_bounds__(256) schwinger_force_kernel(uint32_t Mt, uint3
     const uint32_t jm = j == 0 ? Mx - 1 : j - 1;
     for (uint32_t i = threadIdx.x; i < Mt; i += blockDim.x) {
       const uint32_t im = i == 0 ? Mt - 1 : i - 1;
-      const double F = beta * sin(plaquette_angle(t, Mt, Mx, i, j));
-      const double Fd = beta * sin(plaquette_angle(t, Mt, Mx, i, jm));
-      const double Fl = beta * sin(plaquette_angle(t, Mt, Mx, im, j));
+      const double F = beta * sin_reduced(plaquette_angle(t, Mt, Mx, i, j));
+      const double Fd = beta * sin_reduced(plaquette_angle(t, Mt, Mx, i, jm));
+      const double Fl = beta * sin_reduced(plaquette_angle(t, Mt, Mx, im, j));
       f[(size_t)j * Mt + i] = make_double2(F - Fd, Fl - F);
     }
   }
@@ -1274,9 +1274,9 @@ __global__ void __launch_bounds__(256)
       for (uint32_t i = threadIdx.x; i < Mt; i += blockDim.x) {
         const uint32_t im = i == 0 ? Mt - 1 : i - 1;
         const size_t o = (size_t)j * Mt + i;
-        const double F = coupling * sin(plaquette_angle(t, Mt, Mx, i, j));
-        const double Fd = coupling * sin(plaquette_angle(t, Mt, Mx, i, jm));
-        const double Fl = coupling * sin(plaquette_angle(t, Mt, Mx, im, j));
+        const double F = coupling * sin_reduced(plaquette_angle(t, Mt, Mx, i, j));
+        const double Fd = coupling * sin_reduced(plaquette_angle(t, Mt, Mx, i, jm));
+        const double Fl = coupling * sin_reduced(plaquette_angle(t, Mt, Mx, im, j));
         double2 pn = p[o];
         pn.x -= dtp * (F - Fd);
         pn.y -= dtp * (Fl - F);

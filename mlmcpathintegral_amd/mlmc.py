@@ -1,25 +1,25 @@
-"""Batched, level-sharded multilevel Monte Carlo over device chains (1-D actions).
+"""Batched multilevel Monte Carlo over device chains (1-D actions), level instances sharded over ranks.
 
 The telescoping estimator of montecarlo/montecarlomultilevel.cc:71-204 with B independent chains per level:
     Q = sum_l E[Y_l],   Y_{L-1} = Q_{L-1}(x)                    (coarsest level: HMCSampler)
                         Y_l     = Q_l(theta) - Q_{l+1}(x_c)      (TwoLevelMetropolisStep fed by the sampler of level l+1)
-Level l lives on rank l % world (chains.level_owner); per pass the ranks exchange the [n_level, 5] table of
-chains.py.  Everything that computes runs through the C ABI (ops.PathHMC, ops.PathTwoLevelStep, mlmcpi_qoi_*,
-mlmcpi_stats_accumulate); this module is the host loop only -- the Python twin of MonteCarloMultiLevel in
-include/mlmcpi/multilevel.hh, for tests and bench.py.
+A level INSTANCE is (level, block of chains); chains.partition_instances cuts the (level, chain) pairs into `world`
+equal-cost shares, so a rank owns at most one chain block per level.  Per pass the ranks all-reduce the additive
+[n_level, 7] sums of chains.py.  Everything that computes runs through the C ABI (ops.PathHMC, ops.PathTwoLevelStep,
+mlmcpi_qoi_*, mlmcpi_stats_accumulate); this module is the host loop only -- the Python twin of MonteCarloMultiLevel
+in include/mlmcpi/multilevel.hh, for tests and bench.py.
 """
-import math
-
 import torch
 
 from . import abi, chains, ops
 
 
 class PathLevel:
-    """One level instance: the sampler of level l+1 (or of the coarsest level) and the two-level step, B chains."""
+    """One level instance: the sampler of level l+1 (or of the coarsest level) and the two-level step, chains
+    [chain0, chain0 + B) of the level."""
 
     def __init__(self, acts, level, B, nt, dts, seed, chain0=0, n_sub=2, qoi=None):
-        self.level, self.B, self.n_sub = level, B, n_sub
+        self.level, self.B, self.n_sub, self.chain0 = level, B, n_sub, chain0
         self.coarsest = level == len(acts) - 1
         self.qoi = qoi or ops.qoi_xsquared
         src = level if self.coarsest else level + 1           # level whose sampler feeds this estimator
@@ -58,17 +58,19 @@ class PathLevel:
         self.n_draws += 1
         return y
 
-    def row(self, cost=None):
-        """(samples, mean, variance, tau_int, cost) of this level; chains are independent, so the error of the
-        mean comes from the scatter of the per-chain means and tau_int is reported as their ratio."""
+    def sums(self):
+        """The 7 additive sums of chains.level_sums for this chain block."""
         n = self.acc[:, 0]
-        chain_mean = self.acc[:, 1] / n
         tot = chains.pack_moments(self.acc)
-        s = chains.summarise(tot, chain_means=chain_mean)
-        tau = (s["error"] / s["naive_error"]) ** 2 if s["naive_error"] > 0 else 1.0
-        if cost is None:
-            cost = float(self.site_steps) / max(1, self.n_draws * self.B)   # site-steps per sample
-        return (float(s["samples"]), s["mean"], s["variance"], max(tau, 1e-3), cost)
+        m = self.acc[:, 1] / torch.clamp(n, min=1.0)
+        return [float(tot[0]), float(tot[1]), float(tot[2]), float((n > 0).sum()), float(m.sum()), float((m * m).sum()),
+                float(self.site_steps)]
+
+
+def level_costs(acts, nt, n_sub):
+    """site-steps per Y sample of one chain of each level: sampler trajectories of the feeding level + two-level pass"""
+    L = len(acts)
+    return [n_sub * (nt + 1) * acts[l if l == L - 1 else l + 1].M + (0 if l == L - 1 else acts[l].M) for l in range(L)]
 
 
 class PathMLMC:
@@ -78,9 +80,16 @@ class PathMLMC:
         self.acts = [abi.path_action(kind, M0 >> l, T_final, p["m0"], p["mu2"], p["lam"], p["x0"]) for l in range(n_level)]
         # stable leapfrog step ~ a^(1/2) for the kinetic term and acceptance ~ M dt^4: scale gently with the level
         self.dts = [dt0 * (2.0 ** (0.25 * l)) for l in range(n_level)]
-        self.n_level, self.rank, self.world = n_level, rank, world
-        self.levels = {l: PathLevel(self.acts, l, B, nt, self.dts, seed, chain0=0, n_sub=n_sub)
-                       for l in chains.owned_levels(n_level, rank, world)}
+        self.n_level, self.rank, self.world, self.B = n_level, rank, world, B
+        self.shares = chains.partition_instances(level_costs(self.acts, nt, n_sub), B, world)
+        self.levels = {l: PathLevel(self.acts, l, nb, nt, self.dts, seed, chain0=c0, n_sub=n_sub)
+                       for l, (c0, nb) in self.shares[rank].items()}
+
+    def describe(self):
+        return {str(l): {"chain0": lv.chain0, "chains": lv.B, "M_lat": lv.act_src.M} for l, lv in sorted(self.levels.items())}
+
+    def state_entries(self):
+        return sum(lv.B * lv.act_src.M for lv in self.levels.values())
 
     def thermalise(self, n):
         for lv in self.levels.values():
@@ -91,9 +100,16 @@ class PathMLMC:
             for _ in range(n_samples):
                 lv.sample()
 
+    def packed_finest(self):
+        """per-chain moment rows of the finest level instance this rank owns (zeros if it owns none)"""
+        if not self.levels:
+            return torch.zeros((1, chains.N_MOMENTS), dtype=torch.float64, device="cuda")
+        return self.levels[min(self.levels)].acc
+
     def table(self, device="cpu"):
-        t = chains.level_table(self.n_level, {l: lv.row() for l, lv in self.levels.items()}, device=device)
-        return chains.allreduce_level_table(t)
+        """[n_level, 5] (samples, mean, variance, tau_int, cost), identical on every rank: one all-reduce of the sums"""
+        s = chains.level_sums(self.n_level, {l: lv.sums() for l, lv in self.levels.items()}, device=device)
+        return chains.finish_level_sums(chains.allreduce_level_table(s))
 
     def estimate(self, device="cpu"):
         t = self.table(device)

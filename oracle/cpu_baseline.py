@@ -44,8 +44,15 @@ def _worker(args):
         units = size * (nt + 1)
         s = L.orc_hmc_new(A.h, nt, dt, 1, 0, 0, 0, 0)
         draw = lambda x: L.orc_hmc_draw(s, x)
-    x = np.zeros(A.size)
-    draw(x)  # warm-up (page in, first touch)
+    # start where the reference starts (rotor / Schwinger: U(-pi, pi) per entry, rotoraction.cc:82-89,
+    # quenchedschwingeraction.cc:198-204; others zero) and move off it before timing: the rejection rate of the heat
+    # bath and the HMC acceptance depend on the state
+    if workload in ("schwinger", "rotor_sweep", "rotor"):
+        x = np.random.default_rng(12345).uniform(-np.pi, np.pi, A.size)
+    else:
+        x = np.zeros(A.size)
+    for _ in range(2):
+        draw(x)  # warm-up (page in, first touch, a first pass of thermalisation)
     t0 = time.perf_counter()
     for _ in range(draws):
         draw(x)
@@ -68,7 +75,16 @@ def main():
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    cores = a.cores or min(avail, 16)
+    # One chain per core the job may actually use: the scheduler affinity, cut down to the cgroup CPU quota when there is
+    # one, and to 16 (the CPU share of a 1-GPU job on the GPU boxes, where the affinity mask shows the whole host).
+    quota = avail
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = max(1, int(int(q) / int(period)))
+    except (OSError, ValueError):
+        pass
+    cores = a.cores or min(avail, quota, 16)
     import oracle as O
     O.build()  # compile once, before forking
     job = (a.workload, a.size, a.draws, a.n_overrelax, a.n_heatbath, a.nt, a.dt)
@@ -77,7 +93,7 @@ def main():
         res = pool.map(_worker, [job] * cores)
     wall = time.perf_counter() - t0
     rate = sum(u / el for u, el in res)  # all processes run concurrently: aggregate rate
-    print(json.dumps({"value": rate, "per_core": rate / cores, "cores": cores, "wall_s": wall,
+    print(json.dumps({"value": rate, "per_core": rate / cores, "cores": cores, "cores_available": avail, "wall_s": wall,
                       "sample": f"{a.draws} draws per core of {a.workload} {a.size}, one chain per core"}))
 
 

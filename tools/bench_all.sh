@@ -1,13 +1,19 @@
 #!/bin/bash
-# Secondary workloads (BASELINE configs 2, 3, 5-finest) -- one JSON line each.
+# Every bench workload once (short), JSON lines into gpurun_out/bench_<tag>_<workload>.json; then the N = 2 rehearsal of
+# the rank-spawning path on one GPU (gloo backend, ranks share the device).
 set -o pipefail
+TAG=${1:-all}
 mkdir -p gpurun_out
-for W in rotor_hmc gff quartic_hmc ho_hmc rotor_sweep quartic_mlmc; do
-  timeout -k 10 400 python bench.py --workload $W --steps 5 --warmup 1 > gpurun_out/bench_$W.json 2> gpurun_out/bench_$W.err || { echo "$W failed"; tail -5 gpurun_out/bench_$W.err; exit 1; }
+timeout -k 10 400 python bench.py --steps 10 --warmup 2 > gpurun_out/bench_${TAG}.json 2> gpurun_out/bench_${TAG}.err || { tail -5 gpurun_out/bench_${TAG}.err; exit 1; }
+cut -c1-600 gpurun_out/bench_${TAG}.json
+for W in gff rotor_hmc quartic_hmc ho_hmc quartic_mlmc rotor_sweep; do
+  timeout -k 10 400 python bench.py --workload $W --steps 5 --warmup 1 > gpurun_out/bench_${TAG}_$W.json 2> gpurun_out/bench_${TAG}_$W.err || { echo "$W failed"; tail -5 gpurun_out/bench_${TAG}_$W.err; exit 1; }
   python - <<PY
 import json
-r=json.load(open("gpurun_out/bench_$W.json"))
-rf=r.get("roofline",{})
-print("$W", "value %.2f G/s"%(r["value"]/1e9), "ms/step %.3f"%r["ms_per_step"], "roofline frac %.3f"%rf.get("frac",0), "launch_ms %.3f"%rf.get("launch_ms",0), "HB", r.get("heatbath",{}).get("launch_ms"), "cpu %.3g (%s cores)"%(r["cpu_baseline"]["value"], r["cpu_baseline"]["cores"]), "x%.0f"%r.get("gpu_over_cpu",0), "qoi", r["qoi_mean"])
+r = json.load(open("gpurun_out/bench_${TAG}_$W.json"))
+print("$W", "%.4g" % r["value"], r["unit"], "ms/step %.3f" % r["ms_per_step"], "roofline frac %.3f" % r["roofline"]["frac"], "qoi", r.get("qoi_mean"))
 PY
 done
+MLMCPI_BENCH_BACKEND=gloo timeout -k 10 400 python bench.py --gpus 2 --steps 4 --warmup 1 --chains 8 --no-extra-points > gpurun_out/bench_${TAG}_n2.json 2> gpurun_out/bench_${TAG}_n2.err; echo "n2 rehearsal exit $?"; cut -c1-300 gpurun_out/bench_${TAG}_n2.json
+MLMCPI_BENCH_BACKEND=gloo timeout -k 10 400 python bench.py --gpus 2 --workload quartic_mlmc --steps 3 --warmup 1 --chains 64 > gpurun_out/bench_${TAG}_mlmc_n2.json 2> gpurun_out/bench_${TAG}_mlmc_n2.err; echo "mlmc n2 rehearsal exit $?"; cut -c1-300 gpurun_out/bench_${TAG}_mlmc_n2.json
+timeout -k 10 120 python bench.py --gpus 2 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/bench_${TAG}_n2_nogpu.json 2> gpurun_out/bench_${TAG}_n2_nogpu.err; echo "n2 without a second GPU: exit $? (must be non-zero)"
