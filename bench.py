@@ -343,7 +343,7 @@ def main():
         extra["single_chain"]["note"] = "BASELINE configs[3] read literally: one chain per GPU (16 MiB state, cache resident)"
 
     # the one collective: packed per-chain moments of the QoI, summed over ranks (RCCL)
-    packed = chains.allreduce_moments(chains.pack_moments(acc_of()).to(coll_device))
+    packed, collective = stats_allreduce(chains.pack_moments(acc_of()), rank, world, local, backend, torch, dist, chains)
     if a.workload == "quartic_mlmc":
         mlmc_q, mlmc_e, mlmc_t = est.estimate(device=coll_device)  # the level-table exchange (RCCL when world > 1)
         mlmc_t = mlmc_t.cpu()
@@ -371,6 +371,7 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "step_includes": ["sampler->draw", "qoi->evaluate", "stats->record_sample"],
+            "stats_collective": collective,
             "kernel_build": build_id(),
         }
         if a.workload in ("schwinger", "gff"):
@@ -423,6 +424,52 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def stats_allreduce(packed, rank, world, local, backend, torch, dist, chains):
+    """Sum of the packed statistics buffer over ranks.  With RCCL ranks it goes through the library's own C entry point
+    (include/mlmcpi_comm.h, libmlmcpi_rccl.so: ncclAllReduce on the RCCL runtime this process already carries) -- the
+    same call the C++ Statistics / MonteCarlo classes make through mlmcpi::RcclExchange; torch.distributed only carries
+    the 128-byte rendezvous id.  Should that path fail or stall on any rank, every rank falls back to
+    torch.distributed's all_reduce (same RCCL underneath) and says so."""
+    if world == 1:
+        return packed.cpu(), "none (one rank)"
+    if backend != "nccl":
+        return chains.allreduce_moments(packed.cpu()), f"torch.distributed all_reduce ({backend} rehearsal)"
+    import threading
+    from mlmcpathintegral_amd import comm
+    how, out = "", {}
+    try:
+        comm.open_runtime()
+        idt = torch.zeros(comm.ID_BYTES, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            idt.copy_(torch.frombuffer(bytearray(comm.unique_id()), dtype=torch.uint8))
+        dist.broadcast(idt, src=0)
+        id128 = bytes(idt.cpu().tolist())
+        buf = packed.detach().clone().contiguous()
+
+        def work():
+            try:
+                c = comm.Comm(rank, world, id128, local)
+                c.allreduce_sum_(buf)
+                torch.cuda.synchronize()
+                out["ok"] = True
+                out["comm"] = c
+            except Exception as e:  # noqa: BLE001 -- any failure means: fall back
+                out["err"] = repr(e)[:200]
+        t = threading.Thread(target=work, daemon=True)
+        t.start()
+        t.join(timeout=90.0)
+        if t.is_alive():
+            out["err"] = "timed out after 90 s"
+    except Exception as e:  # noqa: BLE001
+        out["err"] = repr(e)[:200]
+    ok = torch.tensor([1.0 if out.get("ok") else 0.0], device="cuda")
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if float(ok.item()) == 1.0:
+        return buf.cpu(), "mlmcpi_comm_allreduce_sum_f64 (libmlmcpi_rccl.so: ncclAllReduce over xGMI; rendezvous id via torch.distributed)"
+    red = chains.allreduce_moments(packed.detach().clone())
+    return red.cpu(), f"torch.distributed all_reduce (fallback; libmlmcpi_rccl.so path: {out.get('err', 'failed on another rank')})"
 
 
 def register_resident_roofline(kernel, launch_ms, floor_bytes, streaming_bytes, valu, note):

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <thread>
 
 #include "mlmcpi/multilevel.hh"
 
@@ -352,6 +353,81 @@ int main(int argc, char **argv) {
                 st->error(), exact, mc.get_sampler()->p_accept());
     EXPECT(std::fabs(st->average() - exact) < 5 * std::fmax(st->error(), 5e-4), "Schwinger CoarsenBoth plaquette");
     EXPECT(mc.get_sampler()->p_accept() > 0.5, "Schwinger CoarsenBoth acceptance");
+  }
+  // ---- OverrelaxedHeatBathSampler::draw without a copy: same chain as the plain C-ABI sweeps, lent samples stay intact ----
+  {
+    auto lat = std::make_shared<Lattice2D>(64, 64, CoarsenBoth);
+    auto act = std::make_shared<QuenchedSchwingerAction>(lat, nullptr, RenormalisationNone, 1.0);
+    act->set_seed(77, 3);
+    OverrelaxedHeatBathParameters hb;
+    hb.n_sweep_heatbath = 1; hb.n_sweep_overrelax = 5; hb.n_burnin = 0; hb.batch = 2;
+    OverrelaxedHeatBathSampler s(act, hb);
+    // the same chain through the in-place C entry point
+    const unsigned n = act->sample_size();
+    auto ref = std::make_shared<SampleState>(n, 2), scr = std::make_shared<SampleState>(n, 2);
+    act->initialise_state(ref);
+    auto a = std::make_shared<SampleState>(n, 2), b = std::make_shared<SampleState>(n, 2), keep = std::make_shared<SampleState>(n, 2);
+    double worst = 0, kept_drift = 0;
+    std::vector<double> kept;
+    for (int d = 0; d < 7; ++d) {
+      auto &out = (d & 1) ? b : a;
+      s.draw(out);
+      check(mlmcpi_lattice_sweep_draw(&act->abi_action(), ref->device_mutable(), scr->device_mutable(), 2, 5, 1, 77, 3, 6 * d, 0, nullptr), "sweep");
+      for (size_t l = 0; l < out->data.size(); l += 97) worst = std::fmax(worst, std::fabs(out->data[l] - ref->data[l]));
+      if (d == 1) {  // hold on to the second sample while the sampler moves on
+        keep->share(*out);
+        kept.assign(keep->data.data(), keep->data.data() + keep->data.size());
+      }
+    }
+    for (size_t l = 0; l < kept.size(); ++l) kept_drift = std::fmax(kept_drift, std::fabs(keep->data[l] - kept[l]));
+    EXPECT(worst == 0.0, "zero-copy draw differs from the in-place sweeps by %g", worst);
+    EXPECT(kept_drift == 0.0, "a sample lent to the caller was overwritten (%g)", kept_drift);
+    EXPECT(s.pool_size() <= 4, "sampler buffer pool grew to %zu", s.pool_size());
+    std::printf(" zero-copy OverrelaxedHeatBathSampler: 7 draws identical to in-place sweeps, lent sample intact, pool %zu buffers\n", s.pool_size());
+  }
+  // ---- cross-rank statistics: 2 ranks (threads of this process, one GPU) through MonteCarloSingleLevel -------------------------
+  {
+    const int W = 2;
+    auto hub = std::make_shared<ThreadExchangeHub>(W);
+    std::vector<double> avg(W), err(W);
+    std::vector<unsigned> total(W), local(W), passes(W);
+    std::vector<std::thread> ranks;
+    for (int r = 0; r < W; ++r)
+      ranks.emplace_back([&, r] {
+        auto lat = std::make_shared<Lattice2D>(16, 16, CoarsenBoth);
+        auto act = std::make_shared<QuenchedSchwingerAction>(lat, nullptr, RenormalisationNone, 1.0);
+        act->set_seed(2481317, (uint32_t)r);  // chain index = rank: independent Philox streams
+        OverrelaxedHeatBathParameters hb;
+        hb.n_sweep_heatbath = 1; hb.n_sweep_overrelax = 1; hb.n_burnin = 50;
+        SingleLevelMCParameters mp;
+        mp.n_burnin = 100; mp.n_samples = 0; mp.epsilon = 2e-3; mp.n_min_samples_qoi = 200; mp.n_autocorr_window = 20;
+        MonteCarloSingleLevel mc(act, std::make_shared<QoIAvgPlaquette>(lat), std::make_shared<OverrelaxedHeatBathSamplerFactory>(hb), mp,
+                                 std::make_shared<ThreadExchange>(hub, r));
+        mc.evaluate();
+        auto st = mc.get_statistics();
+        StatsSync sync(*st);
+        avg[r] = st->average(); err[r] = st->error(); total[r] = st->samples(); local[r] = st->local_samples(); passes[r] = mc.passes();
+      });
+    for (auto &t : ranks) t.join();
+    const double exact = 0.446390;  // I1(1) / I0(1)
+    std::printf(" 2-rank single-level MC (thread ranks, one all-reduce per pass): plaquette %.6f +- %.6f (exact %.6f), %u samples "
+                "(%u + %u), %u passes\n", avg[0], err[0], exact, total[0], local[0], local[1], passes[0]);
+    EXPECT(avg[0] == avg[1] && err[0] == err[1] && total[0] == total[1] && passes[0] == passes[1], "ranks disagree on the reduced statistics");
+    EXPECT(total[0] == local[0] + local[1] && local[0] >= local[1] && local[0] - local[1] <= 1 + total[0] / 2, "sample split");
+    EXPECT(std::fabs(avg[0] - exact) < 4 * err[0] && err[0] < 2.5e-3, "2-rank plaquette %.6f +- %.6f", avg[0], err[0]);
+  }
+  // ---- RcclExchange (one rank here: communicator set-up, the all-reduce itself and the tear-down on real RCCL) ------------
+  {
+    RcclExchange ex(0, 1, "/tmp/mlmcpi_test_host_id", 0);
+    std::vector<double> v = {1.5, -2.0, 3.25};
+    ex.allreduce_sum(v.data(), v.size());
+    EXPECT(ex.rank() == 0 && ex.size() == 1 && v[0] == 1.5 && v[1] == -2.0 && v[2] == 3.25, "RcclExchange with one rank");
+    Statistics st("Q", 5, std::make_shared<RcclExchange>(0, 1, "/tmp/mlmcpi_test_host_id2", 0));
+    for (int i = 0; i < 50; ++i) st.record_sample(std::sin(0.3 * i));
+    Statistics local("Q", 5);
+    for (int i = 0; i < 50; ++i) local.record_sample(std::sin(0.3 * i));
+    EXPECT(st.variance() == local.variance() && st.tau_int() == local.tau_int() && st.samples() == 50, "Statistics over RcclExchange");
+    std::printf(" RcclExchange: ncclCommInitRank / ncclAllReduce / ncclCommDestroy through libmlmcpi_rccl.so OK\n");
   }
   std::printf(failures ? "%d FAILURES\n" : "host layer: all checks passed\n", failures);
   return failures ? 1 : 0;

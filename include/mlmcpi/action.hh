@@ -49,6 +49,11 @@ public:
   virtual void sweep(std::shared_ptr<SampleState>, std::shared_ptr<SampleState>, unsigned, unsigned, uint32_t) {
     fatal("overrelaxation update not implemented for this action");
   }
+  /** The same sweeps with the input left untouched: reads d_src, alternates between the work buffers d_w0 and d_w1 (d_w1
+   *  may be d_src); returns 0 / 1 = the work buffer that holds the result.  batch = number of chains. */
+  virtual int sweep_from(const double *, double *, double *, unsigned, unsigned, unsigned, uint32_t) {
+    fatal("overrelaxation update not implemented for this action");
+  }
   /** action.hh:130-143: transfers between this level and the next coarser / finer one */
   virtual void copy_from_coarse(const std::shared_ptr<SampleState>, std::shared_ptr<SampleState>) { fatal("cannot copy from coarse lattice."); }
   virtual void copy_from_fine(const std::shared_ptr<SampleState>, std::shared_ptr<SampleState>) { fatal("cannot copy from fine lattice."); }
@@ -219,6 +224,13 @@ public:
     check(mlmcpi_path_sweep_draw(&abi, x->device_mutable(), scratch->device_mutable(), x->batch(), n_or, n_hb, seed,
                                  chain0, sweep0, nullptr), "path_sweep_draw");
   }
+  int sweep_from(const double *d_src, double *d_w0, double *d_w1, unsigned batch, unsigned n_or, unsigned n_hb,
+                 uint32_t sweep0) override {
+    int32_t where = 0;
+    check(mlmcpi_path_sweep_draw_from(&abi, d_src, d_w0, d_w1, batch, n_or, n_hb, seed, chain0, sweep0, &where, nullptr),
+          "path_sweep_draw_from");
+    return where;
+  }
   /** rotoraction.hh:195-213 */
   double getWcurvature(const double x_m, const double x_p) const { return 2.0 * m0 / a_lat * std::fabs(std::cos(0.5 * (x_p - x_m))); }
   double getWminimum(const double x_m, const double x_p) const {
@@ -256,6 +268,13 @@ public:
     check(mlmcpi_lattice_sweep_draw_pingpong(&abi, phi->device_mutable(), scratch->device_mutable(), phi->batch(), n_or,
                                              n_hb, seed, chain0, sweep0, fuse, &in_scratch, nullptr), "lattice_sweep_draw");
     if (in_scratch) phi->swap_device(*scratch);  // no copy: the buffers exchange roles
+  }
+  int sweep_from(const double *d_src, double *d_w0, double *d_w1, unsigned batch, unsigned n_or, unsigned n_hb,
+                 uint32_t sweep0) override {
+    int32_t where = 0;
+    check(mlmcpi_lattice_sweep_draw_from(&abi, d_src, d_w0, d_w1, batch, n_or, n_hb, seed, chain0, sweep0, fuse, &where, nullptr),
+          "lattice_sweep_draw_from");
+    return where;
   }
   /** quenchedschwingeraction.cc:92-195, gffaction.cc:97-118: `this` is the level being written to */
   void copy_from_coarse(const std::shared_ptr<SampleState> phi_coarse, std::shared_ptr<SampleState> phi_state) override {

@@ -439,6 +439,16 @@ public:
   virtual void allreduce_sum(std::vector<double> &table) = 0;
 };
 
+/** the level table over any Exchange of exchange.hh (RcclExchange in production) */
+class LevelExchangeOver : public LevelExchange {
+public:
+  explicit LevelExchangeOver(std::shared_ptr<Exchange> e_) : e(e_) {}
+  void allreduce_sum(std::vector<double> &table) override { e->allreduce_sum(table.data(), table.size()); }
+
+private:
+  std::shared_ptr<Exchange> e;
+};
+
 /** montecarlomultilevel.cc:7-282: telescoping-sum estimator Q = sum_l E[Y_l], Y_L = Q_L on the coarsest
  *  level, Y_l = Q_l(x_f) - Q_{l+1}(x_c) from the two-level step; sample numbers from the variance / cost
  *  model of :148-164.  Levels are independent estimators (each owns its samplers and states), which is
@@ -541,7 +551,10 @@ public:
     for (unsigned int ell = 0; ell < n_level; ++ell) sum += std::sqrt(table[5 * ell + 2] * table[5 * ell + 4]);
     for (unsigned int ell = 0; ell < n_level; ++ell) {
       const double V = table[5 * ell + 2], C = table[5 * ell + 4];
-      n_target[ell] = (unsigned int)std::ceil(two_epsilon_inv2 * sum * std::sqrt(V / C) * table[5 * ell + 3]);
+      // a level without variance or cost information yet (V or C zero / NaN) keeps its target instead of casting a
+      // non-finite number (undefined behaviour); the reference has the same division and no guard
+      const double want = std::ceil(two_epsilon_inv2 * sum * std::sqrt(V / C) * table[5 * ell + 3]);
+      if (std::isfinite(want) && want < 4294967295.0) n_target[ell] = (unsigned int)want;
       sufficient = sufficient && (table[5 * ell] >= n_target[ell]);
     }
     return sufficient;
@@ -600,8 +613,10 @@ private:
   }
   /** montecarlomultilevel.cc:193-204 */
   double cost_eff(const int ell) const {
-    if (ell == (int)n_level - 1) return t_indep[ell - 1] * coarse_sampler[ell - 1]->cost_per_sample();
-    return twolevel_step[ell]->cost_per_sample() + t_indep[ell] * coarse_sampler[ell]->cost_per_sample();
+    const double cost = ell == (int)n_level - 1
+                            ? t_indep[ell - 1] * coarse_sampler[ell - 1]->cost_per_sample()
+                            : twolevel_step[ell]->cost_per_sample() + t_indep[ell] * coarse_sampler[ell]->cost_per_sample();
+    return std::ceil(stats_qoi[ell]->tau_int()) * cost;
   }
 
   const MultiLevelMCParameters param;

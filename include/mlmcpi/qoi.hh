@@ -1,5 +1,7 @@
 // qoi.hh -- QoI interface (qoi/quantityofinterest.hh:16-36) and the five observables of the sweep
-// path as device reductions.  evaluate() returns chain 0; evaluate_batch() all chains of the state.
+// path as device reductions.  evaluate() returns chain 0; evaluate_batch() all chains of the state;
+// evaluate_device() leaves the per-chain values on the device (asynchronous: no host round trip per sample, for
+// loops that accumulate statistics on the device with mlmcpi_stats_accumulate).
 #ifndef MLMCPI_QOI_HH
 #define MLMCPI_QOI_HH
 #include "action.hh"
@@ -11,7 +13,20 @@ public:
   QoI() {}
   virtual ~QoI() {}
   const double virtual evaluate(const std::shared_ptr<SampleState> phi_state) { return evaluate_batch(phi_state)[0]; }
-  virtual std::vector<double> evaluate_batch(const std::shared_ptr<SampleState> phi_state) = 0;
+  virtual std::vector<double> evaluate_batch(const std::shared_ptr<SampleState> phi_state) {
+    if (!out || out_n != phi_state->batch()) {
+      out = std::make_unique<DeviceVector>(phi_state->batch());  // allocated once per batch size, not per sample
+      out_n = phi_state->batch();
+    }
+    evaluate_device(phi_state, (double *)out->ptr());
+    return out->download<double>();
+  }
+  /** d_out[b] = Q(chain b), enqueued on the default stream */
+  virtual void evaluate_device(const std::shared_ptr<SampleState> phi_state, double *d_out) = 0;
+
+private:
+  std::unique_ptr<DeviceVector> out;
+  unsigned int out_n = 0;
 };
 
 class QoIFactory {
@@ -24,11 +39,9 @@ public:
 class QoIXsquared : public QoI {
 public:
   explicit QoIXsquared(const std::shared_ptr<Lattice1D> lattice) : M_lat(lattice->getM_lat()) {}
-  std::vector<double> evaluate_batch(const std::shared_ptr<SampleState> x) override {
+  void evaluate_device(const std::shared_ptr<SampleState> x, double *d_out) override {
     if (x->size() != M_lat) fatal("Evaluating QoISusceptibility on path of wrong size.");
-    DeviceVector out(x->batch());
-    check(mlmcpi_qoi_xsquared(x->device(), M_lat, x->batch(), (double *)out.ptr(), nullptr), "qoi_xsquared");
-    return out.download<double>();
+    check(mlmcpi_qoi_xsquared(x->device(), M_lat, x->batch(), d_out, nullptr), "qoi_xsquared");
   }
 private:
   const unsigned int M_lat;
@@ -38,11 +51,9 @@ private:
 class QoISusceptibility : public QoI {
 public:
   explicit QoISusceptibility(const std::shared_ptr<Lattice1D> lattice) : M_lat(lattice->getM_lat()), T_final(lattice->getT_final()) {}
-  std::vector<double> evaluate_batch(const std::shared_ptr<SampleState> x) override {
+  void evaluate_device(const std::shared_ptr<SampleState> x, double *d_out) override {
     if (x->size() != M_lat) fatal("Evaluating QoISusceptibility on path of wrong size.");
-    DeviceVector out(x->batch());
-    check(mlmcpi_qoi_susceptibility(x->device(), M_lat, T_final, x->batch(), (double *)out.ptr(), nullptr), "qoi_susceptibility");
-    return out.download<double>();
+    check(mlmcpi_qoi_susceptibility(x->device(), M_lat, T_final, x->batch(), d_out, nullptr), "qoi_susceptibility");
   }
 private:
   const unsigned int M_lat;
@@ -53,11 +64,9 @@ private:
 class QoI2DSusceptibility : public QoI {
 public:
   explicit QoI2DSusceptibility(const std::shared_ptr<Lattice2D> lattice) : Mt_lat(lattice->getMt_lat()), Mx_lat(lattice->getMx_lat()) {}
-  std::vector<double> evaluate_batch(const std::shared_ptr<SampleState> phi) override {
+  void evaluate_device(const std::shared_ptr<SampleState> phi, double *d_out) override {
     if (phi->size() != 2 * Mt_lat * Mx_lat) fatal("Evaluating QoI2DSusceptibility on state of wrong size.");
-    DeviceVector out(phi->batch());
-    check(mlmcpi_qoi_2d_susceptibility(phi->device(), Mt_lat, Mx_lat, phi->batch(), (double *)out.ptr(), nullptr), "qoi_2d_susceptibility");
-    return out.download<double>();
+    check(mlmcpi_qoi_2d_susceptibility(phi->device(), Mt_lat, Mx_lat, phi->batch(), d_out, nullptr), "qoi_2d_susceptibility");
   }
 private:
   const unsigned int Mt_lat, Mx_lat;
@@ -67,11 +76,9 @@ private:
 class QoIAvgPlaquette : public QoI {
 public:
   explicit QoIAvgPlaquette(const std::shared_ptr<Lattice2D> lattice) : Mt_lat(lattice->getMt_lat()), Mx_lat(lattice->getMx_lat()) {}
-  std::vector<double> evaluate_batch(const std::shared_ptr<SampleState> phi) override {
+  void evaluate_device(const std::shared_ptr<SampleState> phi, double *d_out) override {
     if (phi->size() != 2 * Mt_lat * Mx_lat) fatal("Evaluating QoIAvgPlaquette on state of wrong size.");
-    DeviceVector out(phi->batch());
-    check(mlmcpi_qoi_avg_plaquette(phi->device(), Mt_lat, Mx_lat, phi->batch(), (double *)out.ptr(), nullptr), "qoi_avg_plaquette");
-    return out.download<double>();
+    check(mlmcpi_qoi_avg_plaquette(phi->device(), Mt_lat, Mx_lat, phi->batch(), d_out, nullptr), "qoi_avg_plaquette");
   }
 private:
   const unsigned int Mt_lat, Mx_lat;
@@ -81,10 +88,8 @@ private:
 class QoI2DPhiSquared : public QoI {
 public:
   explicit QoI2DPhiSquared(const std::shared_ptr<Lattice2D> lattice) : M_lat(lattice->getNvertices()) {}
-  std::vector<double> evaluate_batch(const std::shared_ptr<SampleState> phi) override {
-    DeviceVector out(phi->batch());
-    check(mlmcpi_qoi_phi_squared(phi->device(), M_lat, phi->batch(), (double *)out.ptr(), nullptr), "qoi_phi_squared");
-    return out.download<double>();
+  void evaluate_device(const std::shared_ptr<SampleState> phi, double *d_out) override {
+    check(mlmcpi_qoi_phi_squared(phi->device(), M_lat, phi->batch(), d_out, nullptr), "qoi_phi_squared");
   }
 private:
   const unsigned int M_lat;

@@ -8,6 +8,7 @@
 #include <iostream>
 #include <memory>
 #include <typeinfo>
+#include <vector>
 
 #include "action.hh"
 
@@ -174,7 +175,13 @@ struct OverrelaxedHeatBathParameters {
 };
 
 /** overrelaxedheatbathsampler.cc:8-37: n_sweep_overrelax overrelaxation sweeps, then
- *  n_sweep_heatbath heat-bath sweeps, every sample accepted. */
+ *  n_sweep_heatbath heat-bath sweeps, every sample accepted.
+ *
+ *  No copy per draw.  The reference ends draw() with `phi_state->data = phi_state_cur->data` (:30); here the caller's
+ *  state becomes a second holder of the buffer the new sample was written to (SampleState::share), and the sampler
+ *  rotates a small pool of buffers: a draw reads the current sample (which the caller may still hold: it is not written)
+ *  and lets the launches alternate between two buffers nobody else holds.  In the loop of
+ *  MonteCarloSingleLevel::evaluate that settles at three buffers and zero copies. */
 class OverrelaxedHeatBathSampler : public Sampler {
 public:
   OverrelaxedHeatBathSampler(const std::shared_ptr<Action> action_, const OverrelaxedHeatBathParameters p)
@@ -182,28 +189,52 @@ public:
         n_burnin(p.n_burnin), random_order(p.random_order) {
     if (!action->has_local_updates()) fatal("heat bath update not implemented for this action ");
     phi_state_cur = std::make_shared<SampleState>(action->sample_size(), p.batch);
-    scratch = std::make_shared<SampleState>(action->sample_size(), p.batch);
     action->initialise_state(phi_state_cur);
     std::shared_ptr<SampleState> tmp = std::make_shared<SampleState>(action->sample_size(), p.batch);
     for (unsigned int i = 0; i < n_burnin; ++i) draw(tmp);
     reset_stats();
   }
   void draw(std::shared_ptr<SampleState> phi_state) override {
-    action->sweep(phi_state_cur, scratch, n_sweep_overrelax, n_sweep_heatbath, sweep_counter);
+    advance();
+    if (phi_state != phi_state_cur) phi_state->share(*phi_state_cur);
+  }
+  /** the draw without handing the sample out (callers that read current_state()) */
+  void advance() {
+    if (n_sweep_overrelax + n_sweep_heatbath > 0) {
+      std::shared_ptr<DeviceBuffer> src = phi_state_cur->buffer();
+      // `src` is held by phi_state_cur, by this local variable and by the pool if it came from there: one holder more
+      // means somebody outside still reads the current sample
+      long own = 2;
+      for (auto &c : pool) own += (c == src) ? 1 : 0;
+      const bool src_is_lent = src.use_count() > own;
+      std::shared_ptr<DeviceBuffer> w0 = free_buffer(src, nullptr);
+      std::shared_ptr<DeviceBuffer> w1 = src_is_lent ? free_buffer(src, w0) : src;
+      const int where = action->sweep_from(src->p, w0->p, w1->p, phi_state_cur->batch(), n_sweep_overrelax, n_sweep_heatbath,
+                                           sweep_counter);
+      phi_state_cur->adopt(where == 0 ? w0 : w1);
+    }
     sweep_counter += n_sweep_overrelax + n_sweep_heatbath;
     accept = true;
     n_total_samples++;
     n_accepted_samples++;
-    phi_state->data = phi_state_cur->data;
   }
   void set_state(std::shared_ptr<SampleState> phi_state) override { phi_state_cur->data = phi_state->data; }
   std::shared_ptr<SampleState> current_state() { return phi_state_cur; }
+  size_t pool_size() const { return pool.size(); }
 
 protected:
+  /** a pool buffer nobody else holds (other than `a`, `b`), allocated on first need */
+  std::shared_ptr<DeviceBuffer> free_buffer(const std::shared_ptr<DeviceBuffer> &a, const std::shared_ptr<DeviceBuffer> &b) {
+    for (auto &c : pool)
+      if (c != a && c != b && c.use_count() == 1) return c;
+    pool.push_back(std::make_shared<DeviceBuffer>(phi_state_cur->bytes()));
+    return pool.back();
+  }
   const std::shared_ptr<Action> action;
   const unsigned int n_sweep_heatbath, n_sweep_overrelax, n_burnin;
   bool random_order;
-  mutable std::shared_ptr<SampleState> phi_state_cur, scratch;
+  mutable std::shared_ptr<SampleState> phi_state_cur;
+  std::vector<std::shared_ptr<DeviceBuffer>> pool;  // buffers that have carried a sample (some may still be lent out)
   uint32_t sweep_counter = 0;
 };
 

@@ -6,6 +6,12 @@
 // assignment): the authoritative copy lives in HBM and is mirrored to the host lazily, so that
 // Sampler::draw / QoI::evaluate / Action::evaluate never move the state over PCIe unless host code
 // actually reads or writes elements.  `batch` > 1 holds that many independent chains, chain-major.
+//
+// The device copy is a reference-counted buffer.  `a->data = b->data` copies, as in the reference; `a->share(*b)` makes
+// `a` a second holder of b's buffer instead (copy on write).  The sweep sampler ends its draw with the latter: the
+// reference's `phi_state->data = phi_state_cur->data` (overrelaxedheatbathsampler.cc:30) would be a full pass over HBM
+// per sample -- as much traffic as two fused sweeps.  A state that is about to be modified in place while someone else
+// still holds its buffer is detached first (device_mutable), so value semantics are kept.
 #ifndef MLMCPI_SAMPLESTATE_HH
 #define MLMCPI_SAMPLESTATE_HH
 #include <cstdlib>
@@ -30,6 +36,16 @@ inline void check(int status, const char *what) {
   if (status != MLMCPI_OK) fatal(std::string(what) + ": " + mlmcpi_last_error());
 }
 
+/** reference-counted device allocation */
+struct DeviceBuffer {
+  explicit DeviceBuffer(size_t bytes_) : bytes(bytes_) { check(mlmcpi_malloc((void **)&p, bytes), "mlmcpi_malloc"); }
+  ~DeviceBuffer() { mlmcpi_free(p); }
+  DeviceBuffer(const DeviceBuffer &) = delete;
+  DeviceBuffer &operator=(const DeviceBuffer &) = delete;
+  double *p = nullptr;
+  const size_t bytes;
+};
+
 class SampleState {
 public:
   /** Host view with lazy synchronisation; mirrors the uses of Eigen::VectorXd on the sweep path. */
@@ -45,7 +61,8 @@ public:
       if (this == &other) return *this;
       if (size() != other.size()) fatal("SampleState size mismatch in assignment");
       if (other.owner->device_valid) {
-        check(mlmcpi_copy_d2d(owner->dev, other.owner->dev, size() * sizeof(double), nullptr), "copy_d2d");
+        if (owner->dev != other.owner->dev)
+          check(mlmcpi_copy_d2d(owner->device_overwrite(), other.owner->dev->p, size() * sizeof(double), nullptr), "copy_d2d");
         owner->device_valid = true;
         owner->host_valid = false;
       } else {
@@ -71,24 +88,35 @@ public:
   explicit SampleState(const unsigned int M_, const unsigned int batch_ = 1)
       : M(M_), B(batch_), host((size_t)M_ * batch_, 0.0) {
     data.owner = this;
-    check(mlmcpi_malloc((void **)&dev, bytes()), "mlmcpi_malloc");
-    check(mlmcpi_memset(dev, 0, bytes(), nullptr), "mlmcpi_memset");
+    dev = std::make_shared<DeviceBuffer>(bytes());
+    check(mlmcpi_memset(dev->p, 0, bytes(), nullptr), "mlmcpi_memset");
     host_valid = device_valid = true;
   }
-  ~SampleState() { mlmcpi_free(dev); }
   SampleState(const SampleState &) = delete;
   SampleState &operator=(const SampleState &) = delete;
 
   /** Device pointer for reading (uploads pending host writes). */
   const double *device() const {
     const_cast<SampleState *>(this)->to_device();
-    return dev;
+    return dev->p;
   }
-  /** Device pointer for kernels that modify the state. */
+  /** Device pointer for kernels that modify the state in place: a shared buffer is detached (copied) first. */
   double *device_mutable() {
     to_device();
+    if (dev.use_count() > 1) {
+      std::shared_ptr<DeviceBuffer> mine = std::make_shared<DeviceBuffer>(bytes());
+      check(mlmcpi_copy_d2d(mine->p, dev->p, bytes(), nullptr), "copy_d2d");
+      dev = mine;
+    }
     host_valid = false;
-    return dev;
+    return dev->p;
+  }
+  /** Device pointer for kernels that overwrite the whole state: a shared buffer is dropped, not copied. */
+  double *device_overwrite() {
+    if (dev.use_count() > 1) dev = std::make_shared<DeviceBuffer>(bytes());
+    host_valid = false;
+    device_valid = true;
+    return dev->p;
   }
   /** Exchange device buffers with a state of equal shape (ping-pong sweeps end in the scratch). */
   void swap_device(SampleState &other) {
@@ -98,6 +126,27 @@ public:
     std::swap(dev, other.dev);
     host_valid = other.host_valid = false;
   }
+  /** Become a second holder of `other`'s device buffer (no copy).  Both states keep value semantics: whoever modifies
+   *  its state in place while the buffer is shared gets a private copy first (device_mutable). */
+  void share(SampleState &other) {
+    if (M != other.M || B != other.B) fatal("SampleState shape mismatch in share");
+    other.to_device();
+    dev = other.dev;
+    device_valid = true;
+    host_valid = false;
+  }
+  /** the buffer itself, for samplers that rotate a small pool of buffers instead of copying (sampler.hh) */
+  std::shared_ptr<DeviceBuffer> buffer() {
+    to_device();
+    return dev;
+  }
+  void adopt(std::shared_ptr<DeviceBuffer> b) {
+    if (b->bytes != bytes()) fatal("SampleState shape mismatch in adopt");
+    dev = b;
+    device_valid = true;
+    host_valid = false;
+  }
+  bool device_shared() const { return dev.use_count() > 1; }
   unsigned int size() const { return M; }
   unsigned int batch() const { return B; }
   size_t bytes() const { return host.size() * sizeof(double); }
@@ -116,20 +165,21 @@ public:
 private:
   void to_host(bool will_write) {
     if (!host_valid) {
-      check(mlmcpi_copy_d2h(host.data(), dev, bytes(), nullptr), "copy_d2h");
+      check(mlmcpi_copy_d2h(host.data(), dev->p, bytes(), nullptr), "copy_d2h");
       host_valid = true;
     }
     if (will_write) device_valid = false;
   }
   void to_device() {
     if (!device_valid) {
-      check(mlmcpi_copy_h2d(dev, host.data(), bytes(), nullptr), "copy_h2d");
+      if (dev.use_count() > 1) dev = std::make_shared<DeviceBuffer>(bytes());  // never upload into a buffer someone else reads
+      check(mlmcpi_copy_h2d(dev->p, host.data(), bytes(), nullptr), "copy_h2d");
       device_valid = true;
     }
   }
   const unsigned int M, B;
   std::vector<double> host;
-  double *dev = nullptr;
+  std::shared_ptr<DeviceBuffer> dev;
   bool host_valid = false, device_valid = false;
 };
 

@@ -140,6 +140,12 @@ int mlmcpi_path_sweep_draw(const mlmcpi_path_action *act, double *d_x, double *d
                            uint32_t n_overrelax, uint32_t n_heatbath, uint64_t seed, uint32_t chain0,
                            uint32_t sweep0, void *stream);
 
+/* The same with the input left untouched (see mlmcpi_lattice_sweep_draw_from): reads d_src, alternates between d_w0 and
+ * d_w1 (which may equal d_src), *result_in = 0 / 1 names the buffer holding the result; no final copy. */
+int mlmcpi_path_sweep_draw_from(const mlmcpi_path_action *act, const double *d_src, double *d_w0, double *d_w1, uint32_t B,
+                                uint32_t n_overrelax, uint32_t n_heatbath, uint64_t seed, uint32_t chain0, uint32_t sweep0,
+                                int32_t *result_in, void *stream);
+
 /* TwoLevelMetropolisStep::draw (montecarlo/twolevelmetropolisstep.cc:35-89) with QMAction::copy_from_{coarse,fine}
  * (action/qm/qmaction.cc:7-24) and the action's conditioned fine action: Gaussian for the harmonic / quartic
  * oscillator (action/qm/gaussianconditionedfineaction.cc:7-43), ExpSin2 for the rotor
@@ -198,6 +204,13 @@ int mlmcpi_lattice_sweep_draw(const mlmcpi_lattice_action *act, double *d_phi, d
 int mlmcpi_lattice_sweep_draw_pingpong(const mlmcpi_lattice_action *act, double *d_a, double *d_b, uint32_t B,
                                        uint32_t n_overrelax, uint32_t n_heatbath, uint64_t seed, uint32_t chain0,
                                        uint32_t sweep0, uint32_t fuse, int32_t *result_in_b, void *stream);
+/* Same, with the input left untouched: the first launch reads d_src (never written), the launches then alternate between
+ * the work buffers d_w0 and d_w1; *result_in = 0 / 1 names the work buffer that holds the result.  d_w1 may equal
+ * d_src (then this is the ping-pong form).  This is what Sampler::draw(out) needs to hand `out` the new sample without a
+ * copy while the caller still holds the previous one (sampler/overrelaxedheatbathsampler.cc:30 copies the state out). */
+int mlmcpi_lattice_sweep_draw_from(const mlmcpi_lattice_action *act, const double *d_src, double *d_w0, double *d_w1,
+                                   uint32_t B, uint32_t n_overrelax, uint32_t n_heatbath, uint64_t seed, uint32_t chain0,
+                                   uint32_t sweep0, uint32_t fuse, int32_t *result_in, void *stream);
 /* Action::copy_from_fine / copy_from_coarse between a lattice and its next-coarser level, coarsening
  * factors rt, rx in {1, 2} in the temporal / spatial direction (CoarsenBoth = 2,2; CoarsenTemporal = 2,1;
  * CoarsenSpatial = 1,2; lattice/lattice2d.cc:24-47).  `fine` describes the FINE lattice.

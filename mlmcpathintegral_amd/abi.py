@@ -62,6 +62,7 @@ SIGNATURES = {
     "mlmcpi_path_hmc_run": (_i, [_PA, _vp, _u32, _u32, _d, _u32, _u32, _i, _u64, _u32, _u32, _vp, _vp, _vp, _vp]),
     "mlmcpi_path_hmc_run_layout": (_i, [_PA, _u32, _u32, C.POINTER(C.c_int32)]),
     "mlmcpi_path_sweep_draw": (_i, [_PA, _vp, _vp, _u32, _u32, _u32, _u64, _u32, _u32, _vp]),
+    "mlmcpi_path_sweep_draw_from": (_i, [_PA, _vp, _vp, _vp, _u32, _u32, _u32, _u64, _u32, _u32, _vp, _vp]),
     "mlmcpi_path_twolevel_workspace_bytes": (_i, [_PA, _u32, C.POINTER(_sz)]),
     "mlmcpi_path_twolevel_draw": (_i, [_PA, _PA, _vp, _vp, _u32, _u64, _u32, _u32, _vp, _vp, _vp, _vp]),
     "mlmcpi_path_copy_from_fine": (_i, [_vp, _vp, _u32, _u32, _vp]),
@@ -79,6 +80,7 @@ SIGNATURES = {
     "mlmcpi_lattice_force": (_i, [_LA, _vp, _vp, _u32, _vp]),
     "mlmcpi_lattice_initialise": (_i, [_LA, _vp, _u32, _u64, _u32, _vp]),
     "mlmcpi_lattice_sweep_draw": (_i, [_LA, _vp, _vp, _u32, _u32, _u32, _u64, _u32, _u32, _u32, _vp]),
+    "mlmcpi_lattice_sweep_draw_from": (_i, [_LA, _vp, _vp, _vp, _u32, _u32, _u32, _u64, _u32, _u32, _u32, _vp, _vp]),
     "mlmcpi_lattice_sweep_draw_pingpong": (_i, [_LA, _vp, _vp, _u32, _u32, _u32, _u64, _u32, _u32, _u32,
                                                 C.POINTER(C.c_int32), _vp]),
     "mlmcpi_qoi_phi_squared": (_i, [_vp, _u32, _u32, _vp, _vp]),

@@ -87,7 +87,8 @@ def allreduce_level_table(table, group=None):
 def level_targets(table, epsilon):
     """montecarlomultilevel.cc:148-164: samples needed per level for a statistical error epsilon / sqrt(2);
     returns (targets [n_level], sufficient)."""
-    n, var, tau, cost = table[:, 0], table[:, 2], table[:, 3], table[:, 4]
+    n, var, tau = table[:, 0], table[:, 2], table[:, 3]
+    cost = torch.ceil(tau) * table[:, 4]   # montecarlomultilevel.cc:193-204: C_eff = ceil(tau_int) x cost per sample
     total = torch.sqrt(var * cost).sum()
     targets = torch.ceil(2.0 / (epsilon * epsilon) * total * torch.sqrt(var / cost) * tau)
     return targets, bool((n >= targets).all())
@@ -150,3 +151,110 @@ def finish_level_sums(sums):
             tau = max((var_c / nc) / (var / n), 1e-3)
         out[l] = torch.tensor([n, mean, var, tau, work / n], dtype=torch.float64)
     return out
+
+
+# ---- Statistics across ranks, as the reference defines them (common/statistics.cc:4-95) ----------------------------------
+# Python twin of include/mlmcpi/statistics.hh: the estimator's state is the packed buffer
+#   [avg, avg_longterm, avg2_longterm, avg3_longterm, avg4_longterm, n, n_longterm, S_k[0 .. k_max)]
+# and every estimator is a function of the rank-AVERAGE of the first five entries and of S_k and of the rank-SUM of
+# the counts: one all_reduce(SUM) of the buffer per convergence check (plus one slot per rank for the termination test
+# of montecarlosinglelevel.cc:84-86) replaces the reference's ~10 scalar MPI_Allreduce calls.
+class Statistics:
+    AVG, AVG_LT, AVG2_LT, AVG3_LT, AVG4_LT, N, N_LT, SK0 = range(8)
+
+    def __init__(self, k_max, group=None):
+        self.k_max, self.group = k_max, group
+        self.hard_reset()
+
+    def hard_reset(self):
+        self.buf = [0.0] * (self.SK0 + self.k_max)
+        self.window = []
+
+    def reset(self):
+        self.buf[self.N] = 0.0
+        self.buf[self.AVG] = 0.0
+
+    def record_sample(self, q):
+        b = self.buf
+        b[self.N] += 1.0
+        b[self.N_LT] += 1.0
+        n, nl = b[self.N], b[self.N_LT]
+        self.window.insert(0, q)
+        if len(self.window) > self.k_max:
+            self.window.pop()
+        b[self.AVG] = ((n - 1.0) * b[self.AVG] + q) / (1.0 * n)
+        b[self.AVG_LT] = ((nl - 1.0) * b[self.AVG_LT] + q) / (1.0 * nl)
+        b[self.AVG2_LT] = ((nl - 1.0) * b[self.AVG2_LT] + q * q) / (1.0 * nl)
+        b[self.AVG3_LT] = ((nl - 1.0) * b[self.AVG3_LT] + q * q * q) / (1.0 * nl)
+        b[self.AVG4_LT] = ((nl - 1.0) * b[self.AVG4_LT] + q * q * q * q) / (1.0 * nl)
+        for k, qk in enumerate(self.window):
+            n_k = nl - k
+            b[self.SK0 + k] = ((n_k - 1.0) * b[self.SK0 + k] + self.window[0] * qk) / (1.0 * n_k)
+
+    def local_samples(self):
+        return int(self.buf[self.N])
+
+    def reduce(self, local_value=0.0):
+        """ONE all-reduce: returns the global view g (rank-averages / rank-sums) and the list of every rank's
+        `local_value`."""
+        on = dist.is_available() and dist.is_initialized()
+        size = dist.get_world_size(self.group) if on else 1
+        rank = dist.get_rank(self.group) if on else 0
+        t = torch.tensor(self.buf + [0.0] * size, dtype=torch.float64)
+        t[len(self.buf) + rank] = local_value
+        if size > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        g = t[:len(self.buf)].tolist()
+        for s in (self.AVG, self.AVG_LT, self.AVG2_LT, self.AVG3_LT, self.AVG4_LT):
+            g[s] /= size
+        for k in range(self.k_max):
+            g[self.SK0 + k] /= size
+        return g, t[len(self.buf):].tolist()
+
+    # estimators on a reduced view (statistics.cc:29-95)
+    @classmethod
+    def variance(cls, g):
+        return 1.0 * g[cls.N_LT] / (g[cls.N_LT] - 1.0) * (g[cls.SK0] - g[cls.AVG_LT] * g[cls.AVG_LT])
+
+    @classmethod
+    def tau_int(cls, g):
+        a2 = g[cls.AVG_LT] * g[cls.AVG_LT]
+        t = 0.0
+        for k in range(1, len(g) - cls.SK0):
+            t += (1. - k / (1.0 * g[cls.N_LT])) * (g[cls.SK0 + k] - a2)
+        return max(1.0, 1.0 + 2.0 * t / (g[cls.SK0] - a2))
+
+    @classmethod
+    def error(cls, g):
+        return math.sqrt(cls.tau_int(g) * cls.variance(g) / (1.0 * g[cls.N]))
+
+    @classmethod
+    def variance_error(cls, g):
+        a = g[cls.AVG_LT]
+        return math.sqrt(1.0 / g[cls.N_LT] * (g[cls.AVG4_LT] - 4 * a * g[cls.AVG3_LT] + 8 * a * a * g[cls.AVG2_LT] -
+                                              g[cls.AVG2_LT] * g[cls.AVG2_LT] - 4 * a * a * a * a))
+
+
+def run_single_level(draw_qoi, k_max, n_min, epsilon, n_samples=0, n_burnin=0, group=None, max_passes=1000):
+    """The do-while of MonteCarloSingleLevel::evaluate (montecarlosinglelevel.cc:23-87) on this rank's chain with ONE
+    all-reduce per pass; draw_qoi() = sampler->draw + qoi->evaluate.  Returns (Statistics, reduced view, passes)."""
+    on = dist.is_available() and dist.is_initialized()
+    size = dist.get_world_size(group) if on else 1
+    rank = dist.get_rank(group) if on else 0
+    s = Statistics(k_max, group)
+    for _ in range(n_burnin):
+        s.record_sample(draw_qoi())
+    s.reset()
+    n_target = n_samples if n_samples > 0 else n_min
+    n_local = distribute_n(n_target, rank, size)
+    passes = 0
+    while True:
+        for _ in range(s.local_samples(), n_local):
+            s.record_sample(draw_qoi())
+        g, counts = s.reduce(float(s.local_samples()))
+        if n_samples == 0:
+            n_target = int(math.ceil(Statistics.tau_int(g) * 2.0 / (epsilon * epsilon) * Statistics.variance(g)))
+        n_local = distribute_n(n_target, rank, size)
+        passes += 1
+        if all(counts[r] >= distribute_n(n_target, r, size) for r in range(size)) or passes >= max_passes:
+            return s, g, passes

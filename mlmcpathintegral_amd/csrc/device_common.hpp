@@ -644,7 +644,7 @@ __device__ __forceinline__ double approx_bessel_pdf(double beta, double x, doubl
 // stencil kernels are LDS-issue bound, so their loads are issued through inline asm, which the merger
 // does not see.  The caller issues a group of reads and then ONE lds_wait7() before the first use (the
 // compiler does not track inline-asm loads, cdna_hip_programming.md 5.7).  `addr` is the LDS byte address
-// (these kernels have no static __shared__, so the dynamic array starts at LDS address 0).
+// (the callers add the LDS address of their dynamic array, see schwinger_or_kernel).
 template <int OFF>
 __device__ __forceinline__ double lds_read_f64(uint32_t addr) {
   double v;

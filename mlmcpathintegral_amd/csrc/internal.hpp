@@ -33,10 +33,9 @@ int fail_hip(hipError_t e, const char *what);
 
 inline hipStream_t as_stream(void *s) { return (hipStream_t)s; }
 
-// Library-owned scratch for reduction partials.  One buffer per device, grown on demand (the
-// first call of a given size allocates; steady state does not).  Calls that use it must not
-// overlap on different streams of the same device.
-int scratch(size_t bytes, void **d_ptr);
+// Library-owned scratch for reduction partials: one buffer per (host thread, device, stream), grown on demand (the
+// first call of a given size allocates; steady state does not).  `stream` = the stream the caller launches on.
+int scratch(size_t bytes, void **d_ptr, hipStream_t stream);
 
 inline RngKey make_key(uint64_t seed, uint32_t chain0, uint32_t step) {
   return RngKey{(uint32_t)seed, (uint32_t)(seed >> 32), chain0, step};

@@ -244,6 +244,9 @@ __global__ void __launch_bounds__(NT)
   constexpr int NCI = (BW - 2) / 2, NR1 = BH - 1, T1 = NCI * NR1, M1 = (T1 + NT - 1) / NT;
   extern __shared__ double lds[];
   double *th0 = lds, *th1 = lds + BH * P;
+  // LDS byte address of lds[0] for the ds_read_b64 issued through inline asm (the low word of a flat LDS address is the
+  // LDS offset): 0 today, but static LDS added to this kernel would move it
+  const uint32_t lds0 = (uint32_t)(uintptr_t)lds;
   const uint32_t tile = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
   const uint32_t i0 = tx * TW, j0 = ty * TH;
@@ -279,7 +282,7 @@ __global__ void __launch_bounds__(NT)
       for (int m = 0; m < M0; ++m) {
         if ((m + 1) * NT <= T0 || (int)tid + NT * m < T0) {
           const int o = o0[m] - par * P;
-          const uint32_t a0 = (uint32_t)(o - P) * 8u, a1 = a0 + (uint32_t)(BH * P) * 8u;  // th0 / th1 at (r-1, c)
+          const uint32_t a0 = lds0 + (uint32_t)(o - P) * 8u, a1 = a0 + (uint32_t)(BH * P) * 8u;  // th0 / th1 at (r-1, c)
           double t0_up = lds_read_f64<2 * P * 8>(a0), t0_dn = lds_read_f64<0>(a0), t0_own = lds_read_f64<P * 8>(a0);
           double t1_c = lds_read_f64<P * 8>(a1), t1_r = lds_read_f64<P * 8 + 8>(a1);
           double t1_dc = lds_read_f64<0>(a1), t1_dr = lds_read_f64<8>(a1);
@@ -297,7 +300,7 @@ __global__ void __launch_bounds__(NT)
       for (int m = 0; m < M1; ++m) {
         if ((m + 1) * NT <= T1 || (int)tid + NT * m < T1) {
           const int o = o1[m] - par;
-          const uint32_t a0 = (uint32_t)(o - 1) * 8u, a1 = a0 + (uint32_t)(BH * P) * 8u;  // th0 / th1 at (r, c-1)
+          const uint32_t a0 = lds0 + (uint32_t)(o - 1) * 8u, a1 = a0 + (uint32_t)(BH * P) * 8u;  // th0 / th1 at (r, c-1)
           double t0_c = lds_read_f64<8>(a0), t0_u = lds_read_f64<P * 8 + 8>(a0);
           double t0_lu = lds_read_f64<P * 8>(a0), t0_l = lds_read_f64<0>(a0);
           double t1_r = lds_read_f64<16>(a1), t1_l = lds_read_f64<0>(a1), t1_own = lds_read_f64<8>(a1);
@@ -587,6 +590,7 @@ __global__ void __launch_bounds__(NT)
   constexpr int NRR = BH - 2, NCC = (BW - 2) / 2, T = NRR * NCC, M = (T + NT - 1) / NT;
   extern __shared__ double lds[];
   double *phi = lds;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)lds;  // see schwinger_or_kernel
   const uint32_t tile = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
   const uint32_t i0 = tx * TW, j0 = ty * TH;
@@ -616,7 +620,7 @@ __global__ void __launch_bounds__(NT)
       for (int m = 0; m < M; ++m) {
         if ((m + 1) * NT <= T || (int)tid + NT * m < T) {
           const int o = colour ? o1[m] : o0[m];
-          const uint32_t a = (uint32_t)(o - P) * 8u;  // LDS byte address of the cell below
+          const uint32_t a = lds0 + (uint32_t)(o - P) * 8u;  // LDS byte address of the cell below
           double dn = lds_read_f64<0>(a), lf = lds_read_f64<(P - 1) * 8>(a), own = lds_read_f64<P * 8>(a);
           double rt = lds_read_f64<(P + 1) * 8>(a), up = lds_read_f64<2 * P * 8>(a), pad0 = 0.0, pad1 = 0.0;
           lds_wait7(dn, lf, own, rt, up, pad0, pad1);
@@ -891,7 +895,7 @@ static int launch_lattice_reduce(uint32_t Mt, uint32_t Mx, double mu2, const dou
                                  double *d_out, hipStream_t st) {
   const uint32_t nsplit = row_blocks(Mx, B);
   void *ws = nullptr;
-  if (int rc = scratch((size_t)B * nsplit * sizeof(double), &ws)) return rc;
+  if (int rc = scratch((size_t)B * nsplit * sizeof(double), &ws, st)) return rc;
   hipLaunchKernelGGL((lattice_reduce_kernel<OP>), dim3(nsplit, B), dim3(256), 0, st, Mt, Mx, mu2, d_state, (double *)ws);
   MLMCPI_LAUNCH_CHECK("lattice_reduce_kernel");
   hipLaunchKernelGGL(lattice_finish_kernel, dim3((B + 255) / 256), dim3(256), 0, st, (const double *)ws, nsplit, B, OP,
@@ -976,9 +980,15 @@ static int allow_full_lds() {
   return MLMCPI_OK;
 }
 
-static bool g_lds_attr_set = false;
+// hipFuncSetAttribute applies to the current device: once per device, under a lock (one process may drive several GPUs)
+static std::mutex g_lds_attr_mutex;
+static bool g_lds_attr_set[64] = {false};
 static int init_sweep_kernels() {
-  if (g_lds_attr_set) return MLMCPI_OK;
+  int dev = 0;
+  MLMCPI_HIP_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64) return fail(MLMCPI_ERR_INVALID, "device index %d out of range", dev);
+  std::lock_guard<std::mutex> lock(g_lds_attr_mutex);
+  if (g_lds_attr_set[dev]) return MLMCPI_OK;
   if (int rc = allow_full_lds<false, 256>()) return rc;
   if (int rc = allow_full_lds<true, 256>()) return rc;
   if (int rc = allow_full_lds<false, 512>()) return rc;
@@ -990,7 +1000,7 @@ static int init_sweep_kernels() {
   MLMCPI_OR_ATTR(5, 256); MLMCPI_OR_ATTR(5, 512); MLMCPI_OR_ATTR(5, 1024);
   MLMCPI_OR_ATTR(6, 256); MLMCPI_OR_ATTR(6, 512); MLMCPI_OR_ATTR(6, 1024);
 #undef MLMCPI_OR_ATTR
-  g_lds_attr_set = true;
+  g_lds_attr_set[dev] = true;
   return MLMCPI_OK;
 }
 
@@ -1048,11 +1058,14 @@ int mlmcpi_lattice_initialise(const mlmcpi_lattice_action *act, double *d_phi, u
   return MLMCPI_OK;
 }
 
-static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, double *d_scratch, uint32_t B,
+// The launches read `src` and write `dst`; after each one src <- dst and dst <- the other work buffer.  d_phi is only
+// read unless it is also d_w1.  result_in (may be NULL: then the result is copied into d_phi, which must be writable):
+// 0 -> the result is in d_w0, 1 -> in d_w1, -1 -> no sweep was run (result is the input).
+static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, double *d_w0, double *d_w1, uint32_t B,
                            uint32_t n_overrelax, uint32_t n_heatbath, uint64_t seed, uint32_t chain0, uint32_t sweep0,
-                           uint32_t fuse, int32_t *result_in_b, void *stream) {
+                           uint32_t fuse, int32_t *result_in, void *stream) {
   if (int rc = check_lattice(act)) return rc;
-  MLMCPI_REQUIRE(d_phi && d_scratch && d_phi != d_scratch && B > 0, "bad arguments");
+  MLMCPI_REQUIRE(d_phi && d_w0 && d_w1 && d_phi != d_w0 && d_w0 != d_w1 && B > 0, "bad arguments");
   MLMCPI_REQUIRE(act->Mt % 2 == 0 && act->Mx % 2 == 0, "multicolour sweeps need even Mt, Mx (got %u x %u)", act->Mt,
                  act->Mx);
   if (fuse == 0) fuse = 4;  // library default: best measured whole-step time (tools/scan_fuse.sh)
@@ -1062,7 +1075,11 @@ static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, doub
   const uint32_t total = n_overrelax + n_heatbath;
   const size_t state_bytes = (size_t)B * act->Mt * act->Mx * (schw ? 16 : 8);
   if (int rc = init_sweep_kernels()) return rc;
-  double *src = d_phi, *dst = d_scratch;
+  double *src = d_phi, *dst = d_w0;
+  auto advance = [&]() {  // the buffer just written becomes the input; the next output is the other work buffer
+    src = dst;
+    dst = (dst == d_w0) ? d_w1 : d_w0;
+  };
   uint32_t s = 0;
   while (s < total) {
     // Only overrelaxation sweeps are fused: they are bound by the passes over the state, and a fused launch trades
@@ -1105,7 +1122,7 @@ static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, doub
           default: hipLaunchKernelGGL((schwinger_or_patch_kernel<4>), sgrid, pblock, plds, st, act->Mt, act->Mx, in2, out2, act->Mt / 64);
         }
         MLMCPI_LAUNCH_CHECK("schwinger_or_patch_kernel");
-        double *tmp2 = src; src = dst; dst = tmp2;
+        advance();
         s += n;
         continue;
       }
@@ -1142,7 +1159,7 @@ static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, doub
           default: hipLaunchKernelGGL((gff_or_patch_kernel<4>), sgrid, pblock, plds, st, act->Mt, act->Mx, mu2, (const double *)src, dst, act->Mt / 64);
         }
         MLMCPI_LAUNCH_CHECK("gff_or_patch_kernel");
-        double *tmp2 = src; src = dst; dst = tmp2;
+        advance();
         s += n;
         continue;
       }
@@ -1163,11 +1180,11 @@ static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, doub
       rc = kinds ? launch_sweep<false, true>(g, grid, st, act->Mt, act->Mx, gff_mu2(*act), src, dst, n, kinds, key)
                  : launch_sweep<false, false>(g, grid, st, act->Mt, act->Mx, gff_mu2(*act), src, dst, n, kinds, key);
     if (rc) return rc;
-    double *tmp = src; src = dst; dst = tmp;
+    advance();
     s += n;
   }
-  if (result_in_b)
-    *result_in_b = (src != d_phi) ? 1 : 0;
+  if (result_in)
+    *result_in = total == 0 ? -1 : (src == d_w0 ? 0 : 1);
   else if (src != d_phi)
     MLMCPI_HIP_TRY(hipMemcpyAsync(d_phi, src, state_bytes, hipMemcpyDeviceToDevice, st));
   return MLMCPI_OK;
@@ -1176,14 +1193,27 @@ static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, doub
 int mlmcpi_lattice_sweep_draw(const mlmcpi_lattice_action *act, double *d_phi, double *d_scratch, uint32_t B,
                               uint32_t n_overrelax, uint32_t n_heatbath, uint64_t seed, uint32_t chain0,
                               uint32_t sweep0, uint32_t fuse, void *stream) {
-  return sweep_draw_impl(act, d_phi, d_scratch, B, n_overrelax, n_heatbath, seed, chain0, sweep0, fuse, nullptr, stream);
+  return sweep_draw_impl(act, d_phi, d_scratch, d_phi, B, n_overrelax, n_heatbath, seed, chain0, sweep0, fuse, nullptr, stream);
 }
 
 int mlmcpi_lattice_sweep_draw_pingpong(const mlmcpi_lattice_action *act, double *d_a, double *d_b, uint32_t B,
                                        uint32_t n_overrelax, uint32_t n_heatbath, uint64_t seed, uint32_t chain0,
                                        uint32_t sweep0, uint32_t fuse, int32_t *result_in_b, void *stream) {
   MLMCPI_REQUIRE(result_in_b, "result_in_b is NULL");
-  return sweep_draw_impl(act, d_a, d_b, B, n_overrelax, n_heatbath, seed, chain0, sweep0, fuse, result_in_b, stream);
+  int32_t where = 0;
+  if (int rc = sweep_draw_impl(act, d_a, d_b, d_a, B, n_overrelax, n_heatbath, seed, chain0, sweep0, fuse, &where, stream)) return rc;
+  *result_in_b = where == 0 ? 1 : 0;  // work buffer 0 is d_b; no sweeps (-1) or work buffer 1: the result is in d_a
+  return MLMCPI_OK;
+}
+
+int mlmcpi_lattice_sweep_draw_from(const mlmcpi_lattice_action *act, const double *d_src, double *d_w0, double *d_w1,
+                                   uint32_t B, uint32_t n_overrelax, uint32_t n_heatbath, uint64_t seed, uint32_t chain0,
+                                   uint32_t sweep0, uint32_t fuse, int32_t *result_in, void *stream) {
+  MLMCPI_REQUIRE(result_in, "result_in is NULL");
+  MLMCPI_REQUIRE(n_overrelax + n_heatbath > 0, "no sweeps requested: the result would be the (read-only) input");
+  // the input is only ever the `src` of the first launch (or a work buffer when the caller passes d_w1 == d_src)
+  return sweep_draw_impl(act, const_cast<double *>(d_src), d_w0, d_w1, B, n_overrelax, n_heatbath, seed, chain0, sweep0, fuse,
+                         result_in, stream);
 }
 
 int mlmcpi_qoi_phi_squared(const double *d_phi, uint32_t n_vertices, uint32_t B, double *d_out, void *stream) {
@@ -1924,11 +1954,18 @@ int mlmcpi_lattice_exact_workspace_bytes(const mlmcpi_lattice_action *act, uint3
 static int gff_exact_batch(const mlmcpi_lattice_action *act, double *d_phi, uint32_t B, uint64_t seed, uint32_t chain0,
                            uint32_t step, uint32_t sub, void *d_work, hipStream_t st) {
   const uint32_t n = act->Mt * act->Mx;
-  // one cached plan per (Mt, Mx, B): plan creation costs milliseconds
+  // one cached plan per device and (Mt, Mx, B): plan creation costs milliseconds; a plan is bound to the device that was
+  // current when it was made.  The lock is held across the enqueue: hipfftSetStream + Exec on a shared plan is not
+  // re-entrant.
+  struct PlanSlot { hipfftHandle plan = 0; uint32_t mt = 0, mx = 0, b = 0; };
   static std::mutex guard;
-  static hipfftHandle plan = 0;
-  static uint32_t p_mt = 0, p_mx = 0, p_b = 0;
+  static PlanSlot slots[64];
+  int dev = 0;
+  MLMCPI_HIP_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64) return fail(MLMCPI_ERR_INVALID, "device index %d out of range", dev);
   std::lock_guard<std::mutex> lock(guard);
+  hipfftHandle &plan = slots[dev].plan;
+  uint32_t &p_mt = slots[dev].mt, &p_mx = slots[dev].mx, &p_b = slots[dev].b;
   if (!plan || p_mt != act->Mt || p_mx != act->Mx || p_b != B) {
     if (plan) hipfftDestroy(plan);
     plan = 0;
@@ -1968,7 +2005,7 @@ static int gff_initialise_exact(const mlmcpi_lattice_action *act, double *d_phi,
   uint32_t chunk = (uint32_t)std::max<size_t>(1, ((size_t)256 << 20) / per_chain);
   if (chunk > B) chunk = B;
   void *work = nullptr;
-  if (int rc = scratch((size_t)chunk * per_chain, &work)) return rc;
+  if (int rc = scratch((size_t)chunk * per_chain, &work, st)) return rc;
   for (uint32_t b0 = 0; b0 < B; b0 += chunk) {
     const uint32_t nb = std::min(chunk, B - b0);
     if (int rc = gff_exact_batch(act, d_phi + (size_t)b0 * act->Mt * act->Mx, nb, seed, chain0 + b0, 0, 1, work, st)) return rc;

@@ -671,7 +671,7 @@ static int launch_reduce(const PathP &P, const double *d_x, uint32_t B, double s
                          uint32_t stride = 1) {
   const uint32_t nsplit = choose_split(P.M, B);
   void *ws = nullptr;
-  int rc = scratch((size_t)B * nsplit * sizeof(double), &ws);
+  int rc = scratch((size_t)B * nsplit * sizeof(double), &ws, st);
   if (rc) return rc;
   dim3 grid(nsplit, B), block(256);
   switch (P.kind) {
@@ -858,19 +858,20 @@ int mlmcpi_path_hmc_draw(const mlmcpi_path_action *act, double *d_x, uint32_t B,
   return MLMCPI_OK;
 }
 
-int mlmcpi_path_sweep_draw(const mlmcpi_path_action *act, double *d_x, double *d_scratch, uint32_t B,
+// see sweep_draw_impl of lattice2d.hip: reads d_x first, then alternates between d_w0 and d_w1 (which may be d_x)
+static int path_sweep_impl(const mlmcpi_path_action *act, double *d_x, double *d_w0, double *d_w1, uint32_t B,
                            uint32_t n_overrelax, uint32_t n_heatbath, uint64_t seed, uint32_t chain0,
-                           uint32_t sweep0, void *stream) {
+                           uint32_t sweep0, int32_t *result_in, void *stream) {
   if (int rc = check_action(act)) return rc;
   // action/action.hh:73-96: only the rotor implements local updates among the 1-D actions
   if (act->kind != MLMCPI_ROTOR)
     return fail(MLMCPI_ERR_UNSUPPORTED, "heat bath / overrelaxation update not implemented for this action");
-  MLMCPI_REQUIRE(d_x && d_scratch && d_x != d_scratch && B > 0, "bad arguments");
+  MLMCPI_REQUIRE(d_x && d_w0 && d_w1 && d_x != d_w0 && d_w0 != d_w1 && B > 0, "bad arguments");
   MLMCPI_REQUIRE(act->M % 2 == 0, "even/odd sweeps need an even number of sites (M_lat = %u)", act->M);
   PathP P = make_params(*act);
   hipStream_t st = as_stream(stream);
   const uint32_t total = n_overrelax + n_heatbath;
-  double *src = d_x, *dst = d_scratch;
+  double *src = d_x, *dst = d_w0;
   uint32_t s = 0;
   while (s < total) {
     // overrelaxation sweeps (they come first, sampler order) are fused up to 8 per launch: in one dimension the halo
@@ -894,11 +895,30 @@ int mlmcpi_path_sweep_draw(const mlmcpi_path_action *act, double *d_x, double *d
       hipLaunchKernelGGL(rotor_sweep_kernel<false>, dim3(nseg2, B), dim3(256), lds, st, P, (const double *)src, dst, owned, n,
                          kinds, make_key(seed, chain0, sweep0 + s), 0u);
     MLMCPI_LAUNCH_CHECK("rotor_sweep_kernel");
-    double *tmp = src; src = dst; dst = tmp;
+    src = dst;
+    dst = (dst == d_w0) ? d_w1 : d_w0;
     s += n;
   }
-  if (src != d_x) MLMCPI_HIP_TRY(hipMemcpyAsync(d_x, src, (size_t)B * P.M * 8, hipMemcpyDeviceToDevice, st));
+  if (result_in)
+    *result_in = total == 0 ? -1 : (src == d_w0 ? 0 : 1);
+  else if (src != d_x)
+    MLMCPI_HIP_TRY(hipMemcpyAsync(d_x, src, (size_t)B * P.M * 8, hipMemcpyDeviceToDevice, st));
   return MLMCPI_OK;
+}
+
+int mlmcpi_path_sweep_draw(const mlmcpi_path_action *act, double *d_x, double *d_scratch, uint32_t B,
+                           uint32_t n_overrelax, uint32_t n_heatbath, uint64_t seed, uint32_t chain0,
+                           uint32_t sweep0, void *stream) {
+  return path_sweep_impl(act, d_x, d_scratch, d_x, B, n_overrelax, n_heatbath, seed, chain0, sweep0, nullptr, stream);
+}
+
+int mlmcpi_path_sweep_draw_from(const mlmcpi_path_action *act, const double *d_src, double *d_w0, double *d_w1, uint32_t B,
+                                uint32_t n_overrelax, uint32_t n_heatbath, uint64_t seed, uint32_t chain0, uint32_t sweep0,
+                                int32_t *result_in, void *stream) {
+  MLMCPI_REQUIRE(result_in, "result_in is NULL");
+  MLMCPI_REQUIRE(n_overrelax + n_heatbath > 0, "no sweeps requested: the result would be the (read-only) input");
+  return path_sweep_impl(act, const_cast<double *>(d_src), d_w0, d_w1, B, n_overrelax, n_heatbath, seed, chain0, sweep0,
+                         result_in, stream);
 }
 
 // workspace: theta' [B*M] | energies [4][B] | CFA partials [B*nblk*2]

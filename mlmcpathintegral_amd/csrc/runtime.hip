@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include <mutex>
+#include <vector>
 
 #include "internal.hpp"
 
@@ -26,27 +27,44 @@ int fail_hip(hipError_t e, const char *what) {
   return MLMCPI_ERR_HIP;
 }
 
-static std::mutex g_scratch_mutex;
-static void *g_scratch[64] = {nullptr};
-static size_t g_scratch_bytes[64] = {0};
+// Scratch for reduction partials: one buffer per (host thread, device, stream), grown on demand (the first call of a
+// given size allocates; steady state does not).  A launch sequence that uses it (reduce -> finish) is issued by one
+// thread on one stream, so neither another stream nor another host thread driving the same device can overwrite the
+// partials in between.  The caller passes the stream it is about to launch on.
+namespace {
+struct ScratchSlot { int dev; hipStream_t stream; void *ptr; size_t bytes; };
+struct ScratchPool {
+  std::vector<ScratchSlot> slots;
+  ~ScratchPool() {
+    for (auto &s : slots)
+      if (s.ptr) (void)hipFree(s.ptr);  // may fail at process teardown (runtime already gone): nothing to do about it
+  }
+};
+thread_local ScratchPool t_scratch;
+}  // namespace
 
-int scratch(size_t bytes, void **d_ptr) {
+int scratch(size_t bytes, void **d_ptr, hipStream_t stream) {
   int dev = 0;
   MLMCPI_HIP_TRY(hipGetDevice(&dev));
-  if (dev < 0 || dev >= 64) return fail(MLMCPI_ERR_INVALID, "device index %d out of range", dev);
-  std::lock_guard<std::mutex> lock(g_scratch_mutex);
-  if (g_scratch_bytes[dev] < bytes) {
-    if (g_scratch[dev]) {
-      MLMCPI_HIP_TRY(hipDeviceSynchronize());
-      MLMCPI_HIP_TRY(hipFree(g_scratch[dev]));
-      g_scratch[dev] = nullptr;
-      g_scratch_bytes[dev] = 0;
-    }
-    size_t want = bytes < (1u << 20) ? (1u << 20) : bytes;
-    MLMCPI_HIP_TRY(hipMalloc(&g_scratch[dev], want));
-    g_scratch_bytes[dev] = want;
+  ScratchSlot *slot = nullptr;
+  for (auto &s : t_scratch.slots)
+    if (s.dev == dev && s.stream == stream) slot = &s;
+  if (!slot) {
+    t_scratch.slots.push_back(ScratchSlot{dev, stream, nullptr, 0});
+    slot = &t_scratch.slots.back();
   }
-  *d_ptr = g_scratch[dev];
+  if (slot->bytes < bytes) {
+    if (slot->ptr) {
+      MLMCPI_HIP_TRY(hipStreamSynchronize(stream));  // the only work that can still read it is on this stream
+      MLMCPI_HIP_TRY(hipFree(slot->ptr));
+      slot->ptr = nullptr;
+      slot->bytes = 0;
+    }
+    const size_t want = bytes < (1u << 20) ? (1u << 20) : bytes;
+    MLMCPI_HIP_TRY(hipMalloc(&slot->ptr, want));
+    slot->bytes = want;
+  }
+  *d_ptr = slot->ptr;
   return MLMCPI_OK;
 }
 

@@ -91,6 +91,8 @@ _SIGS = {
     "orc_stats_record": (None, [_vp, _dp, _u32]),
     "orc_stats_reset": (None, [_vp, _i]),
     "orc_stats_get": (None, [_vp, _dp]),
+    "orc_rank_seeds": (None, [_u32, _u32, _vp]),
+    "orc_rank_engine_outputs": (None, [_u32, _u32, _u32, _u32, _vp]),
     "orc_ho_xsquared_analytical": (_d, [_u32, _d, _d, _d]),
     "orc_gff_phi_squared_analytical": (_d, [_d, _i, _i]),
 }

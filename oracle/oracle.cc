@@ -31,6 +31,7 @@
 #include <numeric>
 #include <memory>
 #include <random>
+#include <set>
 #include <vector>
 
 namespace {
@@ -1574,6 +1575,25 @@ void orc_stats_get(void *h, double *out) {
   StatsO *s = (StatsO *)h;
   out[0] = s->avg; out[1] = s->variance(); out[2] = s->variance_error(); out[3] = s->tau_int();
   out[4] = s->error(); out[5] = (double)s->n;
+}
+
+// mpi/mpi_random.cc:5-29: seeds of the ranks' engines = the sorted set {seed} + outputs of minstd_rand(seed) until it
+// holds `world` distinct values (std::set iterates in ascending order; rank r takes the r-th smallest).
+void orc_rank_seeds(unsigned seed, unsigned world, unsigned *out) {
+  std::linear_congruential_engine<unsigned int, 48271, 0, 2147483647> seed_engine;
+  seed_engine.seed(seed);
+  std::set<unsigned int> seeds;
+  seeds.insert(seed);
+  while (seeds.size() < world) seeds.insert(seed_engine());
+  unsigned r = 0;
+  for (unsigned v : seeds) out[r++] = v;
+}
+// the engine of rank `rank`: std::mt19937_64 seeded with that rank's seed (parallel_mt19937_64::seed)
+void orc_rank_engine_outputs(unsigned seed, unsigned rank, unsigned world, unsigned n, unsigned long long *out) {
+  std::vector<unsigned> seeds(world);
+  orc_rank_seeds(seed, world, seeds.data());
+  std::mt19937_64 engine(seeds[rank]);
+  for (unsigned i = 0; i < n; ++i) out[i] = engine();
 }
 
 // ---- analytic expectation values ---------------------------------------------------------------------

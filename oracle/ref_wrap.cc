@@ -1,5 +1,5 @@
 // ref_wrap.cc -- thin C surface over the REAL reference classes that build here without Eigen/GSL
-// (lattice/lattice1d.cc, lattice/lattice2d.cc, common/statistics.cc + their dependencies
+// (lattice/lattice1d.cc, lattice/lattice2d.cc, common/statistics.cc, mpi/mpi_random.cc + their dependencies
 // common/parameters.cc and mpi/mpi_wrapper.cc, compiled unmodified from /root/reference/src by
 // oracle/Makefile into oracle/_ref/libref.so).  Written for this repository; it contains no
 // reference code, only calls into it.  TEST INFRASTRUCTURE ONLY: used by tests/ to pin the
@@ -8,6 +8,7 @@
 #include "common/statistics.hh"
 #include "lattice/lattice1d.hh"
 #include "lattice/lattice2d.hh"
+#include "mpi/mpi_random.hh"
 #include <memory>
 
 extern "C" {
@@ -60,6 +61,16 @@ void ref_stats_get(void *h, double *out) {
   out[0] = s->average(); out[1] = s->variance(); out[2] = s->variance_error(); out[3] = s->tau_int();
   out[4] = s->error(); out[5] = (double)s->samples();
 }
+void ref_stats_autocorr(void *h, double *out) {  // k_max values
+  const std::vector<double> c = ((Statistics *)h)->auto_corr();
+  for (size_t k = 0; k < c.size(); ++k) out[k] = c[k];
+}
 unsigned ref_distribute_n(unsigned n) { return distribute_n(n); }
+
+// mpi/mpi_random.cc:5-29 as shipped (this build has no USE_MPI: one rank, the seed list is {value})
+void ref_parallel_mt19937_64(unsigned long long seed, unsigned n, unsigned long long *out) {
+  parallel_mt19937_64 engine(seed);
+  for (unsigned i = 0; i < n; ++i) out[i] = engine();
+}
 
 }  // extern "C"

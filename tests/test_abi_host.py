@@ -28,6 +28,21 @@ def test_library_exports_every_declared_symbol():
     assert lib.mlmcpi_abi_version() == 1
 
 
+def test_comm_library_exports_every_declared_symbol():
+    """include/mlmcpi_comm.h (the RCCL statistics all-reduce): libmlmcpi_rccl.so loads without a GPU and without an RCCL
+    runtime in the process (RCCL is opened on first use), and exports what the header declares."""
+    from mlmcpathintegral_amd import comm
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "mlmcpi_comm.h")).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(mlmcpi_comm_[a-z0-9_]+)\s*\(", text)))
+    lib = comm.load()
+    assert len(names) == 10 and set(names) == set(comm.SIGNATURES)
+    for n in names:
+        assert hasattr(lib, n), f"libmlmcpi_rccl.so lacks {n}"
+    # bad arguments are rejected before anything touches RCCL or a GPU
+    h = C.c_void_p()
+    assert lib.mlmcpi_comm_init(3, 2, b"x" * 128, 0, C.byref(h)) == -1 and b"rank 3 of 2" in lib.mlmcpi_comm_last_error()
+
+
 def test_no_silent_cpu_fallback():
     """Without a GPU a compute entry point must return an error, not compute on the host."""
     import torch

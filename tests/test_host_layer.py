@@ -68,6 +68,38 @@ def test_driver_multilevel_on_gpu():
     assert m and float(m.group(1)) < 5.0
 
 
+@pytest.mark.gpu
+def test_driver_throughput_mode_on_gpu():
+    """host/driver --method throughput: the C++ sampling loop (Sampler::draw without a copy, QoI and moments on the
+    device) on a batch of Schwinger chains; prints one JSON line with link-updates/s and a sane plaquette."""
+    import json
+    if not os.path.exists(EXE):
+        build()
+    r = subprocess.run([os.path.join(ROOT, "host", "driver"), "--method", "throughput", "--action", "schwinger", "--Mt_lat", "256",
+                        "--sampler", "heatbath", "--batch", "8", "--n_samples", "10", "--n_burnin", "20"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    print(line)
+    assert line["batch"] == 8 and line["updates_per_s"] > 1e9 and 0.40 < line["qoi_mean"] < 0.49
+
+
+@pytest.mark.gpu
+def test_comm_single_rank_on_gpu():
+    """libmlmcpi_rccl.so through ctypes with the RCCL runtime of this PyTorch process: communicator of one rank, device
+    and host all-reduce (the N > 1 path of bench.py uses the same calls; one GPU per rank is all RCCL allows)."""
+    import torch
+    from mlmcpathintegral_amd import comm
+    comm.open_runtime()
+    c = comm.Comm(0, 1, comm.unique_id(), 0)
+    t = torch.arange(7, dtype=torch.float64, device="cuda") * 0.5
+    c.allreduce_sum_(t)
+    torch.cuda.synchronize()
+    assert torch.equal(t.cpu(), torch.arange(7, dtype=torch.float64) * 0.5)
+    assert c.allreduce_sum_host([1.0, 2.5]) == [1.0, 2.5]
+    c.close()
+
+
 def test_driver_rejects_unknown_options():
     r = subprocess.run([os.path.join(ROOT, "host", "driver"), "--no_such_option", "1"], capture_output=True, text=True, timeout=60)
     assert r.returncode == 1 and "unknown option" in r.stderr

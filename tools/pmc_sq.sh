@@ -4,10 +4,10 @@ set -o pipefail
 TAG=${1:-sq}; shift
 CTRS=${1:-"SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS"}; shift
 ARGS=${@:---steps 3 --warmup 1 --no-cpu-baseline}
-OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
+OUT=${GRAFT_REPO_ROOT:?}/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 500 rocprofv3 --pmc $CTRS --kernel-trace --output-format csv -d $OUT/sq -- python3 $GRAFT_REPO_ROOT/bench.py $ARGS > $OUT/sq.log 2>&1 || { echo "pmc pass failed"; tail -5 $OUT/sq.log; exit 1; }
+timeout -k 10 500 rocprofv3 --pmc $CTRS --kernel-trace --output-format csv -d $OUT/sq -- python3 ${GRAFT_REPO_ROOT:?}/bench.py $ARGS > $OUT/sq.log 2>&1 || { echo "pmc pass failed"; tail -5 $OUT/sq.log; exit 1; }
 python3 - <<PY
 import csv, glob, collections
 acc=collections.defaultdict(lambda: collections.defaultdict(list))

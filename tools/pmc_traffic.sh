@@ -4,10 +4,10 @@
 set -o pipefail
 TAG=${1:-pmc}; shift
 ARGS=${@:---steps 3 --warmup 1 --no-cpu-baseline}
-OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
+OUT=${GRAFT_REPO_ROOT:?}/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 500 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$C -- python3 $GRAFT_REPO_ROOT/bench.py $ARGS > $OUT/$C.log 2>&1 || { echo "pmc pass $C failed"; tail -5 $OUT/$C.log; exit 1; }
+  timeout -k 10 500 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$C -- python3 ${GRAFT_REPO_ROOT:?}/bench.py $ARGS > $OUT/$C.log 2>&1 || { echo "pmc pass $C failed"; tail -5 $OUT/$C.log; exit 1; }
 done
-python3 $GRAFT_REPO_ROOT/tools/pmc_summarise.py $OUT
+python3 ${GRAFT_REPO_ROOT:?}/tools/pmc_summarise.py $OUT
