@@ -48,11 +48,16 @@ inline unsigned int distribute_n(const unsigned int n, const int rank, const int
  *  handed in by a host program that has its own channel. */
 class RcclExchange : public Exchange {
 public:
+  RcclExchange(int rank_, int size_, const char *id_path, int device, double timeout_s = 120.0)
+      : RcclExchange(rank_, size_, std::string(id_path), device, timeout_s) {}
   RcclExchange(int rank_, int size_, const std::string &id_path, int device, double timeout_s = 120.0) : comm(nullptr) {
     if (mlmcpi_comm_init_file(rank_, size_, id_path.c_str(), device, timeout_s, &comm)) die("mlmcpi_comm_init_file");
   }
-  RcclExchange(int rank_, int size_, const void *id128, int device) : comm(nullptr) {
-    if (mlmcpi_comm_init(rank_, size_, id128, device, &comm)) die("mlmcpi_comm_init");
+  /** the rendezvous id itself (MLMCPI_COMM_ID_BYTES bytes from mlmcpi_comm_unique_id on rank 0, distributed by the
+   *  caller).  A struct, not a pointer: a string literal must never be mistaken for an id. */
+  struct Id { unsigned char bytes[MLMCPI_COMM_ID_BYTES]; };
+  RcclExchange(int rank_, int size_, const Id &id, int device) : comm(nullptr) {
+    if (mlmcpi_comm_init(rank_, size_, id.bytes, device, &comm)) die("mlmcpi_comm_init");
   }
   ~RcclExchange() override { mlmcpi_comm_destroy(comm); }
   int rank() const override { int r = 0; mlmcpi_comm_rank(comm, &r); return r; }
