@@ -4,14 +4,16 @@ import math, sys, torch
 sys.path.insert(0, ".")
 from scipy import special
 from mlmcpathintegral_amd import abi, ops
-B, n_burn, n = 16, 60, int(sys.argv[1]) if len(sys.argv) > 1 else 300
+n_burn, n = 60, int(sys.argv[1]) if len(sys.argv) > 1 else 300
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+seed = int(sys.argv[3]) if len(sys.argv) > 3 else 99
 act = abi.lattice_action(abi.SCHWINGER, 1024, 1024, beta=1.0)
-x = ops.lattice_initialise(act, B, 99)
+x = ops.lattice_initialise(act, B, seed)
 s = torch.empty_like(x)
 sweep = 0
 plaq, chi = [], []
 for k in range(n_burn + n):
-    x, s = ops.lattice_sweep_draw_pingpong(act, x, s, 10, 1, 99, 0, sweep)
+    x, s = ops.lattice_sweep_draw_pingpong(act, x, s, 10, 1, seed, 0, sweep)
     sweep += 11
     if k >= n_burn:
         plaq.append(ops.qoi_avg_plaquette(x, 1024, 1024))
