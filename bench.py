@@ -504,7 +504,7 @@ def report_sweeps(result, a, W, size, B, world, step_ms, ms):
     if a.workload == "schwinger":
         or_name = (f"schwinger_or_patch_kernel<{fuse}>" if fuse <= 4 and not lds_kernel
                    else f"schwinger_or_kernel<64,32,{fuse},{1024 if fuse >= 4 else 512}>") if special else "schwinger_sweep_kernel<false,256>"
-        hb_name = "schwinger_sweep_kernel<true,256>"
+        hb_name = "schwinger_sweep_kernel<true,256,64,32>" if (size % 64 == 0 and size >= 128 and a.n_heatbath == 1) else "schwinger_sweep_kernel<true,256,0,0>"
     else:
         or_name = (f"gff_or_patch_kernel<{fuse}>" if not lds_kernel else f"gff_or_kernel<64,32,{fuse},256>") if special else "gff_sweep_kernel<false,256>"
         hb_name = "gff_sweep_kernel<true,256>"
@@ -542,7 +542,7 @@ def report_sweeps(result, a, W, size, B, world, step_ms, ms):
     if a.n_heatbath:
         record(hb_name, "heat-bath sweep", W.ev["hb"], a.n_heatbath, 1, state_rw,
                pmc_entry("entries", chains=B, fuse=1, kind="heatbath", **wl), pmc_entry("valu", kind="heatbath", **wl))
-    qk = record("lattice_reduce_kernel (QoI) + stats_accumulate_kernel", "qoi->evaluate + record_sample", W.ev["qoi"], 1, 1,
+    qk = record(("schwinger_reduce_band_kernel" if a.workload == "schwinger" else "lattice_reduce_kernel") + " (QoI) + stats_accumulate_kernel", "qoi->evaluate + record_sample", W.ev["qoi"], 1, 1,
                 0.5 * state_rw, None, None)
     del qk["updates_per_s"], qk["algorithmic_bytes_per_launch"], qk["algorithmic_GBps"], qk["sweeps_per_launch"]
     result["kernels"] = kernels

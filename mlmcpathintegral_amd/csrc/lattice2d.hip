@@ -75,9 +75,18 @@ __device__ __forceinline__ void stage_region(uint32_t nr, uint32_t nc, Load load
 }
 
 // region given as nr x nc with a runtime nc (generic kernels)
-template <int NT, int S, class Setup, class Commit>
+template <int NT, int S, bool DIRECT = false, class Setup, class Commit>
 __device__ __forceinline__ void heatbath_region(uint32_t nr, uint32_t nc, const RngKey &key, HbPool &pool, Setup setup,
                                                 Commit commit) {
+  if (DIRECT) {  // nc is a compile-time constant at the call site: the division is a multiply and a shift
+    heatbath_cells<NT, S>(nr * nc, key, pool,
+                          [&](uint32_t idx, double &tau, double &centre, uint32_t &site, uint32_t &o) {
+                            const uint32_t ri = idx / nc;
+                            setup(ri, idx - ri * nc, tau, centre, site, o);
+                          },
+                          commit);
+    return;
+  }
   // (row, column) of a thread's cells without a division per cell: one division for the first cell, then steps of NT
   // (heatbath_cells asks for a thread's cells in increasing order: idx = tid, tid + NT, tid + 2 NT, ...)
   uint32_t cur = threadIdx.x, ri = cur / nc, ci = cur - ri * nc;
@@ -115,21 +124,35 @@ __device__ __forceinline__ uint32_t wrap_add(uint32_t base, uint32_t off, uint32
 // six staple links lie inside the buffer is updated; the region of exact values shrinks by at most
 // two sites per side per sweep, so a halo of 2*nsweeps keeps the owned tile exact (tile origins are
 // even, which makes buffer parity equal lattice parity).
-template <bool HEAT, int NT>
+// TWC x THC > 0: single-sweep launch on a lattice that the TWC x THC tiles divide and that is wider than a buffer
+// (Mt >= TWC + 4, Mx >= THC + 4): tile and buffer extents are compile-time constants (index arithmetic folds, cell
+// coordinates come from divisions by constants) and a buffer coordinate wraps around the lattice at most once.  Same
+// updates in the same order as the generic instantiation (TWC = THC = 0): bit-identical results.
+template <bool HEAT, int NT, int TWC = 0, int THC = 0>
 __global__ void __launch_bounds__(NT, HEAT ? (NT == 256 ? 4 : NT == 512 ? 2 : 1) : 1)
     schwinger_sweep_kernel(uint32_t Mt, uint32_t Mx, double beta, const double2 *__restrict__ in,
-                           double2 *__restrict__ out, TileGeom tg, uint32_t nsweeps, uint32_t kinds, RngKey key0,
+                           double2 *__restrict__ out, TileGeom tg, uint32_t nsweeps_arg, uint32_t kinds, RngKey key0,
                            uint32_t pool_cap) {
   extern __shared__ double lds[];
+  constexpr bool FIXED = TWC > 0;
+  const uint32_t nsweeps = FIXED ? 1u : nsweeps_arg;
   const uint32_t H = 2 * nsweeps;
   const uint32_t tile = blockIdx.x, b = blockIdx.y;
   const uint32_t ty = tile / tg.tiles_x, tx = tile - ty * tg.tiles_x;
-  const uint32_t i0 = tx * tg.TW, j0 = ty * tg.TH;
-  const uint32_t ow = min(tg.TW, Mt - i0), oh = min(tg.TH, Mx - j0);
+  const uint32_t i0 = tx * (FIXED ? TWC : tg.TW), j0 = ty * (FIXED ? THC : tg.TH);
+  const uint32_t ow = FIXED ? TWC : min(tg.TW, Mt - i0), oh = FIXED ? THC : min(tg.TH, Mx - j0);
   const uint32_t bw = ow + 2 * H, bh = oh + 2 * H;
+  // lattice coordinate of a buffer coordinate
+  auto wrap = [&](uint32_t base, uint32_t off, uint32_t n) {
+    if (FIXED) {
+      const uint32_t v = base + off;
+      return v >= n ? v - n : v;
+    }
+    return wrap_add(base, off, n);
+  };
   double *th0 = lds, *th1 = lds + (size_t)bw * bh;
   // retry pool of the heat-bath phases, behind the tile image (the host sizes the allocation for tg.TW x tg.TH tiles)
-  HbPool pool = HbPool::carve(lds + (size_t)2 * (tg.TW + 2 * H) * (tg.TH + 2 * H), HEAT ? pool_cap : 0u);
+  HbPool pool = HbPool::carve(lds + (size_t)2 * ((FIXED ? TWC : tg.TW) + 2 * H) * ((FIXED ? THC : tg.TH) + 2 * H), HEAT ? pool_cap : 0u);
   const uint32_t sc = (uint32_t)(((uint64_t)i0 + Mt - (H % Mt)) % Mt);  // lattice column of buffer column 0
   const uint32_t sr = (uint32_t)(((uint64_t)j0 + Mx - (H % Mx)) % Mx);
   const double2 *src = in + (size_t)b * Mt * Mx;
@@ -137,7 +160,7 @@ __global__ void __launch_bounds__(NT, HEAT ? (NT == 256 ? 4 : NT == 512 ? 2 : 1)
   key.chain += b;
 
   stage_region<NT, (NT >= 1024 ? 3 : 5), double2>(
-      bh, bw, [&](uint32_t r, uint32_t c) { return src[(size_t)wrap_add(sr, r, Mx) * Mt + wrap_add(sc, c, Mt)]; },
+      bh, bw, [&](uint32_t r, uint32_t c) { return src[(size_t)wrap(sr, r, Mx) * Mt + wrap(sc, c, Mt)]; },
       [&](uint32_t r, uint32_t c, double2 v) {
         th0[r * bw + c] = v.x;
         th1[r * bw + c] = v.y;
@@ -145,7 +168,7 @@ __global__ void __launch_bounds__(NT, HEAT ? (NT == 256 ? 4 : NT == 512 ? 2 : 1)
   __syncthreads();
 
   for (uint32_t s = 0; s < nsweeps; ++s) {
-    const bool heat = HEAT && ((kinds >> s) & 1u);
+    const bool heat = HEAT && (FIXED || ((kinds >> s) & 1u));
     RngKey skey = key;
     skey.step += s;
     // Update regions.  In general every link whose staple links lie inside the buffer is updated:
@@ -166,7 +189,7 @@ __global__ void __launch_bounds__(NT, HEAT ? (NT == 256 ? 4 : NT == 512 ? 2 : 1)
       const uint32_t nr = r_first <= r_hi0 ? (r_hi0 - r_first) / 2 + 1 : 0;
       const uint32_t ncol = c_hi0 - c_lo0 + 1;
       if (heat) {
-        heatbath_region<NT, 5>(
+        heatbath_region<NT, 5, FIXED>(
             nr, ncol, skey, pool,
             [&](uint32_t ri, uint32_t ci, double &tau, double &centre, uint32_t &site, uint32_t &o) {
               const uint32_t r = r_first + 2 * ri, c = c_lo0 + ci;
@@ -174,7 +197,7 @@ __global__ void __launch_bounds__(NT, HEAT ? (NT == 256 ? 4 : NT == 512 ? 2 : 1)
               const double tp = th0[o + bw] + th1[o] - th1[o + 1];  // staple angles, unwrapped (expcos_params)
               const double tm = th0[o - bw] + th1[o - bw + 1] - th1[o - bw];
               expcos_params(beta, tp, tm, tau, centre);
-              site = 2 * (wrap_add(sr, r, Mx) * Mt + wrap_add(sc, c, Mt));
+              site = 2 * (wrap(sr, r, Mx) * Mt + wrap(sc, c, Mt));
             },
             [&](uint32_t o, double v) { th0[o] = v; });
       } else
@@ -195,7 +218,7 @@ __global__ void __launch_bounds__(NT, HEAT ? (NT == 256 ? 4 : NT == 512 ? 2 : 1)
       const uint32_t nc = c_first <= c_hi1 ? (c_hi1 - c_first) / 2 + 1 : 0;
       const uint32_t nrow = r_hi1 - r_lo1 + 1;
       if (heat) {
-        heatbath_region<NT, 5>(
+        heatbath_region<NT, 5, FIXED>(
             nrow, nc, skey, pool,
             [&](uint32_t ri, uint32_t ci, double &tau, double &centre, uint32_t &site, uint32_t &o) {
               const uint32_t r = r_lo1 + ri, c = c_first + 2 * ci;
@@ -203,7 +226,7 @@ __global__ void __launch_bounds__(NT, HEAT ? (NT == 256 ? 4 : NT == 512 ? 2 : 1)
               const double tp = th0[o] + th1[o + 1] - th0[o + bw];
               const double tm = th0[o + bw - 1] + th1[o - 1] - th0[o - 1];
               expcos_params(beta, tp, tm, tau, centre);
-              site = 2 * (wrap_add(sr, r, Mx) * Mt + wrap_add(sc, c, Mt)) + 1;
+              site = 2 * (wrap(sr, r, Mx) * Mt + wrap(sc, c, Mt)) + 1;
             },
             [&](uint32_t o, double v) { th1[o] = v; });
       } else
@@ -1029,8 +1052,14 @@ static void launch_sweep_nt(const SweepGeom &g, dim3 grid, hipStream_t st, uint3
       lds += HbPool::bytes(cap);
       if (lds > 160 * 1024) { cap = 0; lds = g.lds_bytes; }
     }
-    hipLaunchKernelGGL((schwinger_sweep_kernel<HEAT, NT>), grid, dim3(NT), lds, st, Mt, Mx, coupling,
-                       (const double2 *)src, (double2 *)dst, g.tg, n, kinds, key, cap);
+    // single heat-bath sweep on a lattice the default tiles divide: compile-time geometry (bit-identical results)
+    if (HEAT && NT == 256 && n == 1 && !g.overridden && g.tg.TW == 64 && g.tg.TH == 32 && Mt % 64 == 0 && Mx % 32 == 0 &&
+        Mt >= 128 && Mx >= 64)
+      hipLaunchKernelGGL((schwinger_sweep_kernel<HEAT, NT, 64, 32>), grid, dim3(NT), lds, st, Mt, Mx, coupling,
+                         (const double2 *)src, (double2 *)dst, g.tg, n, kinds, key, cap);
+    else
+      hipLaunchKernelGGL((schwinger_sweep_kernel<HEAT, NT>), grid, dim3(NT), lds, st, Mt, Mx, coupling,
+                         (const double2 *)src, (double2 *)dst, g.tg, n, kinds, key, cap);
   }
   else
     hipLaunchKernelGGL((gff_sweep_kernel<HEAT, NT>), grid, dim3(NT), g.lds_bytes, st, Mt, Mx, coupling, src, dst, g.tg, n,
