@@ -384,7 +384,7 @@ def main():
                                 "parallelism": f"chains sharded over {world} GPU(s), no data-path collective"}
             result["roofline"] = register_resident_roofline(
                 "rotor_sweep_kernel<true> + rotor_sweep_kernel<false> (all sweeps of a step)", launch_ms, floor,
-                16.0 * units_per_step, pmc_entry("valu", workload=a.workload, size=size, chains=B),
+                16.0 * units_per_step, pmc_entry("kernels_valu_busy", workload=a.workload, size=size, chains=B),
                 "overrelaxation sweeps are fused 8 per launch on LDS-resident segments; the heat-bath sweep is "
                 "VALU bound (von Mises sampler)")
         elif a.workload == "quartic_mlmc":
@@ -401,7 +401,7 @@ def main():
             floor = 16.0 * est.state_entries() * 2  # every owned state read and written once per trajectory, 2 per step
             result["roofline"] = register_resident_roofline(
                 "hmc_trajectory_kernel (the level samplers; > 99 % of the site-steps)", launch_ms, floor,
-                32.0 * units_per_step / world, pmc_entry("valu", workload=a.workload, size=size, chains=B),
+                32.0 * units_per_step / world, pmc_entry("kernels_valu_busy", workload=a.workload, size=size, chains=B),
                 "one step of all level instances of rank 0")
         else:
             launch_ms = ms(events) / a.steps
@@ -412,7 +412,7 @@ def main():
                                 "parallelism": f"chains sharded over {world} GPU(s), no data-path collective"}
             result["roofline"] = register_resident_roofline(
                 "hmc_chain_kernel" if draws_per_step > 1 else "hmc_trajectory_kernel", launch_ms, floor,
-                32.0 * units_per_step, pmc_entry("valu", workload=a.workload, size=size, chains=B),
+                32.0 * units_per_step, pmc_entry("kernels_valu_busy", workload=a.workload, size=size, chains=B),
                 "state and momenta stay in registers for the whole trajectory")
         result["qoi_mean"] = qoi_mean
         result.update(extra)
@@ -485,11 +485,12 @@ def register_resident_roofline(kernel, launch_ms, floor_bytes, streaming_bytes, 
                         "and written once); streaming_model_GBps is SURVEY 8(d)'s per-unit figure x units / time, a "
                         "rate for comparison with streaming implementations, not a fraction of any roofline"}
     if valu:
-        insts = valu["SQ_INSTS_VALU_per_launch"]
-        r["valu"] = {"wave_insts_per_launch": insts, "achieved": insts / (launch_ms * 1e-3) / 1e9,
-                     "peak": VALU_PEAK_WAVE_INSTS / 1e9, "unit": "G wave-insts/s",
-                     "frac": insts / (launch_ms * 1e-3) / VALU_PEAK_WAVE_INSTS, "source": valu.get("source")}
-        r["valu_frac"] = r["valu"]["frac"]
+        # vector-issue utilisation of the library's kernels over the rocprofv3 SQ pass of THIS kernel build (time weighted):
+        # SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x 2.4 GHz x kernel time); not re-measured in this run
+        r["valu"] = {"frac": valu["valu_frac"], "wave_insts": valu["wave_insts"], "kernel_ns": valu["kernel_ns"],
+                     "peak": VALU_PEAK_WAVE_INSTS / 1e9, "unit": "G wave-insts/s", "dominant_kernel": valu.get("dominant_kernel"),
+                     "source": valu.get("source")}
+        r["valu_frac"] = valu["valu_frac"]
     return r
 
 

@@ -4,14 +4,15 @@
 set -o pipefail
 TAG=${1:-all}
 mkdir -p gpurun_out
-timeout -k 10 400 python bench.py --steps 10 --warmup 2 > gpurun_out/bench_${TAG}.json 2> gpurun_out/bench_${TAG}.err || { tail -5 gpurun_out/bench_${TAG}.err; exit 1; }
+timeout -k 10 400 python bench.py --steps 20 --warmup 5 > gpurun_out/bench_${TAG}.json 2> gpurun_out/bench_${TAG}.err || { tail -5 gpurun_out/bench_${TAG}.err; exit 1; }
 cut -c1-600 gpurun_out/bench_${TAG}.json
 for W in gff rotor_hmc quartic_hmc ho_hmc quartic_mlmc rotor_sweep; do
-  timeout -k 10 400 python bench.py --workload $W --steps 5 --warmup 1 > gpurun_out/bench_${TAG}_$W.json 2> gpurun_out/bench_${TAG}_$W.err || { echo "$W failed"; tail -5 gpurun_out/bench_${TAG}_$W.err; exit 1; }
+  NOCPU="--no-cpu-baseline"; case $W in gff|rotor_hmc|quartic_mlmc) NOCPU="";; esac   # CPU leg for the BASELINE configs only
+  timeout -k 10 400 python bench.py --workload $W --steps 10 --warmup 2 $NOCPU > gpurun_out/bench_${TAG}_$W.json 2> gpurun_out/bench_${TAG}_$W.err || { echo "$W failed"; tail -5 gpurun_out/bench_${TAG}_$W.err; exit 1; }
   python - <<PY
 import json
 r = json.load(open("gpurun_out/bench_${TAG}_$W.json"))
-print("$W", "%.4g" % r["value"], r["unit"], "ms/step %.3f" % r["ms_per_step"], "roofline frac %.3f" % r["roofline"]["frac"], "qoi", r.get("qoi_mean"))
+print("$W", "%.4g" % r["value"], r["unit"], "ms/step %.3f" % r["ms_per_step"], "roofline frac %.3f" % r["roofline"]["frac"], "valu_frac", r["roofline"].get("valu_frac"), "qoi", r.get("qoi_mean"))
 PY
 done
 MLMCPI_BENCH_BACKEND=gloo timeout -k 10 400 python bench.py --gpus 2 --steps 4 --warmup 1 --chains 8 --no-extra-points > gpurun_out/bench_${TAG}_n2.json 2> gpurun_out/bench_${TAG}_n2.err; echo "n2 rehearsal exit $?"; cut -c1-300 gpurun_out/bench_${TAG}_n2.json

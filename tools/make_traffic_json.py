@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""profiles/traffic.json from the summary of tools/profile_all.sh (gpurun_out/prof_<tag>/summary.json): the per-launch PMC
+figures bench.py quotes, each tagged with the kernel build it was measured on (bench.py quotes none from another build).
+   python tools/make_traffic_json.py gpurun_out/prof_r02 r02"""
+import json, os, sys
+src, tag = sys.argv[1], sys.argv[2]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+S = json.load(open(os.path.join(src, "summary.json")))
+SIZES = {"schwinger": 1024, "gff": 512, "rotor_hmc": 65536, "quartic_hmc": 32768, "ho_hmc": 128, "quartic_mlmc": 32768, "rotor_sweep": 65536}
+CHAINS = {"schwinger": 32, "gff": 1024, "rotor_hmc": 1024, "quartic_hmc": 2048, "ho_hmc": 8192, "quartic_mlmc": 512, "rotor_sweep": 1024}
+out = {"_how": "tools/profile_all.sh: rocprofv3 --pmc <counters> --kernel-trace on `python3 bench.py --workload W --steps 5 --warmup 2 "
+               "--no-cpu-baseline --no-extra-points`, one pass per counter group (SQ group; FETCH_SIZE; WRITE_SIZE), per-launch "
+               "averages over every launch of the run.  FETCH_SIZE / WRITE_SIZE are KiB; FETCH_SIZE is doubled (gfx950 counts a "
+               "128-byte request of a 16-byte-per-lane streaming read as 64 B, MI355X_MICROARCH.md HBM section); WRITE_SIZE is "
+               "exact.  `build` = hash of the kernel sources (bench.py build_id()).  Raw summary: profiles/%s_profile_summary.json." % tag,
+       "entries": [], "valu": [], "kernels_valu_busy": []}
+for w, e in S.items():
+    build = (e.get("bench_profiled") or {}).get("kernel_build")
+    tot_insts = tot_ns = 0.0
+    for name, k in e["kernels"].items():
+        if "SQ_INSTS_VALU" in k and "avg_ns" in k:
+            tot_insts += k["SQ_INSTS_VALU"] * k["calls"]
+            tot_ns += k["avg_ns"] * k["calls"]
+        short = name.replace("mlmcpi::", "")
+        kind = None
+        if "or_patch_kernel" in short or "or_kernel" in short or "sweep_kernel<false" in short:
+            kind = "overrelax"
+        elif "sweep_kernel<true" in short:
+            kind = "heatbath"
+        fuse = 1
+        if "or_patch_kernel<" in short:
+            fuse = int(short.split("<")[1].split(">")[0])
+        if kind and w in ("schwinger", "gff", "rotor_sweep"):
+            if "hbm_bytes_per_launch" in k:
+                out["entries"].append({"workload": w, "size": SIZES[w], "chains": CHAINS[w], "fuse": fuse, "kind": kind, "kernel": short,
+                                       "hbm_bytes_per_launch": k["hbm_bytes_per_launch"], "read_bytes": k["read_bytes_corrected"],
+                                       "write_bytes": k["write_bytes"], "launches": k.get("FETCH_SIZE_launches"), "build": build,
+                                       "source": f"profiles/{tag}_profile_summary.json"})
+            if "SQ_INSTS_VALU" in k:
+                out["valu"].append({"workload": w, "size": SIZES[w], "chains": CHAINS[w], "fuse": fuse, "kind": kind, "kernel": short,
+                                    "SQ_INSTS_VALU_per_launch": k["SQ_INSTS_VALU"], "SQ_ACTIVE_INST_VALU": k.get("SQ_ACTIVE_INST_VALU"),
+                                    "SQ_BUSY_CYCLES": k.get("SQ_BUSY_CYCLES"), "SQ_INSTS_SALU": k.get("SQ_INSTS_SALU"),
+                                    "SQ_INSTS_LDS": k.get("SQ_INSTS_LDS"), "GRBM_GUI_ACTIVE": k.get("GRBM_GUI_ACTIVE"),
+                                    "avg_ns_profiled": k.get("avg_ns"), "build": build, "source": f"profiles/{tag}_profile_summary.json"})
+    if tot_ns:
+        # time-weighted vector-issue utilisation of the library's kernels over the profiled run:
+        # wave-instructions x 4 cycles / (1024 SIMDs x 2.4 GHz x kernel time)
+        out["kernels_valu_busy"].append({"workload": w, "size": SIZES[w], "chains": CHAINS[w], "wave_insts": tot_insts, "kernel_ns": tot_ns,
+                                         "valu_frac": tot_insts / (tot_ns * 1e-9) / (256 * 4 * 2.4e9 / 4), "build": build,
+                                         "dominant_kernel": max(e["kernels"].items(), key=lambda kv: kv[1].get("pct", 0))[0].replace("mlmcpi::", ""),
+                                         "source": f"profiles/{tag}_profile_summary.json"})
+json.dump(out, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
+json.dump(S, open(os.path.join(ROOT, "profiles", f"{tag}_profile_summary.json"), "w"), indent=1)
+for f in os.listdir(src):
+    if f.endswith("_kernel_stats.csv"):
+        open(os.path.join(ROOT, "profiles", f"{tag}_{f}"), "w").write(open(os.path.join(src, f)).read())
+print(len(out["entries"]), "traffic entries,", len(out["valu"]), "valu entries,", len(out["kernels_valu_busy"]), "workload utilisations")
+for e in out["kernels_valu_busy"]:
+    print(f"  {e['workload']:14s} valu_frac {e['valu_frac']:.3f}  ({e['dominant_kernel']})")
