@@ -135,7 +135,7 @@ class SweepWorkload:
         self.fuse = a.fuse or 4  # library default
         self.sweep = 0
         self.n_full = (a.n_overrelax // self.fuse) * self.fuse
-        self.ev = {"or": [], "hb": [], "qoi": []}
+        self.ev = {"or": [], "rem": [], "hb": [], "qoi": []}
 
     def qoi(self):
         if self.kind == "schwinger":
@@ -168,6 +168,7 @@ class SweepWorkload:
         if record:
             e[4].record()
             self.ev["or"].append((e[0], e[1]))
+            self.ev["rem"].append((e[1], e[2]))
             self.ev["hb"].append((e[2], e[3]))
             self.ev["qoi"].append((e[3], e[4]))
         self.sweep = s + a.n_overrelax + a.n_heatbath
@@ -540,6 +541,10 @@ def report_sweeps(result, a, W, size, B, world, step_ms, ms):
     if n_launch:
         record(or_name, f"{fuse} fused overrelaxation sweeps", W.ev["or"], n_launch, fuse, state_rw,
                pmc_entry("entries", chains=B, fuse=fuse, kind="overrelax", **wl), pmc_entry("valu", kind="overrelax", fuse=fuse, **wl))
+    if rem:
+        rem_name = or_name.replace(f"<{fuse}>", f"<{rem}>") if "patch" in or_name else or_name
+        record(rem_name, f"{rem} fused overrelaxation sweeps (remainder launch)", W.ev["rem"], 1, rem, state_rw,
+               pmc_entry("entries", chains=B, fuse=rem, kind="overrelax", **wl), pmc_entry("valu", kind="overrelax", fuse=rem, **wl))
     if a.n_heatbath:
         record(hb_name, "heat-bath sweep", W.ev["hb"], a.n_heatbath, 1, state_rw,
                pmc_entry("entries", chains=B, fuse=1, kind="heatbath", **wl), pmc_entry("valu", kind="heatbath", **wl))

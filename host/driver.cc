@@ -89,6 +89,8 @@ int main(int argc, char **argv) {
     } else {
       action = std::make_shared<GFFAction>(lat, nullptr, num("mass"));
       qoi = std::make_shared<QoI2DPhiSquared>(lat);
+      qoi_factory = std::make_shared<QoI2DPhiSquaredFactory>();           // driver_qft.cc:247-252
+      cfa_factory = std::make_shared<GFFConditionedFineActionFactory>();  // driver_qft.cc:331-333 (use --coarsening rotate)
     }
   } else {
     fatal("unknown action " + a);

@@ -368,6 +368,45 @@ int main(int argc, char **argv) {
     ZEXPECT(st->average(), std::fmax(st->error(), 5e-4), exact, 5, "Schwinger CoarsenBoth plaquette");
     EXPECT(mc.get_sampler()->p_accept() > 0.5, "Schwinger CoarsenBoth acceptance");
   }
+  // ---- GFF 16 x 16, CoarsenRotate: hierarchical sampler over the rotated coarse level (n_gibbs_smooth = 2, its own exact
+  //      sampler on the coarsest level, Gaussian fill-in of the odd vertices) and a 2-level multilevel estimate ----------
+  {
+    auto lat = std::make_shared<Lattice2D>(16, 16, CoarsenRotate);
+    auto act = std::make_shared<GFFAction>(lat, nullptr, 10.0);
+    const double exact = 0.33804823;  // gff_phi_squared_analytical(10, 16, 16)
+    auto cfa = std::make_shared<GFFConditionedFineActionFactory>();
+    // 2 levels: 16 x 16 -> rotated 16 x 16 (128 vertices), whose smoothed action is two Gibbs sweeps away from the exact
+    // marginal: nearly every proposal is accepted.  3 levels (-> 8 x 8): the fill-in of the rotated level is exact for the
+    // PLAIN stencil there, while that level's action is the smoothed one -- in the reference as here -- so its two-level
+    // step rejects often; the chain is still exact (delayed acceptance), only slower.
+    for (unsigned int n_levels = 2; n_levels <= 3; ++n_levels) {
+      HierarchicalParameters hier;
+      hier.n_max_level = n_levels; hier.n_meas = 20;
+      auto hfac = std::make_shared<HierarchicalSamplerFactory>(std::make_shared<ExactSamplerFactory>(), cfa, hier);
+      SingleLevelMCParameters mp;
+      mp.n_burnin = 100; mp.n_samples = n_levels == 2 ? 8000 : 20000; mp.n_autocorr_window = 20;
+      MonteCarloSingleLevel mc(act, std::make_shared<QoI2DPhiSquared>(lat), hfac, mp);
+      mc.evaluate();
+      auto st = mc.get_statistics();
+      std::printf(" GFF CoarsenRotate hierarchical sampler (%u levels): <phi^2> %.6f +- %.6f (exact %.6f), tau_int %.2f, p_accept %.3f\n",
+                  n_levels, st->average(), st->error(), exact, st->tau_int(), mc.get_sampler()->p_accept());
+      ZEXPECT(st->average(), st->error(), exact, 5, "GFF hierarchical <phi^2>");
+      if (n_levels == 2) EXPECT(mc.get_sampler()->p_accept() > 0.9, "GFF 2-level acceptance %.3f", mc.get_sampler()->p_accept());
+    }
+    // coarse action: copy_from_fine then evaluate on the rotated level equals evaluating Qhat there (consistency of the
+    // vertex maps between the classes)
+    auto coarse = std::dynamic_pointer_cast<GFFAction>(act->coarse_action());
+    auto fine_state = std::make_shared<SampleState>(act->sample_size()), coarse_state = std::make_shared<SampleState>(coarse->sample_size());
+    fill_sin(fine_state);
+    coarse->copy_from_fine(fine_state, coarse_state);
+    auto back = std::make_shared<SampleState>(act->sample_size());
+    act->copy_from_coarse(coarse_state, back);
+    double worst = 0;
+    for (unsigned i = 0; i < 16; ++i)
+      for (unsigned j = 0; j < 16; ++j)
+        if ((i + j) % 2 == 0) worst = std::fmax(worst, std::fabs(back->data[16 * j + i] - fine_state->data[16 * j + i]));
+    EXPECT(worst == 0.0 && coarse->sample_size() == 128 && coarse->evaluate(coarse_state) > 0.0, "GFF level transfer round trip");
+  }
   // ---- OverrelaxedHeatBathSampler::draw without a copy: same chain as the plain C-ABI sweeps, lent samples stay intact ----
   {
     auto lat = std::make_shared<Lattice2D>(64, 64, CoarsenBoth);

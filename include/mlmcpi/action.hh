@@ -317,20 +317,82 @@ protected:
  *  not built (they make the reference unusable beyond ~64 x 64). */
 class GFFAction : public QFTAction {
 public:
-  GFFAction(const std::shared_ptr<Lattice2D> lattice_, const std::shared_ptr<Lattice2D> fine_lattice_, const double mass_)
-      : QFTAction(lattice_, fine_lattice_, RenormalisationNone, MLMCPI_GFF, 0.0, mass_), mass(mass_) {
+  /** gffaction.hh:120-146.  n_gibbs_smooth > 0: the coarse action of a hierarchy, phi^T Qhat phi with the dense smoothed
+   *  precision matrix of gffaction.cc:126-173 (levels of up to 4096 vertices).  Rotated lattices (odd levels of
+   *  CoarsenRotate) and smoothed levels run through the level object of the C ABI (mlmcpi_gff_level_*); the plain
+   *  unrotated level -- the finest level of a run -- keeps the stencil kernels and the FFT sampler of mlmcpi_lattice_*. */
+  GFFAction(const std::shared_ptr<Lattice2D> lattice_, const std::shared_ptr<Lattice2D> fine_lattice_, const double mass_,
+            const int n_gibbs_smooth_ = 0, const double omega_ = 1.0)
+      : QFTAction(lattice_, fine_lattice_, RenormalisationNone, MLMCPI_GFF, 0.0, mass_), mass(mass_), n_gibbs_smooth(n_gibbs_smooth_),
+        omega(omega_) {
     if (lattice->getMt_lat() != lattice->getMx_lat()) fatal("Lattice has to be squared for GFF action ");
-    if (lattice->is_rotated()) fatal("rotated lattices are not supported by the device GFF action");
-    const double a = 1. / lattice->getMt_lat();
+    const double a = (lattice->is_rotated() ? std::sqrt(2.) : 1.) / lattice->getMt_lat();  // gffaction.hh:174-181
     mu2 = a * a * mass * mass;
+    check(mlmcpi_gff_level_create(lattice->getMt_lat(), lattice->getMx_lat(), (int32_t)lattice->get_coarsening_type(),
+                                  lattice->get_coarsening_level(), mass, n_gibbs_smooth, omega, &level), "gff_level_create");
+  }
+  ~GFFAction() override {
+    mlmcpi_gff_level_destroy(level);
+    mlmcpi_gff_level_destroy(fine_level);
   }
   unsigned int sample_size() const override { return lattice->getNvertices(); }
   double getmu2() const { return mu2; }
+  /** the level whose kernels need no table: unrotated, not smoothed */
+  bool plain() const { return !lattice->is_rotated() && n_gibbs_smooth == 0; }
+  mlmcpi_gff_level *level_handle() const { return level; }
+  /** gffaction.hh:201-208 */
+  std::shared_ptr<Action> coarse_action() override {
+    std::shared_ptr<Lattice2D> coarse_lattice = lattice->get_coarse_lattice();
+    if (!coarse_lattice)
+      fatal("cannot coarsen 2d lattice with M_{t,lat} = " + std::to_string(lattice->getMt_lat()) + " , M_{x,lat} = " + std::to_string(lattice->getMx_lat()) + ".");
+    return std::make_shared<GFFAction>(coarse_lattice, lattice, mass, 2, 1.0);
+  }
+  std::vector<double> evaluate_batch(const std::shared_ptr<SampleState> phi) const override {
+    if (plain()) return QFTAction::evaluate_batch(phi);
+    DeviceVector out(phi->batch());
+    check(mlmcpi_gff_level_evaluate(level, phi->device(), phi->batch(), (double *)out.ptr(), nullptr), "gff_level_evaluate");
+    return out.download<double>();
+  }
+  void force(const std::shared_ptr<SampleState> phi, std::shared_ptr<SampleState> p) const override {
+    if (!plain()) fatal("force of the GFF action is only built for the plain (unrotated, unsmoothed) level");
+    QFTAction::force(phi, p);
+  }
+  void sweep(std::shared_ptr<SampleState> phi, std::shared_ptr<SampleState> scratch, unsigned n_or, unsigned n_hb, uint32_t sweep0) override {
+    if (!plain()) fatal("heat bath / overrelaxation sweeps of the GFF action are only built for the plain level");
+    QFTAction::sweep(phi, scratch, n_or, n_hb, sweep0);
+  }
+  int sweep_from(const double *d_src, double *d_w0, double *d_w1, unsigned batch, unsigned n_or, unsigned n_hb, uint32_t sweep0) override {
+    if (!plain()) fatal("heat bath / overrelaxation sweeps of the GFF action are only built for the plain level");
+    return QFTAction::sweep_from(d_src, d_w0, d_w1, batch, n_or, n_hb, sweep0);
+  }
+  /** GFFAction::draw (gffaction.cc:200-213): exact draw + n_gibbs_smooth Gibbs sweeps; `step` numbers the draws */
+  void draw_level(std::shared_ptr<SampleState> phi, uint32_t step) const {
+    check(mlmcpi_gff_level_draw(level, phi->device_overwrite(), phi->batch(), seed ^ 0x45584143ull, chain0, step, nullptr), "gff_level_draw");
+  }
+  /** gffaction.cc:121-123: initialise_state = draw */
+  void initialise_state(std::shared_ptr<SampleState> phi) const override {
+    if (plain()) QFTAction::initialise_state(phi); else draw_level(phi, 0xFFFFFFu);
+  }
+  /** gffaction.cc:97-118 */
+  void copy_from_coarse(const std::shared_ptr<SampleState> phi_coarse, std::shared_ptr<SampleState> phi_state) override {
+    check(mlmcpi_gff_copy_from_coarse(level, phi_coarse->device(), phi_state->device_mutable(), phi_state->batch(), nullptr), "gff_copy_from_coarse");
+  }
+  void copy_from_fine(const std::shared_ptr<SampleState> phi_fine, std::shared_ptr<SampleState> phi_state) override {
+    if (!fine_lattice) fatal("cannot copy from fine lattice.");
+    if (!fine_level)  // the finer lattice's vertex lists (tables only)
+      check(mlmcpi_gff_level_create(fine_lattice->getMt_lat(), fine_lattice->getMx_lat(), (int32_t)fine_lattice->get_coarsening_type(),
+                                    fine_lattice->get_coarsening_level(), mass, 0, 1.0, &fine_level), "gff_level_create");
+    check(mlmcpi_gff_copy_from_fine(fine_level, phi_fine->device(), phi_state->device_mutable(), phi_state->batch(), nullptr), "gff_copy_from_fine");
+  }
   std::string info_string() const override { return QFTAction::info_string() + ", mu2 = " + std::to_string(mu2); }
 
 private:
   const double mass;
+  const int n_gibbs_smooth;
+  const double omega;
   double mu2;
+  mlmcpi_gff_level *level = nullptr;
+  mutable mlmcpi_gff_level *fine_level = nullptr;
 };
 
 /** action/qft/quenchedschwingeraction.hh:100-277 */

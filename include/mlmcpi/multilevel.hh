@@ -109,6 +109,37 @@ public:
   }
 };
 
+/** action/qft/gffconditionedfineaction.{hh,cc}: a fine-only vertex is Gaussian around the mean of its four nearest
+ *  neighbours, all of them coarse vertices (red-black coarsening, CoarsenRotate); fill_fine_points / evaluate run inside
+ *  mlmcpi_gff_twolevel_draw, and are exposed here for direct use. */
+class GFFConditionedFineAction : public ConditionedFineAction {
+public:
+  explicit GFFConditionedFineAction(const std::shared_ptr<GFFAction> action_) : action(action_) {}
+  std::shared_ptr<Action> fine_action() const override { return action; }
+  void fill_fine_points(std::shared_ptr<SampleState> phi_state, uint32_t step = 0) const {
+    DeviceVector S(phi_state->batch());
+    check(mlmcpi_gff_cfa_fill(action->level_handle(), phi_state->device_mutable(), phi_state->batch(), action->get_seed() ^ 0x115147ull,
+                              action->get_chain0(), step, (double *)S.ptr(), nullptr), "gff_cfa_fill");
+  }
+  double evaluate(const std::shared_ptr<SampleState> phi_state) const {
+    DeviceVector S(phi_state->batch());
+    check(mlmcpi_gff_cfa_evaluate(action->level_handle(), phi_state->device(), phi_state->batch(), (double *)S.ptr(), nullptr), "gff_cfa_evaluate");
+    return S.download<double>()[0];
+  }
+
+private:
+  const std::shared_ptr<GFFAction> action;
+};
+
+class GFFConditionedFineActionFactory : public ConditionedFineActionFactory {
+public:
+  std::shared_ptr<ConditionedFineAction> get(std::shared_ptr<Action> action) override {
+    auto gff = std::dynamic_pointer_cast<GFFAction>(action);
+    if (!gff) fatal("GFF conditioned fine action needs a GFFAction");
+    return std::make_shared<GFFConditionedFineAction>(gff);
+  }
+};
+
 /** twolevelmetropolisstep.{hh,cc}: draws a fine-level sample from a coarse-level proposal. */
 class TwoLevelMetropolisStep : public MCMCStep {
 public:
@@ -117,11 +148,13 @@ public:
                          unsigned int n_meas = 200)
       : MCMCStep(), coarse(coarse_action_), fine(fine_action_), qm_coarse(std::dynamic_pointer_cast<QMAction>(coarse_action_)),
         qm_fine(std::dynamic_pointer_cast<QMAction>(fine_action_)), qft_coarse(std::dynamic_pointer_cast<QFTAction>(coarse_action_)),
-        qft_fine(std::dynamic_pointer_cast<QFTAction>(fine_action_)), cfa(conditioned_fine_action_), B(batch),
+        qft_fine(std::dynamic_pointer_cast<QFTAction>(fine_action_)), gff_coarse(std::dynamic_pointer_cast<GFFAction>(coarse_action_)),
+        gff_fine(std::dynamic_pointer_cast<GFFAction>(fine_action_)), cfa(conditioned_fine_action_), B(batch),
         accept_flags(batch, sizeof(int32_t)), cost_per_sample_(0.0) {
     if (!cfa || !((qm_coarse && qm_fine) || (qft_coarse && qft_fine))) fatal("TwoLevelMetropolisStep: actions have no device implementation");
     size_t bytes = 0;
-    if (qm_fine) check(mlmcpi_path_twolevel_workspace_bytes(&qm_fine->abi_action(), B, &bytes), "twolevel_workspace_bytes");
+    if (gff_fine && gff_coarse) check(mlmcpi_gff_twolevel_workspace_bytes(gff_fine->level_handle(), B, &bytes), "gff_twolevel_workspace_bytes");
+    else if (qm_fine) check(mlmcpi_path_twolevel_workspace_bytes(&qm_fine->abi_action(), B, &bytes), "twolevel_workspace_bytes");
     else check(mlmcpi_lattice_twolevel_workspace_bytes(&qft_fine->abi_action(), &qft_coarse->abi_action(), B, &bytes), "twolevel_workspace_bytes");
     check(mlmcpi_malloc(&work, bytes), "mlmcpi_malloc");
     theta_fine = std::make_shared<SampleState>(fine->sample_size(), B);
@@ -139,7 +172,11 @@ public:
 
   /** twolevelmetropolisstep.cc:35-89 */
   void draw(const std::shared_ptr<SampleState> phi_coarse_state, std::shared_ptr<SampleState> phi_state) {
-    if (qm_fine)
+    if (gff_fine && gff_coarse)
+      check(mlmcpi_gff_twolevel_draw(gff_fine->level_handle(), gff_coarse->level_handle(), phi_coarse_state->device(),
+                                     theta_fine->device_mutable(), B, level_seed(), fine->get_chain0(), step++, work,
+                                     (int32_t *)accept_flags.ptr(), nullptr, nullptr), "gff_twolevel_draw");
+    else if (qm_fine)
       check(mlmcpi_path_twolevel_draw(&qm_fine->abi_action(), &qm_coarse->abi_action(), phi_coarse_state->device(),
                                       theta_fine->device_mutable(), B, level_seed(), fine->get_chain0(), step++, work,
                                       (int32_t *)accept_flags.ptr(), nullptr, nullptr), "path_twolevel_draw");
@@ -167,6 +204,7 @@ private:
   const std::shared_ptr<Action> coarse, fine;
   const std::shared_ptr<QMAction> qm_coarse, qm_fine;
   const std::shared_ptr<QFTAction> qft_coarse, qft_fine;
+  const std::shared_ptr<GFFAction> gff_coarse, gff_fine;
   const std::shared_ptr<ConditionedFineAction> cfa;
   const unsigned int B;
   std::shared_ptr<SampleState> theta_fine;

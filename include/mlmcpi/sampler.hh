@@ -297,15 +297,20 @@ public:
   GFFExactSampler(const std::shared_ptr<Action> action_, unsigned int batch = 1)
       : Sampler(), action(std::dynamic_pointer_cast<GFFAction>(action_)), B(batch) {
     if (!action) fatal("exact sampler only for the GFF action");
-    size_t bytes = 0;
-    check(mlmcpi_lattice_exact_workspace_bytes(&action->abi_action(), B, &bytes), "lattice_exact_workspace_bytes");
-    check(mlmcpi_malloc(&work, bytes), "mlmcpi_malloc");
+    if (action->plain()) {
+      size_t bytes = 0;
+      check(mlmcpi_lattice_exact_workspace_bytes(&action->abi_action(), B, &bytes), "lattice_exact_workspace_bytes");
+      check(mlmcpi_malloc(&work, bytes), "mlmcpi_malloc");
+    }
     state = std::make_shared<SampleState>(action->sample_size(), B);
   }
   ~GFFExactSampler() { mlmcpi_free(work); }
   void draw(std::shared_ptr<SampleState> phi_state) override {
-    check(mlmcpi_lattice_exact_draw(&action->abi_action(), state->device_mutable(), B, action->get_seed() ^ 0x45584143ull,
-                                    action->get_chain0(), step++, work, nullptr), "lattice_exact_draw");
+    if (action->plain())  // the finest level: spectral synthesis at any size
+      check(mlmcpi_lattice_exact_draw(&action->abi_action(), state->device_mutable(), B, action->get_seed() ^ 0x45584143ull,
+                                      action->get_chain0(), step++, work, nullptr), "lattice_exact_draw");
+    else  // a level of the hierarchy (rotated and / or Gibbs smoothed): GFFAction::draw, gffaction.cc:200-213
+      action->draw_level(state, step++);
     accept = true;
     n_total_samples++;
     n_accepted_samples++;
@@ -321,7 +326,8 @@ private:
   uint32_t step = 0;
 };
 
-/** sampler = 'exact' (driver_qm.cc / driver_qft.cc): the harmonic oscillator and the GFF are their own samplers */
+/** sampler = 'exact' (driver_qm.cc / driver_qft.cc): the harmonic oscillator and the GFF are their own samplers
+ *  (driver_qft.cc:84-85: GFFSamplerFactory for every level of a GFF hierarchy) */
 class ExactSamplerFactory : public SamplerFactory {
 public:
   explicit ExactSamplerFactory(unsigned int batch_ = 1) : batch(batch_) {}

@@ -247,6 +247,47 @@ int mlmcpi_lattice_twolevel_draw(const mlmcpi_lattice_action *fine, const mlmcpi
 int mlmcpi_lattice_exact_workspace_bytes(const mlmcpi_lattice_action *act, uint32_t B, size_t *bytes);
 int mlmcpi_lattice_exact_draw(const mlmcpi_lattice_action *act, double *d_phi, uint32_t B, uint64_t seed, uint32_t chain0,
                               uint32_t step, void *d_work, void *stream);
+/* ---- Gaussian free field: levels of a coarsening hierarchy and the two-level step between them ------
+ * A level = GFFAction(lattice, fine_lattice, mass, n_gibbs_smooth, omega) (action/qft/gffaction.hh:120-146) on the lattice
+ * (Mt, Mx, coarsening type, coarsening level); CoarsenRotate levels of odd depth are rotated lattices
+ * (lattice/lattice2d.hh:98-437).  The reference's coarse_action() is (coarse lattice, mass, n_gibbs_smooth = 2, omega = 1)
+ * (gffaction.hh:201-208).  Levels with n_gibbs_smooth > 0 evaluate 1/2 phi^T Qhat phi with the dense smoothed precision
+ * matrix of gffaction.cc:126-173 (built on the host, levels of up to 4096 vertices); index maps come from tables like the
+ * reference's.  The finest level of a run keeps using mlmcpi_lattice_* (stencil kernels, FFT sampler). */
+typedef struct mlmcpi_gff_level mlmcpi_gff_level;
+int mlmcpi_gff_level_create(uint32_t Mt, uint32_t Mx, int32_t coarsening_type, int32_t level, double mass, int32_t n_gibbs_smooth,
+                            double omega, mlmcpi_gff_level **out);
+int mlmcpi_gff_level_destroy(mlmcpi_gff_level *level);
+/* sample_size; number of vertices / extents of the next-coarser lattice (0 if there is none); mu2 (gffaction.hh:174-181) */
+int mlmcpi_gff_level_info(const mlmcpi_gff_level *level, uint32_t *n_vertices, uint32_t *n_coarse, uint32_t *Mt_coarse,
+                          uint32_t *Mx_coarse, double *mu2);
+/* lattice2d.cc:82-134 (host): pairs[2 n_coarse] = (fine index, coarse index) ascending in the fine index = fine2coarse_map;
+ * fineonly[n_vertices - n_coarse] ascending = fineonly_vertices */
+int mlmcpi_gff_level_tables(const mlmcpi_gff_level *level, uint32_t *pairs, uint32_t *fineonly);
+/* host copies of the dense matrices, row major [N][N]: which = 0 Qhat (gffaction.cc:165-167), 1 inverse of the Cholesky
+ * factor of the plain precision matrix (the exact sampler, gffaction.cc:169-173) */
+int mlmcpi_gff_level_matrix(mlmcpi_gff_level *level, int32_t which, double *h_out);
+/* GFFAction::evaluate (gffaction.cc:8-30) */
+int mlmcpi_gff_level_evaluate(mlmcpi_gff_level *level, const double *d_phi, uint32_t B, double *d_S, void *stream);
+/* GFFAction::draw (gffaction.cc:200-213): exact draw + n_gibbs_smooth lexicographic sweeps of
+ * global_heatbath_update_eff (:45-66); Philox (pair l >> 1, branch l & 1) with purpose 12 (white noise) / 11 (sweep k = sub) */
+int mlmcpi_gff_level_draw(mlmcpi_gff_level *level, double *d_phi, uint32_t B, uint64_t seed, uint32_t chain0, uint32_t step,
+                          void *stream);
+/* GFFAction::copy_from_fine / copy_from_coarse (gffaction.cc:97-118); `fine` is the finer of the two levels */
+int mlmcpi_gff_copy_from_fine(mlmcpi_gff_level *fine, const double *d_fine, double *d_coarse, uint32_t B, void *stream);
+int mlmcpi_gff_copy_from_coarse(mlmcpi_gff_level *fine, const double *d_coarse, double *d_fine, uint32_t B, void *stream);
+/* GFFConditionedFineAction (gffconditionedfineaction.cc:7-49): fill_fine_points (fine-only vertex l ~ N(sigma^2 Delta,
+ * sigma^2), normal = Philox(site l, purpose 7); d_S[b] = the conditioned action of the filled state) and evaluate */
+int mlmcpi_gff_cfa_fill(mlmcpi_gff_level *fine, double *d_state, uint32_t B, uint64_t seed, uint32_t chain0, uint32_t step,
+                        double *d_S, void *stream);
+int mlmcpi_gff_cfa_evaluate(mlmcpi_gff_level *fine, const double *d_state, uint32_t B, double *d_S, void *stream);
+/* TwoLevelMetropolisStep::draw (twolevelmetropolisstep.cc:35-89) for a GFF level and its coarsening: d_theta is the current
+ * fine state (updated in place on acceptance), d_terms[b] = (dS_fine, dS_coarse, dS_trial) (may be NULL) */
+int mlmcpi_gff_twolevel_workspace_bytes(const mlmcpi_gff_level *fine, uint32_t B, size_t *bytes);
+int mlmcpi_gff_twolevel_draw(mlmcpi_gff_level *fine, mlmcpi_gff_level *coarse, const double *d_phi_coarse, double *d_theta,
+                             uint32_t B, uint64_t seed, uint32_t chain0, uint32_t step, void *d_work, int32_t *d_accept,
+                             double *d_terms, void *stream);
+
 /* QoI2DPhiSquared (qoi/qft/qoi2dphisquared.cc:8-15), QoIAvgPlaquette (qoi/qft/qoiavgplaquette.cc:8-27),
  * QoI2DSusceptibility (qoi/qft/qoi2dsusceptibility.cc:8-27); d_out[b]. */
 int mlmcpi_qoi_phi_squared(const double *d_phi, uint32_t n_vertices, uint32_t B, double *d_out, void *stream);

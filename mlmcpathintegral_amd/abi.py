@@ -80,6 +80,19 @@ SIGNATURES = {
     "mlmcpi_lattice_force": (_i, [_LA, _vp, _vp, _u32, _vp]),
     "mlmcpi_lattice_initialise": (_i, [_LA, _vp, _u32, _u64, _u32, _vp]),
     "mlmcpi_lattice_sweep_draw": (_i, [_LA, _vp, _vp, _u32, _u32, _u32, _u64, _u32, _u32, _u32, _vp]),
+    "mlmcpi_gff_level_create": (_i, [_u32, _u32, C.c_int32, C.c_int32, _d, C.c_int32, _d, _vp]),
+    "mlmcpi_gff_level_destroy": (_i, [_vp]),
+    "mlmcpi_gff_level_info": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "mlmcpi_gff_level_tables": (_i, [_vp, _vp, _vp]),
+    "mlmcpi_gff_level_matrix": (_i, [_vp, C.c_int32, _vp]),
+    "mlmcpi_gff_level_evaluate": (_i, [_vp, _vp, _u32, _vp, _vp]),
+    "mlmcpi_gff_level_draw": (_i, [_vp, _vp, _u32, _u64, _u32, _u32, _vp]),
+    "mlmcpi_gff_copy_from_fine": (_i, [_vp, _vp, _vp, _u32, _vp]),
+    "mlmcpi_gff_copy_from_coarse": (_i, [_vp, _vp, _vp, _u32, _vp]),
+    "mlmcpi_gff_cfa_fill": (_i, [_vp, _vp, _u32, _u64, _u32, _u32, _vp, _vp]),
+    "mlmcpi_gff_cfa_evaluate": (_i, [_vp, _vp, _u32, _vp, _vp]),
+    "mlmcpi_gff_twolevel_workspace_bytes": (_i, [_vp, _u32, _vp]),
+    "mlmcpi_gff_twolevel_draw": (_i, [_vp, _vp, _vp, _vp, _u32, _u64, _u32, _u32, _vp, _vp, _vp, _vp]),
     "mlmcpi_lattice_sweep_draw_from": (_i, [_LA, _vp, _vp, _vp, _u32, _u32, _u32, _u64, _u32, _u32, _u32, _vp, _vp]),
     "mlmcpi_lattice_sweep_draw_pingpong": (_i, [_LA, _vp, _vp, _u32, _u32, _u32, _u64, _u32, _u32, _u32,
                                                 C.POINTER(C.c_int32), _vp]),

@@ -91,6 +91,19 @@ _SIGS = {
     "orc_stats_record": (None, [_vp, _dp, _u32]),
     "orc_stats_reset": (None, [_vp, _i]),
     "orc_stats_get": (None, [_vp, _dp]),
+    "orc_gff_level_new": (_vp, [_u32, _u32, _i, _i, _d, _i, _d]),
+    "orc_gff_level_free": (None, [_vp]),
+    "orc_gff_level_size": (_u32, [_vp]),
+    "orc_gff_level_n_coarse": (_u32, [_vp]),
+    "orc_gff_level_mu2": (_d, [_vp]),
+    "orc_gff_level_tables": (None, [_vp, _vp, _vp]),
+    "orc_gff_level_matrix": (None, [_vp, _i, _dp]),
+    "orc_gff_level_evaluate": (_d, [_vp, _dp]),
+    "orc_gff_level_dev_draw": (None, [_vp, _dp, _u64, _u32, _u32]),
+    "orc_gff_cfa_evaluate": (_d, [_vp, _dp]),
+    "orc_gff_cfa_dev_fill": (_d, [_vp, _dp, _u64, _u32, _u32]),
+    "orc_gff_copy": (None, [_vp, _dp, _dp, _i]),
+    "orc_gff_dev_twolevel_draw": (_i, [_vp, _vp, _dp, _dp, _u64, _u32, _u32, _dp]),
     "orc_rank_seeds": (None, [_u32, _u32, _vp]),
     "orc_rank_engine_outputs": (None, [_u32, _u32, _u32, _u32, _vp]),
     "orc_ho_xsquared_analytical": (_d, [_u32, _d, _d, _d]),

@@ -1288,6 +1288,224 @@ struct StatsO {
 // =============================================================================================
 // C surface for ctypes (tests, smoke, cpu_baseline).
 // =============================================================================================
+
+// =================================================================================================================
+// Gaussian free field on the levels of a coarsening hierarchy: GFFAction with Gibbs smoothing
+// (action/qft/gffaction.{hh,cc}), GFFConditionedFineAction (action/qft/gffconditionedfineaction.cc:7-49), the vertex
+// lists of Lattice2D (lattice/lattice2d.cc:82-134) and the two-level step between two GFF levels
+// (montecarlo/twolevelmetropolisstep.cc:35-89).  Dense matrices as in the reference (gffaction.cc:126-173), with
+// Gauss-Jordan inverses -- deliberately not the Cholesky route of the library under test.
+// =================================================================================================================
+constexpr uint32_t P_GFF_GIBBS = 11, P_GFF_EXACT = 12;
+
+typedef std::vector<double> Mat;  // row major n x n
+
+static Mat mat_inverse(Mat A, unsigned n) {  // Gauss-Jordan with partial pivoting
+  Mat I((size_t)n * n, 0.0);
+  for (unsigned i = 0; i < n; ++i) I[(size_t)i * n + i] = 1.0;
+  for (unsigned c = 0; c < n; ++c) {
+    unsigned piv = c;
+    for (unsigned r = c + 1; r < n; ++r)
+      if (std::fabs(A[(size_t)r * n + c]) > std::fabs(A[(size_t)piv * n + c])) piv = r;
+    if (piv != c)
+      for (unsigned k = 0; k < n; ++k) {
+        std::swap(A[(size_t)c * n + k], A[(size_t)piv * n + k]);
+        std::swap(I[(size_t)c * n + k], I[(size_t)piv * n + k]);
+      }
+    const double inv = 1.0 / A[(size_t)c * n + c];
+    for (unsigned k = 0; k < n; ++k) { A[(size_t)c * n + k] *= inv; I[(size_t)c * n + k] *= inv; }
+    for (unsigned r = 0; r < n; ++r) {
+      if (r == c) continue;
+      const double f = A[(size_t)r * n + c];
+      if (f == 0.0) continue;
+      for (unsigned k = 0; k < n; ++k) { A[(size_t)r * n + k] -= f * A[(size_t)c * n + k]; I[(size_t)r * n + k] -= f * I[(size_t)c * n + k]; }
+    }
+  }
+  return I;
+}
+static Mat mat_mul(const Mat &A, const Mat &B, unsigned n) {
+  Mat C((size_t)n * n, 0.0);
+  for (unsigned i = 0; i < n; ++i)
+    for (unsigned k = 0; k < n; ++k) {
+      const double a = A[(size_t)i * n + k];
+      if (a != 0.0)
+        for (unsigned j = 0; j < n; ++j) C[(size_t)i * n + j] += a * B[(size_t)k * n + j];
+    }
+  return C;
+}
+
+struct GffLevelO {
+  Grid2 g;
+  int ctype, level, n_gibbs;
+  double mass, mu2, omega;
+  unsigned N;
+  std::vector<unsigned> nb, fineonly, pairs;  // neighbour table [8 N]; lattice2d.cc:82-134
+  Grid2 gc{0, 0, false};
+  Mat Qhat, Lt_inv_T;  // smoothed precision matrix; L^-1 of the Cholesky factor Q = L L^T (so that phi = L^-T psi)
+
+  GffLevelO(unsigned Mt, unsigned Mx, int ctype_, int level_, double mass_, int n_gibbs_, double omega_)
+      : g{(int)Mt, (int)Mx, ctype_ == 4 && (level_ % 2)}, ctype(ctype_), level(level_), n_gibbs(n_gibbs_), mass(mass_), omega(omega_) {
+    N = g.nvertices();
+    const double a_lat = g.rotated ? std::sqrt(2.) / Mt : 1. / Mt;  // gffaction.hh:174-181
+    mu2 = a_lat * a_lat * mass * mass;
+    nb.resize(8 * (size_t)N);
+    for (unsigned l = 0; l < N; ++l) g.neighbours(l, &nb[8 * (size_t)l]);
+    // lattice2d.cc:20-134
+    int rt = 1, rx = 1;
+    bool ok = true;
+    switch (ctype) {
+      case 0: rt = rx = 2; break;
+      case 1: rt = 2; break;
+      case 2: rx = 2; break;
+      case 3: (level % 2 == 0 ? rt : rx) = 2; break;
+      case 4: if (g.rotated) { rt = rx = 2; ok = !((Mt % 2) || (Mx % 2)); } break;
+      default: ok = false;
+    }
+    unsigned mt = Mt, mx = Mx;
+    if (rt > 1) { if (Mt % rt) ok = false; mt = Mt / rt; }
+    if (rx > 1) { if (Mx % rx) ok = false; mx = Mx / rx; }
+    if (ok && mt > 1 && mx > 1) {
+      gc = Grid2{(int)mt, (int)mx, ctype == 4 && ((level + 1) % 2)};
+      for (int i = 0; i < (int)Mt; ++i)
+        for (int j = 0; j < (int)Mx; ++j) {
+          bool coarse;
+          if (ctype == 4) {
+            if (g.rotated) { if ((i + j) % 2) continue; coarse = (i % 2 == 0) && (j % 2 == 0); }
+            else coarse = (i + j) % 2 == 0;
+          } else {
+            coarse = (i % rt == 0) && (j % rx == 0);
+          }
+          (coarse ? pairs : fineonly).push_back(g.vertex(i, j));
+          if (coarse) pairs.push_back(gc.vertex(i / rt, j / rx));
+        }
+      // the reference sorts both lists (lattice2d.cc:121-122) and its map iterates in key order
+      std::sort(fineonly.begin(), fineonly.end());
+      std::vector<std::pair<unsigned, unsigned>> pv;
+      for (size_t k = 0; k < pairs.size(); k += 2) pv.push_back({pairs[k], pairs[k + 1]});
+      std::sort(pv.begin(), pv.end());
+      for (size_t k = 0; k < pv.size(); ++k) { pairs[2 * k] = pv[k].first; pairs[2 * k + 1] = pv[k].second; }
+    }
+  }
+
+  Mat precision(const double *stencil, int shells) const {  // gffaction.cc:176-197
+    Mat Q((size_t)N * N, 0.0);
+    for (unsigned l = 0; l < N; ++l) {
+      Q[(size_t)l * N + l] += stencil[0];
+      for (int s = 0; s < shells; ++s)
+        for (int k = 0; k < 4; ++k) Q[(size_t)l * N + nb[8 * (size_t)l + 4 * s + k]] += stencil[s + 1];
+    }
+    return Q;
+  }
+  void build() {  // gffaction.cc:126-173
+    if (!Qhat.empty()) return;
+    const double st[2] = {4. + mu2, -1.};
+    const Mat Q = precision(st, 1);
+    const double h = 4. + 0.5 * mu2;
+    const double st_eff[3] = {h - 4. / h, -2. / h, -1. / h};
+    const Mat Qeff = precision(st_eff, 2);
+    const Mat Sigma = mat_inverse(Q, N), Sigma_eff = mat_inverse(Qeff, N);
+    Mat M((size_t)N * N, 0.0);
+    for (unsigned i = 0; i < N; ++i)
+      for (unsigned j = 0; j <= i; ++j) M[(size_t)i * N + j] = Qeff[(size_t)i * N + j];
+    if (std::fabs(omega - 1.0) > 1e-14)
+      for (unsigned i = 0; i < N; ++i) M[(size_t)i * N + i] += (1. / omega - 1.) * Qeff[(size_t)i * N + i];
+    Mat G((size_t)N * N, 0.0);
+    for (unsigned i = 0; i < N; ++i) G[(size_t)i * N + i] = 1.0;
+    if (n_gibbs > 0) {
+      Mat Gt = mat_mul(mat_inverse(M, N), Qeff, N);
+      for (double &v : Gt) v = -v;
+      for (unsigned i = 0; i < N; ++i) Gt[(size_t)i * N + i] += 1.0;
+      for (int k = 0; k < n_gibbs; ++k) G = mat_mul(G, Gt, N);
+    }
+    Mat D(Sigma);
+    for (size_t k = 0; k < D.size(); ++k) D[k] -= Sigma_eff[k];
+    Mat GT((size_t)N * N);
+    for (unsigned i = 0; i < N; ++i)
+      for (unsigned j = 0; j < N; ++j) GT[(size_t)j * N + i] = G[(size_t)i * N + j];
+    Mat S = mat_mul(mat_mul(G, D, N), GT, N);
+    for (size_t k = 0; k < S.size(); ++k) S[k] += Sigma_eff[k];
+    Qhat = mat_inverse(S, N);
+    // Cholesky factor of Q (textbook recursion), then its inverse
+    Mat L((size_t)N * N, 0.0);
+    for (unsigned j = 0; j < N; ++j) {
+      double d = Q[(size_t)j * N + j];
+      for (unsigned k = 0; k < j; ++k) d -= L[(size_t)j * N + k] * L[(size_t)j * N + k];
+      L[(size_t)j * N + j] = std::sqrt(d);
+      for (unsigned i = j + 1; i < N; ++i) {
+        double v = Q[(size_t)i * N + j];
+        for (unsigned k = 0; k < j; ++k) v -= L[(size_t)i * N + k] * L[(size_t)j * N + k];
+        L[(size_t)i * N + j] = v / L[(size_t)j * N + j];
+      }
+    }
+    Lt_inv_T = mat_inverse(L, N);
+  }
+  double evaluate(const double *phi) {  // gffaction.cc:8-30
+    double S = 0.0;
+    if (n_gibbs == 0) {
+      for (unsigned l = 0; l < N; ++l) {
+        double loc = (4. + mu2) * phi[l];
+        for (int k = 0; k < 4; ++k) loc -= phi[nb[8 * (size_t)l + k]];
+        S += phi[l] * loc;
+      }
+    } else {
+      build();
+      for (unsigned i = 0; i < N; ++i) {
+        double y = 0.0;
+        for (unsigned j = 0; j < N; ++j) y += Qhat[(size_t)i * N + j] * phi[j];
+        S += phi[i] * y;
+      }
+    }
+    return 0.5 * S;
+  }
+  // gffaction.cc:200-213 with the device's random numbers
+  void dev_draw(double *phi, const DevRng &rng) {
+    build();
+    std::vector<double> psi(N);
+    auto normals = [&](Purpose p, uint32_t sub, std::vector<double> &out) {
+      for (unsigned q = 0; 2 * q < N; ++q) {
+        double n0, n1;
+        rng.normals(q, p, sub, n0, n1);
+        out[2 * q] = n0;
+        if (2 * q + 1 < N) out[2 * q + 1] = n1;
+      }
+    };
+    normals((Purpose)P_GFF_EXACT, 0, psi);
+    for (unsigned i = 0; i < N; ++i) {  // solve L^T phi = psi
+      double y = 0.0;
+      for (unsigned j = i; j < N; ++j) y += Lt_inv_T[(size_t)j * N + i] * psi[j];
+      phi[i] = y;
+    }
+    const double h = 4. + 0.5 * mu2, d0 = h - 4. / h;
+    const double sigma_eff = 1. / std::sqrt(d0), kappa = omega / h, gamma = std::sqrt(omega * (2. - omega));
+    for (int k = 0; k < n_gibbs; ++k) {  // gffaction.cc:45-66
+      normals((Purpose)P_GFF_GIBBS, (uint32_t)k, psi);
+      for (unsigned l = 0; l < N; ++l) {
+        double Delta = (1. - omega) * d0 * phi[l];
+        for (int m = 0; m < 4; ++m) Delta += 2. * kappa * phi[nb[8 * (size_t)l + m]];
+        for (int m = 4; m < 8; ++m) Delta += kappa * phi[nb[8 * (size_t)l + m]];
+        phi[l] = sigma_eff * (gamma * psi[l] + sigma_eff * Delta);
+      }
+    }
+  }
+  // gffconditionedfineaction.cc:7-49
+  double cfa(double *phi, bool fill, const DevRng *rng) const {
+    const double sigma2 = 1. / (4. + mu2), sigma = std::sqrt(sigma2), sigma2_inv = 1. / sigma2;
+    double S = 0.0;
+    for (unsigned l : fineonly) {
+      double Delta = 0.0;
+      for (int k = 0; k < 4; ++k) Delta += phi[nb[8 * (size_t)l + k]];
+      if (fill) {
+        double n0, n1;
+        rng->normals(l, P_FILLIN, 0, n0, n1);
+        phi[l] = sigma * (n0 + sigma * Delta);
+      }
+      const double dphi = phi[l] - sigma2 * Delta;
+      S += 0.5 * sigma2_inv * dphi * dphi;
+    }
+    return S;
+  }
+};
+
 extern "C" {
 
 void orc_philox4x32_10(const uint32_t *ctr, const uint32_t *key, uint32_t *out) {
@@ -1563,6 +1781,66 @@ void orc_gff_transfer(int Mt, int Mx, int rt, int rx, double *fine, double *coar
       if (to_coarse) coarse[gc.vertex(i, j)] = fine[gf.vertex(rt * i, rx * j)];
       else fine[gf.vertex(rt * i, rx * j)] = coarse[gc.vertex(i, j)];
     }
+}
+
+// ---- GFF levels -------------------------------------------------------------------------------------------
+void *orc_gff_level_new(unsigned Mt, unsigned Mx, int ctype, int level, double mass, int n_gibbs, double omega) {
+  return new GffLevelO(Mt, Mx, ctype, level, mass, n_gibbs, omega);
+}
+void orc_gff_level_free(void *h) { delete (GffLevelO *)h; }
+unsigned orc_gff_level_size(void *h) { return ((GffLevelO *)h)->N; }
+unsigned orc_gff_level_n_coarse(void *h) { return (unsigned)((GffLevelO *)h)->pairs.size() / 2; }
+double orc_gff_level_mu2(void *h) { return ((GffLevelO *)h)->mu2; }
+void orc_gff_level_tables(void *h, unsigned *pairs, unsigned *fineonly) {
+  GffLevelO *L = (GffLevelO *)h;
+  std::copy(L->pairs.begin(), L->pairs.end(), pairs);
+  std::copy(L->fineonly.begin(), L->fineonly.end(), fineonly);
+}
+void orc_gff_level_matrix(void *h, int which, double *out) {
+  GffLevelO *L = (GffLevelO *)h;
+  L->build();
+  const Mat &M = which == 0 ? L->Qhat : L->Lt_inv_T;
+  std::copy(M.begin(), M.end(), out);
+}
+double orc_gff_level_evaluate(void *h, const double *phi) { return ((GffLevelO *)h)->evaluate(phi); }
+void orc_gff_level_dev_draw(void *h, double *phi, uint64_t seed, uint32_t chain, uint32_t step) {
+  DevRng rng{(uint32_t)seed, (uint32_t)(seed >> 32), chain, step};
+  ((GffLevelO *)h)->dev_draw(phi, rng);
+}
+double orc_gff_cfa_evaluate(void *h, const double *phi) { return ((GffLevelO *)h)->cfa(const_cast<double *>(phi), false, nullptr); }
+double orc_gff_cfa_dev_fill(void *h, double *phi, uint64_t seed, uint32_t chain, uint32_t step) {
+  DevRng rng{(uint32_t)seed, (uint32_t)(seed >> 32), chain, step};
+  return ((GffLevelO *)h)->cfa(phi, true, &rng);
+}
+void orc_gff_copy(void *fine_h, double *fine, double *coarse, int to_coarse) {  // gffaction.cc:97-118
+  GffLevelO *F = (GffLevelO *)fine_h;
+  for (size_t k = 0; k < F->pairs.size(); k += 2) {
+    if (to_coarse) coarse[F->pairs[k + 1]] = fine[F->pairs[k]]; else fine[F->pairs[k]] = coarse[F->pairs[k + 1]];
+  }
+}
+// twolevelmetropolisstep.cc:35-89 in device order; theta updated in place on acceptance; terms = (dS_fine, dS_coarse, dS_trial)
+int orc_gff_dev_twolevel_draw(void *fine_h, void *coarse_h, const double *phi_coarse, double *theta, uint64_t seed, uint32_t chain,
+                              uint32_t step, double *terms) {
+  GffLevelO *F = (GffLevelO *)fine_h, *Cc = (GffLevelO *)coarse_h;
+  DevRng rng{(uint32_t)seed, (uint32_t)(seed >> 32), chain, step};
+  std::vector<double> prime(F->N, 0.0), theta_C(Cc->N, 0.0);
+  orc_gff_copy(F, prime.data(), const_cast<double *>(phi_coarse), 0);
+  const double cfa_prime = F->cfa(prime.data(), true, &rng);
+  const double cfa_theta = F->cfa(theta, false, nullptr);
+  const double dS_fine = F->evaluate(prime.data()) - F->evaluate(theta);
+  orc_gff_copy(F, theta, theta_C.data(), 1);
+  const double dS_coarse = Cc->evaluate(theta_C.data()) - Cc->evaluate(phi_coarse);
+  const double dS_trial = cfa_theta - cfa_prime;
+  if (terms) { terms[0] = dS_fine; terms[1] = dS_coarse; terms[2] = dS_trial; }
+  const double dS = dS_fine + dS_coarse + dS_trial;
+  bool accept = dS < 0.0;
+  if (!accept) {
+    double u, v;
+    rng.uniforms(0, P_ACCEPT2, 0, u, v);
+    accept = u < std::exp(-dS);
+  }
+  if (accept) std::copy(prime.begin(), prime.end(), theta);
+  return accept ? 1 : 0;
 }
 
 // ---- statistics ------------------------------------------------------------------------------------

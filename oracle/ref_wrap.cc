@@ -38,6 +38,18 @@ void ref_lattice2d_neighbours(void *h, unsigned *out) {  // nvertices x 8
     for (size_t k = 0; k < nb[l].size(); ++k) out[8 * l + k] = nb[l][k];
 }
 
+// lattice2d.cc:82-134: the vertex lists that drive the 2-D multilevel glue
+unsigned ref_lattice2d_n_fineonly(void *h) { return (unsigned)L2(h).get_fineonly_vertices().size(); }
+void ref_lattice2d_fineonly(void *h, unsigned *out) {
+  const auto &v = L2(h).get_fineonly_vertices();
+  for (size_t k = 0; k < v.size(); ++k) out[k] = v[k];
+}
+unsigned ref_lattice2d_n_coarse(void *h) { return (unsigned)L2(h).get_fine2coarse_map().size(); }
+void ref_lattice2d_fine2coarse(void *h, unsigned *out) {  // (fine, coarse) pairs in key order
+  size_t k = 0;
+  for (const auto &p : L2(h).get_fine2coarse_map()) { out[k++] = p.first; out[k++] = p.second; }
+}
+
 void ref_lattice1d_neighbours(unsigned M, double T_final, unsigned *out, double *a_lat) {  // M x 2
   Lattice1D lat(M, T_final);
   const auto &nb = lat.get_neighbour_vertices();

@@ -6,9 +6,12 @@ import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _tag():
+    return open(os.path.join(ROOT, "profiles", "FINAL")).read().strip()   # tag of the round's final build, e.g. "r02"
+
+
 def _latest_default_line():
-    tag = open(os.path.join(ROOT, "profiles", "FINAL")).read().strip()   # tag of the final build of the round
-    return json.load(open(os.path.join(ROOT, "profiles", f"r01_{tag}_bench.json")))
+    return json.load(open(os.path.join(ROOT, "profiles", f"{_tag()}_bench.json")))
 
 
 def test_bench_line_has_the_contract_fields():
@@ -24,6 +27,17 @@ def test_bench_line_has_the_contract_fields():
         assert key in roof, key
     assert roof["bound"] in ("hbm", "mfma") and roof["unit"] in ("GB/s", "TFLOP/s")
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
+    assert 0.0 < roof["frac"] <= 1.0, "a roofline fraction above 1 says the byte model is not a bound"
+    # the roofline names the kernel with the largest share of the step, and says what binds it
+    shares = {k["kernel"]: k["share_of_step"] for k in r["kernels"] if "sweep" in k["role"]}
+    assert roof["kernel"].startswith(max(shares, key=shares.get))
+    for k in r["kernels"]:
+        assert 0.0 < k["hbm_frac"] <= 1.0 and (k.get("valu_frac") is None or k["valu_frac"] <= 1.0)
+        if k["traffic"] is not None:
+            assert k["traffic"] >= 0.95 * k["hbm_floor_bytes_per_launch"]   # measured HBM bytes cannot undercut the floor
+    assert set(r["step_includes"]) == {"sampler->draw", "qoi->evaluate", "stats->record_sample"}
+    assert r["single_chain"]["chains_per_gpu"] == 1 and r["chains_128"]["chains_per_gpu"] == 128
+    assert 0.0 < r["whole_step"]["hbm_floor_frac"] <= 1.0
     cpu = r["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in cpu, key
@@ -37,3 +51,31 @@ def test_bench_source_keeps_the_oracle_out_of_the_timed_path():
     # the oracle is only reached through the cpu_baseline subprocess
     assert "import oracle" not in src and "from oracle" not in src
     assert "cpu_baseline.py" in src
+
+
+def test_secondary_workloads_report_fractions_of_real_bounds():
+    """BASELINE configs 2, 3, 5 and the other workloads: committed lines of the final build; no fraction above 1, the
+    register-resident HMC kernels carry a vector-issue fraction from the SQ counters of the same kernel build."""
+    for w in ("gff", "rotor_hmc", "quartic_hmc", "ho_hmc", "quartic_mlmc", "rotor_sweep"):
+        r = json.load(open(os.path.join(ROOT, "profiles", f"{_tag()}_bench_{w}.json")))
+        assert 0.0 < r["roofline"]["frac"] <= 1.0, w
+        assert r["roofline"].get("valu_frac") is None or 0.0 < r["roofline"]["valu_frac"] <= 1.0, w
+        if w.endswith("hmc") or w == "quartic_mlmc":
+            assert r["roofline"]["limited_by"] == "valu" and r["roofline"]["valu_frac"] is not None, w
+
+
+def test_traffic_json_is_tied_to_a_kernel_build():
+    t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    builds = {e["build"] for sec in ("entries", "valu", "kernels_valu_busy") for e in t[sec]}
+    assert len(builds) == 1 and None not in builds
+    assert builds == {_latest_default_line()["kernel_build"]}
+
+
+def test_bench_refuses_a_rank_count_it_did_not_run():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "spawn_ranks" in src and "sys.exit(2)" in src
+    import subprocess, sys
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-cpu-baseline"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and "started 3 rank" in r.stderr
