@@ -24,6 +24,8 @@ public:
   virtual ~ConditionedFineAction() {}
   /** the fine-level action whose fine-only points this object fills in */
   virtual std::shared_ptr<Action> fine_action() const = 0;
+  /** selector of mlmcpi_lattice_twolevel_draw_cfa: 0 = the class the reference's factory picks for the lattice */
+  virtual int cfa_kind() const { return 0; }
 };
 
 /** Gaussian fill-in x_{2j+1} ~ N(Wminimum(x_2j, x_2j+2), 1/Wcurvature): harmonic and quartic oscillator.
@@ -95,6 +97,31 @@ public:
 
 private:
   const std::shared_ptr<QuenchedSchwingerAction> action;
+};
+
+/** quenchedschwingerconditionedfineaction.hh:98-131 (QuenchedSchwingerGaussianConditionedFineAction): the Gaussian variant
+ *  of the fill-in for lattices coarsened in both directions (GaussianFillinDistribution); the reference's factory never
+ *  selects it, a caller can (QuenchedSchwingerGaussianConditionedFineActionFactory).  Runs inside
+ *  mlmcpi_lattice_twolevel_draw_cfa(cfa_kind = 1). */
+class QuenchedSchwingerGaussianConditionedFineAction : public ConditionedFineAction {
+public:
+  explicit QuenchedSchwingerGaussianConditionedFineAction(const std::shared_ptr<QuenchedSchwingerAction> action_) : action(action_) {
+    if (action->get_lattice()->get_coarsening_type() != CoarsenBoth) fatal("Gaussian conditioned fine action needs CoarsenBoth");
+  }
+  std::shared_ptr<Action> fine_action() const override { return action; }
+  int cfa_kind() const override { return 1; }
+
+private:
+  const std::shared_ptr<QuenchedSchwingerAction> action;
+};
+
+class QuenchedSchwingerGaussianConditionedFineActionFactory : public ConditionedFineActionFactory {
+public:
+  std::shared_ptr<ConditionedFineAction> get(std::shared_ptr<Action> action) override {
+    auto schwinger = std::dynamic_pointer_cast<QuenchedSchwingerAction>(action);
+    if (!schwinger) fatal("Schwinger conditioned fine action needs a QuenchedSchwingerAction");
+    return std::make_shared<QuenchedSchwingerGaussianConditionedFineAction>(schwinger);
+  }
 };
 
 /** quenchedschwingerconditionedfineaction.hh:218-238: the fill-in follows the coarsening type of the lattice */
@@ -181,9 +208,9 @@ public:
                                       theta_fine->device_mutable(), B, level_seed(), fine->get_chain0(), step++, work,
                                       (int32_t *)accept_flags.ptr(), nullptr, nullptr), "path_twolevel_draw");
     else
-      check(mlmcpi_lattice_twolevel_draw(&qft_fine->abi_action(), &qft_coarse->abi_action(), phi_coarse_state->device(),
-                                         theta_fine->device_mutable(), B, level_seed(), fine->get_chain0(), step++, work,
-                                         (int32_t *)accept_flags.ptr(), nullptr, nullptr), "lattice_twolevel_draw");
+      check(mlmcpi_lattice_twolevel_draw_cfa(&qft_fine->abi_action(), &qft_coarse->abi_action(), cfa->cfa_kind(), phi_coarse_state->device(),
+                                             theta_fine->device_mutable(), B, level_seed(), fine->get_chain0(), step++, work,
+                                             (int32_t *)accept_flags.ptr(), nullptr, nullptr), "lattice_twolevel_draw");
     std::vector<int32_t> flags = accept_flags.download<int32_t>();
     double acc = 0;
     for (int32_t f : flags) acc += f;

@@ -238,6 +238,14 @@ int mlmcpi_lattice_twolevel_draw(const mlmcpi_lattice_action *fine, const mlmcpi
                                  const double *d_phi_coarse, double *d_theta, uint32_t B, uint64_t seed,
                                  uint32_t chain0, uint32_t step, void *d_work, int32_t *d_accept, double *d_terms,
                                  void *stream);
+/* The same step with the conditioned fine action chosen by the caller: cfa_kind 0 = what the reference's factory picks
+ * for the lattice (quenchedschwingerconditionedfineaction.hh:218-238), 1 = QuenchedSchwingerGaussianConditionedFineAction
+ * (quenchedschwingerconditionedfineaction.cc:81-134, 293-327; lattices coarsened in both directions): uniform splits of
+ * the coarse links, the four interior links of every 2 x 2 block from GaussianFillinDistribution
+ * (distribution/gaussianfillindistribution.{hh,cc}; Philox purpose 13 of the coarse cell). */
+int mlmcpi_lattice_twolevel_draw_cfa(const mlmcpi_lattice_action *fine, const mlmcpi_lattice_action *coarse, int32_t cfa_kind,
+                                     const double *d_phi_coarse, double *d_theta, uint32_t B, uint64_t seed, uint32_t chain0,
+                                     uint32_t step, void *d_work, int32_t *d_accept, double *d_terms, void *stream);
 /* Exact sampler of the Gaussian free field: GFFAction::draw / initialise_state (action/qft/gffaction.cc:121-123,
  * 200-213; the reference goes through a sparse Cholesky factor built by Eigen, which it cannot build beyond ~64^2).
  * On the periodic lattice the precision matrix is diagonal in Fourier space, so the draw is a spectral synthesis:

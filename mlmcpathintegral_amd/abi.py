@@ -73,6 +73,7 @@ SIGNATURES = {
     "mlmcpi_lattice_copy_from_coarse": (_i, [_LA, _u32, _u32, _vp, _vp, _u32, _vp]),
     "mlmcpi_lattice_twolevel_workspace_bytes": (_i, [_LA, _LA, _u32, C.POINTER(_sz)]),
     "mlmcpi_lattice_twolevel_draw": (_i, [_LA, _LA, _vp, _vp, _u32, _u64, _u32, _u32, _vp, _vp, _vp, _vp]),
+    "mlmcpi_lattice_twolevel_draw_cfa": (_i, [_LA, _LA, C.c_int32, _vp, _vp, _u32, _u64, _u32, _u32, _vp, _vp, _vp, _vp]),
     "mlmcpi_lattice_exact_workspace_bytes": (_i, [_LA, _u32, C.POINTER(_sz)]),
     "mlmcpi_lattice_exact_draw": (_i, [_LA, _vp, _u32, _u64, _u32, _u32, _vp, _vp]),
     "mlmcpi_lattice_state_size": (_i, [_LA, C.POINTER(_u32)]),

@@ -194,6 +194,7 @@ enum Purpose : uint32_t {
   P_ACCEPT2 = 8,  // two-level step: Metropolis uniform
   P_BESSEL = 9,   // two-level step, Schwinger coarsened in both directions: Bessel-product fill-in, sub = call counter
   P_EXACT = 10,   // exact Gaussian sampler of the harmonic oscillator: normals of entries (2 m, 2 m + 1) from site m
+  P_GAUSSFILL = 13,  // two-level step, Schwinger coarsened in both directions, Gaussian fill-in: sub 0 (xi, omega), 1, 2 normals
 };
 
 struct RngKey {
@@ -636,6 +637,103 @@ __device__ __forceinline__ double approx_bessel_pdf(double beta, double x, doubl
     sm += sqrt(s2m) * exp(-0.5 * s2m * zs * zs);
   }
   return sqrt(0.5 / kPi) * (N_p * sp + N_m * sm);
+}
+
+// ---- GaussianFillinDistribution (distribution/gaussianfillindistribution.{hh,cc}): the four interior links of a 2 x 2
+// block given the four perimeter sums phi_12 .. phi_41, as a two-peak Gaussian mixture in three non-trivial directions
+// (eta_1, eta_2, eta_3) plus a uniform common shift omega.  Used by QuenchedSchwingerGaussianConditionedFineAction.
+__device__ __forceinline__ double gaussfill_pc(double beta, double Phi) {  // gaussianfillindistribution.hh get_pc
+  if (Phi < 0.125 * kPi) return 1.0;
+  if (Phi > 0.375 * kPi) return 0.0;
+  const double sp = beta * cos(Phi), sm = beta * sin(Phi);
+  const double rho = pow(sp / sm, 1.5) * exp(-4.0 * (sp - sm));
+  return 1. / (1. + rho);
+}
+
+// gaussianfillindistribution.hh draw (add_gaussian_noise = true): calls of `site` with purpose P_GAUSSFILL: 0 -> (xi, omega / 2 pi),
+// 1 -> normals of eta_1, eta_2, 2 -> normal of eta_3
+__device__ __forceinline__ void gaussfill_draw(const RngKey &k, uint32_t site, double beta, double phi_12, double phi_23,
+                                               double phi_34, double phi_41, double (&theta)[4]) {
+  const double Phi = 0.25 * (phi_12 + phi_23 + phi_34 + phi_41);
+  double Phi_star = Phi;
+  bool swap_eta = false, shift_eta = false;
+  if (Phi_star < 0) { Phi_star = -Phi_star; swap_eta = true; }
+  if (Phi_star > 0.5 * kPi) { Phi_star = kPi - Phi_star; swap_eta = !swap_eta; shift_eta = true; }
+  const double p_c = gaussfill_pc(beta, Phi_star);
+  double xi, om, n1, n2, n3, unused;
+  rng_uniforms(k, site, P_GAUSSFILL, 0, xi, om);
+  rng_normals(k, site, P_GAUSSFILL, 1, n1, n2);
+  rng_normals(k, site, P_GAUSSFILL, 2, n3, unused);
+  double eta_1, eta_2, eta_3, sigma;
+  if (xi < p_c) {
+    eta_1 = 0.0; eta_2 = 0.0; eta_3 = 0.0;
+    sigma = 1. / sqrt(4. * beta * cos(Phi_star));
+  } else {
+    eta_1 = kPi; eta_2 = 0.0; eta_3 = 0.5 * kPi;
+    sigma = 1. / sqrt(4. * beta * sin(Phi_star));
+  }
+  const double sqrt2 = 1.41421356237309504880;
+  eta_1 += sqrt2 * sigma * n1;
+  eta_2 += sqrt2 * sigma * n2;
+  eta_3 += sigma * n3;
+  if (swap_eta) { const double t = eta_1; eta_1 = eta_2; eta_2 = t; }
+  if (shift_eta) { eta_1 += kPi; eta_2 += kPi; }
+  const double omega = 2. * kPi * om;
+  theta[0] = mod_2pi(0.5 * (+eta_1 + eta_2 + eta_3) + omega);
+  theta[1] = mod_2pi(0.5 * (+eta_1 - eta_2 - eta_3) + omega + Phi - phi_12);
+  theta[2] = mod_2pi(0.5 * (-eta_1 - eta_2 + eta_3) + omega + 2. * Phi - phi_12 - phi_23);
+  theta[3] = mod_2pi(0.5 * (-eta_1 + eta_2 - eta_3) + omega + 3. * Phi - phi_12 - phi_23 - phi_34);
+}
+
+// gaussianfillindistribution.cc:7-67 (add_gaussian_noise = true).  The peak lattices of construct_peaks (:70-118), in
+// units of pi/2: main peaks = {0 (mod 4)}^3 and {2 (mod 4)}^3, secondary peaks = (2 mod 4, 0 mod 4, 1 mod 4) and
+// (0 mod 4, 2 mod 4, 3 mod 4), each coordinate within one period of the base cell (n_offsets = 1; 0 for beta > 72, which
+// keeps only the base cell's 9 + 4 peaks).
+__device__ __forceinline__ double gaussfill_pdf(double beta, double theta_1, double theta_2, double theta_3, double theta_4,
+                                                double phi_12, double phi_23, double phi_34, double phi_41) {
+  double eta_1 = mod_2pi(0.5 * (theta_1 + theta_2 - theta_3 - theta_4) + 0.5 * (phi_41 - phi_23));
+  double eta_2 = mod_2pi(0.5 * (theta_1 - theta_2 - theta_3 + theta_4) + 0.5 * (phi_34 - phi_12));
+  const double eta_3 = mod_2pi(0.5 * (theta_1 - theta_2 + theta_3 - theta_4) + 0.25 * (-phi_12 + phi_23 - phi_34 + phi_41));
+  double Phi_star = 0.25 * (phi_12 + phi_23 + phi_34 + phi_41);
+  bool swap_eta = false;
+  if (Phi_star < 0.) { Phi_star = -Phi_star; swap_eta = true; }
+  if (Phi_star > 0.5 * kPi) {
+    Phi_star = kPi - Phi_star;
+    swap_eta = !swap_eta;
+    eta_1 = mod_2pi(eta_1 + kPi);
+    eta_2 = mod_2pi(eta_2 + kPi);
+  }
+  if (swap_eta) { const double t = eta_1; eta_1 = eta_2; eta_2 = t; }
+  const double p_c = gaussfill_pc(beta, Phi_star);
+  const double s2c = 2. * beta * cos(Phi_star), s2s = 2. * beta * sin(Phi_star);
+  const bool wide = !(beta > 72.0);  // n_offsets = 1
+  const double h = 0.5 * kPi;
+  auto gauss = [&](double s2, int px, int py, int pz) {
+    const double d1 = eta_1 - h * px, d2 = eta_2 - h * py, d3 = eta_3 - h * pz;
+    return exp(-0.5 * s2 * (d1 * d1 + d2 * d2 + 2. * d3 * d3));
+  };
+  double g_c = 0.0, g_s = 0.0;
+  if (wide) {
+    for (int a = -4; a <= 4; a += 4)
+      for (int b = -4; b <= 4; b += 4)
+        for (int c = -4; c <= 4; c += 4) g_c += gauss(s2c, a, b, c);
+    for (int a = -6; a <= 6; a += 4)
+      for (int b = -6; b <= 6; b += 4)
+        for (int c = -6; c <= 6; c += 4) g_c += gauss(s2c, a, b, c);
+    for (int a = -6; a <= 6; a += 4)
+      for (int b = -4; b <= 4; b += 4)
+        for (int c = -3; c <= 5; c += 4) g_s += gauss(s2s, a, b, c);
+    for (int a = -4; a <= 4; a += 4)
+      for (int b = -6; b <= 6; b += 4)
+        for (int c = -5; c <= 3; c += 4) g_s += gauss(s2s, a, b, c);
+  } else {
+    g_c += gauss(s2c, 0, 0, 0);
+    for (int a = -2; a <= 2; a += 4)
+      for (int b = -2; b <= 2; b += 4)
+        for (int c = -2; c <= 2; c += 4) g_c += gauss(s2c, a, b, c);
+    g_s = gauss(s2s, 2, 0, 1) + gauss(s2s, -2, 0, 1) + gauss(s2s, 0, 2, -1) + gauss(s2s, 0, -2, -1);
+  }
+  return p_c * pow(s2c, 1.5) * g_c + (1. - p_c) * pow(s2s, 1.5) * g_s;
 }
 
 // ---- LDS reads that stay ds_read_b64 ---------------------------------------------------------------------

@@ -1860,6 +1860,69 @@ __global__ void __launch_bounds__(256)
   if (threadIdx.x == 0) partial[((size_t)b * gridDim.x + blockIdx.x) * 2 + slot] = acc[0];
 }
 
+// QuenchedSchwingerGaussianConditionedFineAction (quenchedschwingerconditionedfineaction.cc:81-134, 293-327): the Gaussian
+// variant of the fill-in for lattices coarsened in both directions.  One thread per coarse cell = one 2 x 2 block of fine
+// vertices: the perimeter links come from the uniform splits of the coarse links (this cell's and, for the far sides, the
+// cells (i+1, j) and (i, j+1), recomputed from their Philox streams as in schwinger_both_fill_kernel); the four interior
+// links from GaussianFillinDistribution::draw.
+__global__ void __launch_bounds__(256)
+    schwinger_gauss_fill_kernel(uint32_t Mtc, uint32_t Mxc, double beta, const double2 *__restrict__ coarse_all,
+                                double2 *__restrict__ prime_all, RngKey key0) {
+  const uint32_t b = blockIdx.y, Mtf = 2 * Mtc;
+  const double2 *coarse = coarse_all + (size_t)b * Mtc * Mxc;
+  double2 *prime = prime_all + (size_t)b * 4 * Mtc * Mxc;
+  RngKey key = key0;
+  key.chain += b;
+  for (uint32_t j = blockIdx.x; j < Mxc; j += gridDim.x) {
+    const uint32_t jp = j + 1 == Mxc ? 0 : j + 1;
+    for (uint32_t i = threadIdx.x; i < Mtc; i += blockDim.x) {
+      const uint32_t ip = i + 1 == Mtc ? 0 : i + 1;
+      const uint32_t c = j * Mtc + i, c_t = j * Mtc + ip, c_x = jp * Mtc + i;
+      double t[2], x[2], tt[2], tx[2], xt[2], xx[2];
+      split_pair(key, c, coarse[c], t, x);
+      split_pair(key, c_t, coarse[c_t], tt, tx);
+      split_pair(key, c_x, coarse[c_x], xt, xx);
+      const double phi_12 = mod_2pi(+x[1] + xt[0]);    // th(2i, 2j+1, 1) + th(2i, 2j+2, 0)
+      const double phi_23 = mod_2pi(+xt[1] - tx[1]);   // th(2i+1, 2j+2, 0) - th(2i+2, 2j+1, 1)
+      const double phi_34 = mod_2pi(-tx[0] - t[1]);    // -th(2i+2, 2j, 1) - th(2i+1, 2j, 0)
+      const double phi_41 = mod_2pi(-t[0] + x[0]);     // -th(2i, 2j, 0) + th(2i, 2j, 1)
+      double th[4];
+      gaussfill_draw(key, c, beta, phi_12, phi_23, phi_34, phi_41, th);
+      const size_t v00 = (size_t)(2 * j) * Mtf + 2 * i, v01 = v00 + Mtf;
+      prime[v00] = make_double2(t[0], x[0]);
+      prime[v00 + 1] = make_double2(t[1], +th[3]);     // (2i+1, 2j): temporal half, interior spatial link theta_4
+      prime[v01] = make_double2(+th[0], x[1]);         // (2i, 2j+1): interior temporal link theta_1, spatial half
+      prime[v01 + 1] = make_double2(-th[2], -th[1]);   // (2i+1, 2j+1): -theta_3, -theta_2
+    }
+  }
+}
+
+// partial[(b * gridDim.x + blockIdx.x) * 2 + slot] = -sum log pdf over the 2 x 2 blocks of `state`
+__global__ void __launch_bounds__(256)
+    schwinger_gauss_cfa_kernel(uint32_t Mt, uint32_t Mx, double beta, const double2 *__restrict__ state_all, double *__restrict__ partial,
+                               uint32_t slot) {
+  __shared__ double red[4];
+  const uint32_t b = blockIdx.y;
+  const double *th = (const double *)(state_all + (size_t)b * Mt * Mx);
+  auto link = [&](uint32_t ii, uint32_t jj, uint32_t mu) { return th[2 * ((size_t)jj * Mt + ii) + mu]; };
+  double acc[1] = {0.0};
+  for (uint32_t jc = blockIdx.x; jc < Mx / 2; jc += gridDim.x) {
+    const uint32_t j0 = 2 * jc, j1 = j0 + 1, j2 = (j0 + 2 == Mx) ? 0 : j0 + 2;
+    for (uint32_t ic = threadIdx.x; ic < Mt / 2; ic += blockDim.x) {
+      const uint32_t i0 = 2 * ic, i1 = i0 + 1, i2 = (i0 + 2 == Mt) ? 0 : i0 + 2;
+      const double phi_12 = mod_2pi(+link(i0, j1, 1) + link(i0, j2, 0));
+      const double phi_23 = mod_2pi(+link(i1, j2, 0) - link(i2, j1, 1));
+      const double phi_34 = mod_2pi(-link(i2, j0, 1) - link(i1, j0, 0));
+      const double phi_41 = mod_2pi(-link(i0, j0, 0) + link(i0, j0, 1));
+      const double theta_1 = mod_2pi(+link(i0, j1, 0)), theta_2 = mod_2pi(-link(i1, j1, 1)), theta_3 = mod_2pi(-link(i1, j1, 0)),
+                   theta_4 = mod_2pi(+link(i1, j0, 1));
+      acc[0] -= log(gaussfill_pdf(beta, theta_1, theta_2, theta_3, theta_4, phi_12, phi_23, phi_34, phi_41));
+    }
+  }
+  block_sum<1>(acc, red);
+  if (threadIdx.x == 0) partial[((size_t)b * gridDim.x + blockIdx.x) * 2 + slot] = acc[0];
+}
+
 // en4 = [4][B]: S_f(theta'), S_f(theta), S_c(theta_C), S_c(phi_c); twolevelmetropolisstep.cc:46-84
 __global__ void __launch_bounds__(256)
     lattice_twolevel_accept_kernel(uint32_t n, double *__restrict__ theta, const double *__restrict__ theta_prime,
@@ -1961,9 +2024,18 @@ int mlmcpi_lattice_twolevel_workspace_bytes(const mlmcpi_lattice_action *fine, c
 int mlmcpi_lattice_twolevel_draw(const mlmcpi_lattice_action *fine, const mlmcpi_lattice_action *coarse,
                                  const double *d_phi_coarse, double *d_theta, uint32_t B, uint64_t seed, uint32_t chain0,
                                  uint32_t step, void *d_work, int32_t *d_accept, double *d_terms, void *stream) {
+  return mlmcpi_lattice_twolevel_draw_cfa(fine, coarse, 0, d_phi_coarse, d_theta, B, seed, chain0, step, d_work, d_accept, d_terms,
+                                          stream);
+}
+
+int mlmcpi_lattice_twolevel_draw_cfa(const mlmcpi_lattice_action *fine, const mlmcpi_lattice_action *coarse, int32_t cfa_kind,
+                                     const double *d_phi_coarse, double *d_theta, uint32_t B, uint64_t seed, uint32_t chain0,
+                                     uint32_t step, void *d_work, int32_t *d_accept, double *d_terms, void *stream) {
   uint32_t rt, rx;
   if (int rc = check_twolevel(fine, coarse, &rt, &rx)) return rc;
   MLMCPI_REQUIRE(d_phi_coarse && d_theta && d_work && d_accept && B > 0, "bad arguments");
+  MLMCPI_REQUIRE(cfa_kind == 0 || cfa_kind == 1, "unknown conditioned fine action %d", cfa_kind);
+  MLMCPI_REQUIRE(cfa_kind == 0 || rt * rx == 4, "the Gaussian conditioned fine action needs a lattice coarsened in both directions");
   hipStream_t st = as_stream(stream);
   const size_t nf = (size_t)2 * fine->Mt * fine->Mx, nc = (size_t)2 * coarse->Mt * coarse->Mx;
   char *w = (char *)d_work;
@@ -1976,7 +2048,15 @@ int mlmcpi_lattice_twolevel_draw(const mlmcpi_lattice_action *fine, const mlmcpi
   double *cfa = (double *)w;
   const RngKey key = make_key(seed, chain0, step);
   const uint32_t nblk = row_blocks(coarse->Mx, B);
-  if (rt * rx == 4) {
+  if (rt * rx == 4 && cfa_kind == 1) {  // QuenchedSchwingerGaussianConditionedFineAction
+    const dim3 grid(nblk, B), block(256);
+    hipLaunchKernelGGL(schwinger_gauss_fill_kernel, grid, block, 0, st, coarse->Mt, coarse->Mx, fine->beta, (const double2 *)d_phi_coarse,
+                       (double2 *)theta_prime, key);
+    MLMCPI_LAUNCH_CHECK("schwinger_gauss_fill_kernel");
+    hipLaunchKernelGGL(schwinger_gauss_cfa_kernel, grid, block, 0, st, fine->Mt, fine->Mx, fine->beta, (const double2 *)theta_prime, cfa, 0u);
+    hipLaunchKernelGGL(schwinger_gauss_cfa_kernel, grid, block, 0, st, fine->Mt, fine->Mx, fine->beta, (const double2 *)d_theta, cfa, 1u);
+    MLMCPI_LAUNCH_CHECK("schwinger_gauss_cfa_kernel");
+  } else if (rt * rx == 4) {
     const BesselFill P = make_bessel_fill(fine->beta);
     const dim3 grid(nblk, B), block(256);
     hipLaunchKernelGGL(schwinger_both_fill_kernel, grid, block, 0, st, coarse->Mt, coarse->Mx, P, (const double2 *)d_phi_coarse,

@@ -187,8 +187,10 @@ class GFFExactSampler:
 class LatticeTwoLevelStep:
     """TwoLevelMetropolisStep on the Schwinger lattice, semi-coarsening (ExpCos fill-in), B device chains."""
 
-    def __init__(self, fine, coarse, B, seed=1, chain0=0, device="cuda"):
-        self.fine, self.coarse, self.B, self.seed, self.chain0 = fine, coarse, B, seed, chain0
+    def __init__(self, fine, coarse, B, seed=1, chain0=0, device="cuda", cfa_kind=0):
+        """cfa_kind 0: the conditioned fine action the reference's factory picks for the lattice; 1: the Gaussian variant
+        (QuenchedSchwingerGaussianConditionedFineAction; lattices coarsened in both directions)"""
+        self.fine, self.coarse, self.B, self.seed, self.chain0, self.cfa_kind = fine, coarse, B, seed, chain0, cfa_kind
         nbytes = C.c_size_t(0)
         abi.call("mlmcpi_lattice_twolevel_workspace_bytes", C.byref(fine), C.byref(coarse), B, C.byref(nbytes))
         self.work = torch.empty(nbytes.value, dtype=torch.uint8, device=device)
@@ -202,8 +204,9 @@ class LatticeTwoLevelStep:
 
     def draw(self, phi_coarse):
         _check_state(phi_coarse, 2 * self.coarse.Mt * self.coarse.Mx)
-        abi.call("mlmcpi_lattice_twolevel_draw", C.byref(self.fine), C.byref(self.coarse), _p(phi_coarse), _p(self.theta),
-                 self.B, self.seed, self.chain0, self.step, _p(self.work), _p(self.accept), _p(self.terms), _stream())
+        abi.call("mlmcpi_lattice_twolevel_draw_cfa", C.byref(self.fine), C.byref(self.coarse), self.cfa_kind, _p(phi_coarse),
+                 _p(self.theta), self.B, self.seed, self.chain0, self.step, _p(self.work), _p(self.accept), _p(self.terms),
+                 _stream())
         self.step += 1
         return self.accept
 

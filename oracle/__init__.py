@@ -78,6 +78,9 @@ _SIGS = {
     "orc_dev_initialise": (None, [_vp, _dp, _u64, _u32]),
     "orc_dev_twolevel_draw": (_i, [_vp, _vp, _dp, _dp, _u64, _u32, _u32, _dp]),
     "orc_dev_lattice_twolevel_draw": (_i, [_vp, _vp, _dp, _dp, _u64, _u32, _u32, _dp]),
+    "orc_dev_lattice_twolevel_draw_cfa": (_i, [_vp, _vp, _i, _dp, _dp, _u64, _u32, _u32, _dp]),
+    "orc_gaussfill_pdf": (_d, [_d, _dp, _dp]),
+    "orc_gaussfill_dev_draw": (None, [_d, _dp, _u64, _u32, _u32, _u32, _dp]),
     "orc_expcos_pdf": (_d, [_d, _d, _d, _d]),
     "orc_i0_scaled": (_d, [_d]),
     "orc_ho_cholesky": (_i, [_vp, _dp]),
@@ -181,10 +184,11 @@ class Action:
         acc = lib().orc_dev_twolevel_draw(self.h, coarse.h, np.ascontiguousarray(x_coarse), theta, seed, chain, step, terms)
         return acc, terms
 
-    def dev_lattice_twolevel_draw(self, coarse, phi_coarse, theta, seed, chain, step):
-        """self = fine Schwinger action (semi-coarsening); returns (accept, terms); theta updated in place."""
+    def dev_lattice_twolevel_draw(self, coarse, phi_coarse, theta, seed, chain, step, cfa_kind=0):
+        """self = fine Schwinger action; returns (accept, terms); theta updated in place.  cfa_kind 1 = the Gaussian
+        conditioned fine action (lattices coarsened in both directions)."""
         terms = np.zeros(3)
-        acc = lib().orc_dev_lattice_twolevel_draw(self.h, coarse.h, np.ascontiguousarray(phi_coarse), theta, seed, chain, step, terms)
+        acc = lib().orc_dev_lattice_twolevel_draw_cfa(self.h, coarse.h, cfa_kind, np.ascontiguousarray(phi_coarse), theta, seed, chain, step, terms)
         if acc < 0:
             raise ValueError("invalid coarsening for fill-in")
         return acc, terms

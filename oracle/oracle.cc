@@ -22,6 +22,7 @@
 //
 // All paths cited are relative to /root/reference/src.
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -1020,8 +1021,134 @@ int twolevel_decide(double dS_fine, double dS_coarse, double dS_trial, const Dev
   return acc ? 1 : 0;
 }
 
+// ---- GaussianFillinDistribution (distribution/gaussianfillindistribution.{hh,cc}) and
+// QuenchedSchwingerGaussianConditionedFineAction (quenchedschwingerconditionedfineaction.cc:81-134, 293-327) -------------
+constexpr uint32_t P_GAUSSFILL = 13;  // coarse cell c: call 0 (xi, omega / 2 pi), calls 1, 2 the normals of eta_1, eta_2 / eta_3
+struct GaussianFillinO {
+  double beta;
+  std::vector<std::array<double, 3>> main_peaks, secondary_peaks;
+  explicit GaussianFillinO(double beta_) : beta(beta_) {  // gaussianfillindistribution.hh:33-46, .cc:70-118
+    const int n_offsets = beta > 72.0 ? 0 : 1;
+    std::set<std::array<int, 3>> main_idx, sec_idx;
+    const int p_main[9][3] = {{0, 0, 0}, {2, 2, 2}, {-2, 2, 2}, {2, -2, 2}, {-2, -2, 2}, {2, 2, -2}, {-2, 2, -2}, {2, -2, -2}, {-2, -2, -2}};
+    const int p_sec[4][3] = {{2, 0, 1}, {-2, 0, 1}, {0, 2, -1}, {0, -2, -1}};
+    for (int kx = -n_offsets; kx <= n_offsets; ++kx)
+      for (int ky = -n_offsets; ky <= n_offsets; ++ky)
+        for (int kz = -n_offsets; kz <= n_offsets; ++kz) {
+          for (auto &q : p_main) main_idx.insert({q[0] + 4 * kx, q[1] + 4 * ky, q[2] + 4 * kz});
+          for (auto &q : p_sec) sec_idx.insert({q[0] + 4 * kx, q[1] + 4 * ky, q[2] + 4 * kz});
+        }
+    for (auto &x : main_idx) main_peaks.push_back({0.5 * kPi * x[0], 0.5 * kPi * x[1], 0.5 * kPi * x[2]});
+    for (auto &x : sec_idx) secondary_peaks.push_back({0.5 * kPi * x[0], 0.5 * kPi * x[1], 0.5 * kPi * x[2]});
+  }
+  double get_pc(double Phi) const {
+    if (Phi < 0.125 * kPi) return 1.0;
+    if (Phi > 0.375 * kPi) return 0.0;
+    const double sp = beta * std::cos(Phi), sm = beta * std::sin(Phi);
+    return 1. / (1. + std::pow(sp / sm, 1.5) * std::exp(-4.0 * (sp - sm)));
+  }
+  void dev_draw(const DevRng &rng, uint32_t cell, double phi_12, double phi_23, double phi_34, double phi_41, double th[4]) const {
+    const double Phi = 0.25 * (phi_12 + phi_23 + phi_34 + phi_41);
+    double Phi_star = Phi;
+    bool swap_eta = false, shift_eta = false;
+    if (Phi_star < 0) { Phi_star *= -1.0; swap_eta = true; }
+    if (Phi_star > 0.5 * kPi) { Phi_star = kPi - Phi_star; swap_eta = !swap_eta; shift_eta = true; }
+    const double p_c = get_pc(Phi_star);
+    double xi, om, n1, n2, n3, unused;
+    rng.uniforms(cell, (Purpose)P_GAUSSFILL, 0, xi, om);
+    rng.normals(cell, (Purpose)P_GAUSSFILL, 1, n1, n2);
+    rng.normals(cell, (Purpose)P_GAUSSFILL, 2, n3, unused);
+    double eta_1, eta_2, eta_3, sigma;
+    if (xi < p_c) { eta_1 = eta_2 = eta_3 = 0.0; sigma = 1. / std::sqrt(4. * beta * std::cos(Phi_star)); }
+    else { eta_1 = kPi; eta_2 = 0.0; eta_3 = 0.5 * kPi; sigma = 1. / std::sqrt(4. * beta * std::sin(Phi_star)); }
+    eta_1 += std::sqrt(2.0) * sigma * n1;
+    eta_2 += std::sqrt(2.0) * sigma * n2;
+    eta_3 += sigma * n3;
+    if (swap_eta) std::swap(eta_1, eta_2);
+    if (shift_eta) { eta_1 += kPi; eta_2 += kPi; }
+    const double omega = 2. * kPi * om;
+    th[0] = wrap_2pi(0.5 * (+eta_1 + eta_2 + eta_3) + omega);
+    th[1] = wrap_2pi(0.5 * (+eta_1 - eta_2 - eta_3) + omega + Phi - phi_12);
+    th[2] = wrap_2pi(0.5 * (-eta_1 - eta_2 + eta_3) + omega + 2. * Phi - phi_12 - phi_23);
+    th[3] = wrap_2pi(0.5 * (-eta_1 + eta_2 - eta_3) + omega + 3. * Phi - phi_12 - phi_23 - phi_34);
+  }
+  double evaluate(double theta_1, double theta_2, double theta_3, double theta_4, double phi_12, double phi_23, double phi_34,
+                  double phi_41) const {
+    double eta_1 = wrap_2pi(0.5 * (theta_1 + theta_2 - theta_3 - theta_4) + 0.5 * (phi_41 - phi_23));
+    double eta_2 = wrap_2pi(0.5 * (theta_1 - theta_2 - theta_3 + theta_4) + 0.5 * (phi_34 - phi_12));
+    double eta_3 = wrap_2pi(0.5 * (theta_1 - theta_2 + theta_3 - theta_4) + 0.25 * (-phi_12 + phi_23 - phi_34 + phi_41));
+    double Phi_star = 0.25 * (phi_12 + phi_23 + phi_34 + phi_41);
+    bool swap_eta = false;
+    if (Phi_star < 0.) { Phi_star *= -1.0; swap_eta = true; }
+    if (Phi_star > 0.5 * kPi) {
+      Phi_star = kPi - Phi_star;
+      swap_eta = !swap_eta;
+      eta_1 = wrap_2pi(eta_1 + kPi);
+      eta_2 = wrap_2pi(eta_2 + kPi);
+    }
+    if (swap_eta) std::swap(eta_1, eta_2);
+    const double p_c = get_pc(Phi_star);
+    const double s2c = 2. * beta * std::cos(Phi_star), s2s = 2. * beta * std::sin(Phi_star);
+    double g_c = 0.0, g_s = 0.0;
+    for (auto &p : main_peaks) {
+      const double d1 = eta_1 - p[0], d2 = eta_2 - p[1], d3 = eta_3 - p[2];
+      g_c += std::exp(-0.5 * s2c * (d1 * d1 + d2 * d2 + 2. * d3 * d3));
+    }
+    for (auto &p : secondary_peaks) {
+      const double d1 = eta_1 - p[0], d2 = eta_2 - p[1], d3 = eta_3 - p[2];
+      g_s += std::exp(-0.5 * s2s * (d1 * d1 + d2 * d2 + 2. * d3 * d3));
+    }
+    return p_c * std::pow(s2c, 1.5) * g_c + (1. - p_c) * std::pow(s2s, 1.5) * g_s;
+  }
+};
+
+// quenchedschwingerconditionedfineaction.cc:81-134 on a state whose coarse links have been halved onto the fine links
+void schwinger_gauss_fill(const ActionO &F, const ActionO &Cc, const GaussianFillinO &gd, const DevRng &rng, double *tp) {
+  const Grid2 &g = F.g, &gc = Cc.g;
+  for (int i = 0; i < g.Mt / 2; ++i)
+    for (int j = 0; j < g.Mx / 2; ++j) {
+      double dt, dx;
+      rng.uniforms((uint32_t)(j * gc.Mt + i), P_FILLIN, 0, dt, dx);
+      dt = (2. * dt - 1.) * kPi;
+      dx = (2. * dx - 1.) * kPi;
+      tp[g.link(2 * i, 2 * j, 0)] = wrap_2pi(tp[g.link(2 * i, 2 * j, 0)] + dt);
+      tp[g.link(2 * i + 1, 2 * j, 0)] = wrap_2pi(tp[g.link(2 * i + 1, 2 * j, 0)] - dt);
+      tp[g.link(2 * i, 2 * j, 1)] = wrap_2pi(tp[g.link(2 * i, 2 * j, 1)] + dx);
+      tp[g.link(2 * i, 2 * j + 1, 1)] = wrap_2pi(tp[g.link(2 * i, 2 * j + 1, 1)] - dx);
+    }
+  for (int i = 0; i < g.Mt / 2; ++i)
+    for (int j = 0; j < g.Mx / 2; ++j) {
+      const double phi_12 = wrap_2pi(+tp[g.link(2 * i, 2 * j + 1, 1)] + tp[g.link(2 * i, 2 * j + 2, 0)]);
+      const double phi_23 = wrap_2pi(+tp[g.link(2 * i + 1, 2 * j + 2, 0)] - tp[g.link(2 * i + 2, 2 * j + 1, 1)]);
+      const double phi_34 = wrap_2pi(-tp[g.link(2 * i + 2, 2 * j, 1)] - tp[g.link(2 * i + 1, 2 * j, 0)]);
+      const double phi_41 = wrap_2pi(-tp[g.link(2 * i, 2 * j, 0)] + tp[g.link(2 * i, 2 * j, 1)]);
+      double th[4];
+      gd.dev_draw(rng, (uint32_t)(j * gc.Mt + i), phi_12, phi_23, phi_34, phi_41, th);
+      tp[g.link(2 * i, 2 * j + 1, 0)] = +th[0];
+      tp[g.link(2 * i + 1, 2 * j + 1, 1)] = -th[1];
+      tp[g.link(2 * i + 1, 2 * j + 1, 0)] = -th[2];
+      tp[g.link(2 * i + 1, 2 * j, 1)] = +th[3];
+    }
+}
+// quenchedschwingerconditionedfineaction.cc:293-327
+double schwinger_gauss_cfa(const ActionO &F, const GaussianFillinO &gd, const double *x) {
+  const Grid2 &g = F.g;
+  double S = 0.0;
+  for (int i = 0; i < g.Mt / 2; ++i)
+    for (int j = 0; j < g.Mx / 2; ++j) {
+      const double phi_12 = wrap_2pi(+x[g.link(2 * i, 2 * j + 1, 1)] + x[g.link(2 * i, 2 * j + 2, 0)]);
+      const double phi_23 = wrap_2pi(+x[g.link(2 * i + 1, 2 * j + 2, 0)] - x[g.link(2 * i + 2, 2 * j + 1, 1)]);
+      const double phi_34 = wrap_2pi(-x[g.link(2 * i + 2, 2 * j, 1)] - x[g.link(2 * i + 1, 2 * j, 0)]);
+      const double phi_41 = wrap_2pi(-x[g.link(2 * i, 2 * j, 0)] + x[g.link(2 * i, 2 * j, 1)]);
+      const double theta_1 = wrap_2pi(+x[g.link(2 * i, 2 * j + 1, 0)]), theta_2 = wrap_2pi(-x[g.link(2 * i + 1, 2 * j + 1, 1)]);
+      const double theta_3 = wrap_2pi(-x[g.link(2 * i + 1, 2 * j + 1, 0)]), theta_4 = wrap_2pi(+x[g.link(2 * i + 1, 2 * j, 1)]);
+      S -= std::log(gd.evaluate(theta_1, theta_2, theta_3, theta_4, phi_12, phi_23, phi_34, phi_41));
+    }
+  return S;
+}
+
 int dev_schwinger_twolevel_draw(const ActionO &F, const ActionO &Cc, const double *phi_coarse, double *theta,
-                                const DevRng &rng, double *terms) {
+                                const DevRng &rng, double *terms, int cfa_kind = 0) {
   const Grid2 &g = F.g, &gc = Cc.g;
   const int rt = g.Mt / gc.Mt, rx = g.Mx / gc.Mx;
   const unsigned nf = 2u * g.Mt * g.Mx, nc = 2u * gc.Mt * gc.Mx;
@@ -1066,6 +1193,14 @@ int dev_schwinger_twolevel_draw(const ActionO &F, const ActionO &Cc, const doubl
         const unsigned l = g.link(i, 2 * j + 1, 0);
         tp[l] = draw(l, theta_p, theta_m);
       }
+  } else if (rt == 2 && rx == 2 && cfa_kind == 1) {  // QuenchedSchwingerGaussianConditionedFineAction
+    const GaussianFillinO gd(F.beta);
+    schwinger_gauss_fill(F, Cc, gd, rng, tp.data());
+    double dS_fine = F.evaluate(tp.data()) - F.evaluate(theta);
+    schwinger_copy_from_fine(gc.Mt, gc.Mx, rt, rx, theta, thetaC.data());
+    double dS_coarse = Cc.evaluate(thetaC.data()) - Cc.evaluate(phi_coarse);
+    double dS_trial = schwinger_gauss_cfa(F, gd, theta) - schwinger_gauss_cfa(F, gd, tp.data());
+    return twolevel_decide(dS_fine, dS_coarse, dS_trial, rng, tp, theta, terms);
   } else if (rt == 2 && rx == 2) {
     // quenchedschwingerconditionedfineaction.hh:62-71: true distribution up to beta = 8, approximation beyond
     static std::unique_ptr<BesselProductO> cached;  // the coefficient table costs ~10 ms to build
@@ -1709,6 +1844,19 @@ int orc_dev_lattice_twolevel_draw(void *fine, void *coarse, const double *phi_co
                                   uint32_t chain, uint32_t step, double *terms) {
   DevRng r{(uint32_t)seed, (uint32_t)(seed >> 32), chain, step};
   return dev_schwinger_twolevel_draw(*(ActionO *)fine, *(ActionO *)coarse, phi_coarse, theta, r, terms);
+}
+int orc_dev_lattice_twolevel_draw_cfa(void *fine, void *coarse, int cfa_kind, const double *phi_coarse, double *theta, uint64_t seed,
+                                      uint32_t chain, uint32_t step, double *terms) {
+  DevRng r{(uint32_t)seed, (uint32_t)(seed >> 32), chain, step};
+  return dev_schwinger_twolevel_draw(*(ActionO *)fine, *(ActionO *)coarse, phi_coarse, theta, r, terms, cfa_kind);
+}
+// density of GaussianFillinDistribution (for normalisation / consistency checks)
+double orc_gaussfill_pdf(double beta, const double *theta4, const double *phi4) {
+  return GaussianFillinO(beta).evaluate(theta4[0], theta4[1], theta4[2], theta4[3], phi4[0], phi4[1], phi4[2], phi4[3]);
+}
+void orc_gaussfill_dev_draw(double beta, const double *phi4, uint64_t seed, uint32_t chain, uint32_t step, uint32_t cell, double *theta4) {
+  DevRng r{(uint32_t)seed, (uint32_t)(seed >> 32), chain, step};
+  GaussianFillinO(beta).dev_draw(r, cell, phi4[0], phi4[1], phi4[2], phi4[3], theta4);
 }
 double orc_expcos_pdf(double beta, double x, double x_p, double x_m) { return expcos_pdf(beta, x, x_p, x_m); }
 double orc_i0_scaled(double z) { return fast_bessel_i0_scaled(z); }

@@ -748,6 +748,31 @@ def test_schwinger_twolevel_step_matches_oracle(gpu_ops, orc, Mt, Mx, rt, rx, be
         assert seen == {0, 1}
 
 
+@pytest.mark.parametrize("Mt,Mx,beta,B", [(8, 8, 4.0, 3), (16, 12, 2.0, 2), (8, 8, 80.0, 2), (64, 64, 9.0, 1)])
+def test_schwinger_gaussian_cfa_twolevel_step_matches_oracle(gpu_ops, orc, Mt, Mx, beta, B):
+    """The two-level step with QuenchedSchwingerGaussianConditionedFineAction (quenchedschwingerconditionedfineaction.cc:
+    81-134, 293-327; GaussianFillinDistribution): fill-in, the three action differences and the accept flags against the
+    oracle's restatement.  beta = 80 takes the n_offsets = 0 branch of the peak construction."""
+    fine, F = make_lattice(orc, "schwinger", Mt, Mx, beta=beta)
+    coarse, Cc = make_lattice(orc, "schwinger", Mt // 2, Mx // 2, beta=beta / 4)
+    rng = np.random.default_rng(Mt * 11 + Mx)
+    step = gpu_ops.LatticeTwoLevelStep(fine, coarse, B, seed=SEED, chain0=2, cfa_kind=1)
+    theta0 = rng.uniform(-np.pi, np.pi, (B, 2 * Mt * Mx)) * 0.1
+    step.set_state(dev(theta0))
+    theta = theta0.copy()
+    for t in range(4):
+        base = gpu_ops.lattice_copy_from_fine(fine, 2, 2, dev(theta)).cpu().numpy()
+        pc = base + rng.normal(0, 0.02 if t % 2 == 0 else 0.8, base.shape)
+        acc = step.draw(dev(pc)).cpu().numpy()
+        terms = step.terms.cpu().numpy()
+        for b in range(B):
+            a, want = F.dev_lattice_twolevel_draw(Cc, pc[b], theta[b], SEED, 2 + b, t, cfa_kind=1)
+            assert_close(terms[b], want, tol=5e-10, scale=max(1.0, float(np.max(np.abs(want)))), what=f"action differences t={t} b={b}")
+            assert acc[b] == a, (t, b, want)
+        assert_angles_close(step.theta.cpu().numpy(), theta, tol=1e-10, what=f"fine state after draw {t}")
+        theta = step.theta.cpu().numpy().copy()
+
+
 def test_schwinger_twolevel_step_errors(gpu_ops):
     from mlmcpathintegral_amd import abi
     f = abi.lattice_action(4, 16, 16, beta=1.0)

@@ -73,6 +73,39 @@ def test_oracle_two_level_chain_samples_the_fine_distribution(orc, rt, rx, beta)
         assert abs(v.mean() - exact) < 4 * err, (v.mean(), err, exact)
 
 
+@pytest.mark.parametrize("beta", [4.0, 9.0])
+def test_oracle_gaussian_cfa_two_level_chain_samples_the_fine_distribution(orc, beta):
+    """QuenchedSchwingerGaussianConditionedFineAction (quenchedschwingerconditionedfineaction.cc:81-134, 293-327; a variant
+    the reference's factory never selects, so nothing pins it but its own mathematics): the two-level chain with the
+    Gaussian fill-in leaves the fine distribution invariant -- average plaquette of the 8 x 8 lattice against the closed
+    form -- which only a matching pair (sampler, density) of GaussianFillinDistribution achieves."""
+    L = orc.lib()
+    M, n, burn = 8, 12000, 500
+    F = orc.Action(orc.SCHWINGER, Mt=M, Mx=M, beta=beta)
+    C = orc.Action(orc.SCHWINGER, Mt=M // 2, Mx=M // 2, beta=beta / 4)
+    hb = L.orc_heatbath_new(C.h, 1, 1, 50, 0)
+    theta = np.random.default_rng(22).uniform(-np.pi, np.pi, 2 * M * M) * 0.1
+    pc = np.zeros(2 * (M // 2) * (M // 2))
+    vals, acc = [], 0
+    for t in range(n):
+        L.orc_schwinger_copy_from_fine(M // 2, M // 2, 2, 2, theta, pc)
+        L.orc_heatbath_set_state(hb, pc)
+        L.orc_heatbath_draw(hb, pc)
+        a, _ = F.dev_lattice_twolevel_draw(C, pc, theta, 5, 0, t, cfa_kind=1)
+        acc += a
+        if t >= burn:
+            vals.append(L.orc_qoi_avg_plaquette(theta, M, M))
+    L.orc_heatbath_free(hb)
+    v = np.array(vals)
+    nb = 25
+    bm = v[: len(v) // nb * nb].reshape(nb, -1).mean(axis=1)
+    err = bm.std(ddof=1) / math.sqrt(nb)
+    exact = plaquette_exact(beta, M * M)
+    print(f"Gaussian CFA beta = {beta}: plaquette {v.mean():.5f} +- {err:.5f} (exact {exact:.5f}), acceptance {acc / n:.3f}")
+    assert acc / n > 0.02
+    assert abs(v.mean() - exact) < 4 * err + (8e-4 if beta > 8 else 0.0), (v.mean(), err, exact)
+
+
 def test_oracle_rotor_two_level_chain_samples_the_fine_distribution(orc):
     """Rotor M_lat = 32: coarse reference-order heat bath (M_lat = 16) + device-order two-level step with the ExpSin2
     conditioned fine action (rotorconditionedfineaction.cc) against a direct reference-order chain on the fine lattice:
