@@ -393,7 +393,7 @@ __global__ void __launch_bounds__(1024)
   // leave them alone, here they are updated from the clamped (wrong) neighbours instead -- no predicates in the sweep
   // loop.  Either way what an edge link holds only ever reaches links that are already outside the exact region
   // (which shrinks by one block per sweep no matter what its surroundings hold), never the owned tile.
-  const int me = (int)tid;
+  const int me = active ? (int)tid : 0;  // idle threads of the last wave: every index is entry 0, nothing is written
   const int dn = pj > 0 ? me - NPX : me, up = pj + 1 < NPY ? me + NPX : me;
   const int lf = pi > 0 ? me - 1 : me, rt = pi + 1 < NPX ? me + 1 : me;
   const int rtdn = (pi + 1 < NPX ? 1 : 0) + (pj > 0 ? -NPX : 0) + me;
@@ -402,83 +402,76 @@ __global__ void __launch_bounds__(1024)
 
   for (int s = 0; s < K; ++s) {
     // phase 0: mu = 0, even rows (c = 0)
-    double D0 = 0, D1 = 0, E0 = 0, E1 = 0, R0 = 0, RD = 0;
-    if (active) {
-      D0 = plane(0, 1, 0)[dn]; D1 = plane(0, 1, 1)[dn]; E0 = plane(1, 1, 0)[dn]; E1 = plane(1, 1, 1)[dn];
-      R0 = plane(1, 0, 0)[rt]; RD = plane(1, 1, 0)[rtdn];
-    }
-    if (active) {
+    // (the idle threads of the last wave read entry 0 and compute on zeros: no predicate, no zero fill in the loop)
+    const double D0 = plane(0, 1, 0)[dn], D1 = plane(0, 1, 1)[dn], E0 = plane(1, 1, 0)[dn], E1 = plane(1, 1, 1)[dn];
+    double R0 = plane(1, 0, 0)[rt];
+    const double RD = plane(1, 1, 0)[rtdn];
+    {
       {  // a = 0
         const double tp = t0[1][0] + t1[0][0] - t1[0][1];
         const double tm = D0 + E1 - E0;
         t0[0][0] = mod_2pi_fast((tp + tm) - t0[0][0]);
-        plane(0, 0, 0)[me] = t0[0][0];
+        if (active) plane(0, 0, 0)[me] = t0[0][0];
       }
       {  // a = 1
         const double tp = t0[1][1] + t1[0][1] - R0;
         const double tm = D1 + RD - E1;
         t0[0][1] = mod_2pi_fast((tp + tm) - t0[0][1]);
-        plane(0, 0, 1)[me] = t0[0][1];
+        if (active) plane(0, 0, 1)[me] = t0[0][1];
       }
     }
     __syncthreads();
     // phase 1: mu = 0, odd rows (c = 1)
-    double U0 = 0, U1 = 0, R1 = 0;
-    if (active) {
-      U0 = plane(0, 0, 0)[up]; U1 = plane(0, 0, 1)[up]; R1 = plane(1, 1, 0)[rt];
-    }
-    if (active) {
+    const double U0 = plane(0, 0, 0)[up], U1 = plane(0, 0, 1)[up];
+    double R1 = plane(1, 1, 0)[rt];
+    {
       {
         const double tp = U0 + t1[1][0] - t1[1][1];
         const double tm = t0[0][0] + t1[0][1] - t1[0][0];
         t0[1][0] = mod_2pi_fast((tp + tm) - t0[1][0]);
-        plane(0, 1, 0)[me] = t0[1][0];
+        if (active) plane(0, 1, 0)[me] = t0[1][0];
       }
       {
         const double tp = U1 + t1[1][1] - R1;
         const double tm = t0[0][1] + R0 - t1[0][1];
         t0[1][1] = mod_2pi_fast((tp + tm) - t0[1][1]);
-        plane(0, 1, 1)[me] = t0[1][1];
+        if (active) plane(0, 1, 1)[me] = t0[1][1];
       }
     }
     __syncthreads();
     // phase 2: mu = 1, even columns (a = 0)
-    double L01 = 0, L11 = 0, M01 = 0, M11 = 0, LU = 0;
-    if (active) {
-      L01 = plane(0, 0, 1)[lf]; L11 = plane(0, 1, 1)[lf]; M01 = plane(1, 0, 1)[lf]; M11 = plane(1, 1, 1)[lf];
-      LU = plane(0, 0, 1)[lfup];
-    }
-    if (active) {
+    const double L01 = plane(0, 0, 1)[lf], L11 = plane(0, 1, 1)[lf], M01 = plane(1, 0, 1)[lf], M11 = plane(1, 1, 1)[lf];
+    const double LU = plane(0, 0, 1)[lfup];
+    {
       {  // c = 0
         const double tp = t0[0][0] + t1[0][1] - t0[1][0];
         const double tm = L11 + M01 - L01;
         t1[0][0] = mod_2pi_fast((tp + tm) - t1[0][0]);
-        plane(1, 0, 0)[me] = t1[0][0];
+        if (active) plane(1, 0, 0)[me] = t1[0][0];
       }
       {  // c = 1
         const double tp = t0[1][0] + t1[1][1] - U0;
         const double tm = LU + M11 - L11;
         t1[1][0] = mod_2pi_fast((tp + tm) - t1[1][0]);
-        plane(1, 1, 0)[me] = t1[1][0];
+        if (active) plane(1, 1, 0)[me] = t1[1][0];
       }
     }
     __syncthreads();
     // phase 3: mu = 1, odd columns (a = 1); the right neighbour's mu = 1 links changed in phase 2
-    if (active) {
-      R0 = plane(1, 0, 0)[rt]; R1 = plane(1, 1, 0)[rt];
-    }
-    if (active) {
+    R0 = plane(1, 0, 0)[rt];
+    R1 = plane(1, 1, 0)[rt];
+    {
       {  // c = 0
         const double tp = t0[0][1] + R0 - t0[1][1];
         const double tm = t0[1][0] + t1[0][0] - t0[0][0];
         t1[0][1] = mod_2pi_fast((tp + tm) - t1[0][1]);
-        plane(1, 0, 1)[me] = t1[0][1];
+        if (active) plane(1, 0, 1)[me] = t1[0][1];
       }
       {  // c = 1
         const double tp = t0[1][1] + R1 - U1;
         const double tm = U0 + t1[1][0] - t0[1][0];
         t1[1][1] = mod_2pi_fast((tp + tm) - t1[1][1]);
-        plane(1, 1, 1)[me] = t1[1][1];
+        if (active) plane(1, 1, 1)[me] = t1[1][1];
       }
     }
     __syncthreads();
@@ -696,7 +689,7 @@ __global__ void __launch_bounds__(1024)
 #pragma unroll
       for (int a = 0; a < 2; ++a) plane(c, a)[tid] = p[c][a];
   }
-  const int me = (int)tid;
+  const int me = active ? (int)tid : 0;  // idle threads of the last wave: every index is entry 0, nothing is written
   const int dn = pj > 0 ? me - NPX : me, up = pj + 1 < NPY ? me + NPX : me;
   const int lf = pi > 0 ? me - 1 : me, rt = pi + 1 < NPX ? me + 1 : me;
   // sites on the buffer edge are updated from clamped neighbours instead of being left alone: see
@@ -705,38 +698,34 @@ __global__ void __launch_bounds__(1024)
 
   for (int s = 0; s < K; ++s) {
     // colour 0: sites (a, c) = (0, 0) and (1, 1)
-    double e_lf = 0, e_dn = 0, e_rt = 0, e_up = 0;
-    if (active) {
-      e_lf = plane(0, 1)[lf]; e_dn = plane(1, 0)[dn]; e_rt = plane(1, 0)[rt]; e_up = plane(0, 1)[up];
-    }
-    if (active) {
+    // (no predicate and no zero fill in the loop: idle threads read entry 0 and compute on zeros)
+    double e_lf = plane(0, 1)[lf], e_dn = plane(1, 0)[dn], e_rt = plane(1, 0)[rt], e_up = plane(0, 1)[up];
+    {
       double Delta = 0.0;
       Delta += p[0][1]; Delta += e_lf; Delta += p[1][0]; Delta += e_dn;
       p[0][0] = fma(two_over_kappa, Delta, -p[0][0]);
-      plane(0, 0)[me] = p[0][0];
+      if (active) plane(0, 0)[me] = p[0][0];
     }
-    if (active) {
+    {
       double Delta = 0.0;
       Delta += e_rt; Delta += p[1][0]; Delta += e_up; Delta += p[0][1];
       p[1][1] = fma(two_over_kappa, Delta, -p[1][1]);
-      plane(1, 1)[me] = p[1][1];
+      if (active) plane(1, 1)[me] = p[1][1];
     }
     __syncthreads();
     // colour 1: sites (1, 0) and (0, 1)
-    if (active) {
-      e_rt = plane(0, 0)[rt]; e_dn = plane(1, 1)[dn]; e_lf = plane(1, 1)[lf]; e_up = plane(0, 0)[up];
-    }
-    if (active) {
+    e_rt = plane(0, 0)[rt]; e_dn = plane(1, 1)[dn]; e_lf = plane(1, 1)[lf]; e_up = plane(0, 0)[up];
+    {
       double Delta = 0.0;
       Delta += e_rt; Delta += p[0][0]; Delta += p[1][1]; Delta += e_dn;
       p[0][1] = fma(two_over_kappa, Delta, -p[0][1]);
-      plane(0, 1)[me] = p[0][1];
+      if (active) plane(0, 1)[me] = p[0][1];
     }
-    if (active) {
+    {
       double Delta = 0.0;
       Delta += p[1][1]; Delta += e_lf; Delta += e_up; Delta += p[0][0];
       p[1][0] = fma(two_over_kappa, Delta, -p[1][0]);
-      plane(1, 0)[me] = p[1][0];
+      if (active) plane(1, 0)[me] = p[1][0];
     }
     __syncthreads();
   }
