@@ -54,6 +54,8 @@ def parse():
                     help="untimed sampler draws before the warm-up (sweep workloads): the timed steps run on a "
                          "thermalised state -- heat-bath rejection rates depend on it -- and at steady clocks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fused-qoi", action="store_true",
+                    help="Schwinger: evaluate the average plaquette in a pass of its own instead of inside the heat-bath launch")
     ap.add_argument("--no-extra-points", action="store_true",
                     help="skip the single-chain and 128-chain side measurements of the default workload")
     ap.add_argument("--cpu-draws", type=int, default=0)
@@ -160,11 +162,18 @@ class SweepWorkload:
                                                        self.chain0, s + self.n_full, self.fuse)
         if record:
             e[2].record()
-        self.x, self.scratch = ops.lattice_sweep_draw_pingpong(self.act, cur, oth, 0, a.n_heatbath, a.seed, self.chain0,
-                                                               s + a.n_overrelax, self.fuse)
+        # fused QoI: one pass over the state less (-0.045 ms per step at 32 chains); a single chain is latency bound and
+        # does better with the stand-alone reduction (0.122 vs 0.144 ms per step), so small batches keep it
+        self.fused = self.kind == "schwinger" and a.n_heatbath > 0 and not a.no_fused_qoi and self.B >= 8
+        if self.fused:  # sampler->draw's last launch sums the plaquettes of the new sample while the tile is in LDS
+            self.x, self.scratch, q = ops.lattice_sweep_draw_qoi(self.act, cur, oth, cur, 0, a.n_heatbath, a.seed, self.chain0,
+                                                                 s + a.n_overrelax, 1, self.fuse)
+        else:
+            self.x, self.scratch = ops.lattice_sweep_draw_pingpong(self.act, cur, oth, 0, a.n_heatbath, a.seed, self.chain0,
+                                                                   s + a.n_overrelax, self.fuse)
         if record:
             e[3].record()
-        ops.stats_accumulate(self.acc, self.qoi())  # qoi->evaluate + record_sample
+        ops.stats_accumulate(self.acc, q if self.fused else self.qoi())  # qoi->evaluate + record_sample
         if record:
             e[4].record()
             self.ev["or"].append((e[0], e[1]))
@@ -548,14 +557,20 @@ def report_sweeps(result, a, W, size, B, world, step_ms, ms):
     if a.n_heatbath:
         record(hb_name, "heat-bath sweep", W.ev["hb"], a.n_heatbath, 1, state_rw,
                pmc_entry("entries", chains=B, fuse=1, kind="heatbath", **wl), pmc_entry("valu", kind="heatbath", **wl))
-    qk = record(("schwinger_reduce_band_kernel" if a.workload == "schwinger" else "lattice_reduce_kernel") + " (QoI) + stats_accumulate_kernel", "qoi->evaluate + record_sample", W.ev["qoi"], 1, 1,
-                0.5 * state_rw, None, None)
+    fused = getattr(W, "fused", False)
+    if fused:
+        kernels[-1]["role"] = "heat-bath sweep + qoi->evaluate (plaquettes summed while the tile is in LDS)"
+    qk = record("stats_accumulate_kernel" if fused else
+                ("schwinger_reduce_band_kernel" if a.workload == "schwinger" else "lattice_reduce_kernel") + " (QoI) + stats_accumulate_kernel",
+                "record_sample (the QoI is fused into the heat-bath launch)" if fused else "qoi->evaluate + record_sample", W.ev["qoi"], 1, 1,
+                8.0 * B if fused else 0.5 * state_rw, None, None)
     del qk["updates_per_s"], qk["algorithmic_bytes_per_launch"], qk["algorithmic_GBps"], qk["sweeps_per_launch"]
     result["kernels"] = kernels
     # roofline: the kernel with the largest share of the step.  `achieved` = algorithmic bytes (16 B x the updates of one
     # launch) / launch time; for a single-sweep launch that equals the HBM floor, for a fused launch the floor is used
     # (a fused launch shares one HBM round trip among its sweeps, so the per-update model is not a bound for it).
     dom = max(kernels[:-1], key=lambda k: k["share_of_step"])
+    result["qoi_fused_into_draw"] = fused
     roof = {"kernel": f"{dom['kernel']} ({dom['role']})", "bound": "hbm",
             "achieved": dom["hbm_floor_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["hbm_frac"],
             "hbm_frac": dom["hbm_frac"], "traffic": dom["traffic"], "launch_ms": dom["launch_ms"],
@@ -564,7 +579,7 @@ def report_sweeps(result, a, W, size, B, world, step_ms, ms):
     if "valu_frac" in dom:
         roof["valu_frac"] = dom["valu_frac"]
         roof["valu_insts_per_update"] = dom["valu_insts_per_update"]
-    if dom["role"] == "heat-bath sweep" and a.workload == "schwinger":
+    if dom["role"].startswith("heat-bath sweep") and a.workload == "schwinger":
         roof["limited_by"] = "valu"
         roof["note"] = ("fp64 vector-issue bound (Philox + von Mises rejection sampler, ~25-45 flop/B, SURVEY A.2): hbm_frac is "
                         "what the contract asks for, valu_frac (SQ_INSTS_VALU x 4 cycles / 2.4 GHz / 1024 SIMDs) is the "
@@ -572,7 +587,7 @@ def report_sweeps(result, a, W, size, B, world, step_ms, ms):
     result["roofline"] = roof
     # whole step: 16 B x every update of the step against the step time, and the bytes the step's launches cannot avoid
     alg_step = 16.0 * sites * B * (a.n_overrelax + a.n_heatbath)
-    floor_step = state_rw * (n_launch + (1 if rem else 0) + a.n_heatbath) + 0.5 * state_rw
+    floor_step = state_rw * (n_launch + (1 if rem else 0) + a.n_heatbath) + (0.0 if fused else 0.5 * state_rw)
     result["whole_step"] = {"algorithmic_bytes": alg_step, "algorithmic_GBps": alg_step / (step_ms * 1e-3) / 1e9,
                             "algorithmic_frac_of_peak": alg_step / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                             "hbm_floor_bytes": floor_step, "hbm_floor_GBps": floor_step / (step_ms * 1e-3) / 1e9,

@@ -132,8 +132,9 @@ template <bool HEAT, int NT, int TWC = 0, int THC = 0>
 __global__ void __launch_bounds__(NT, HEAT ? (NT == 256 ? 4 : NT == 512 ? 2 : 1) : 1)
     schwinger_sweep_kernel(uint32_t Mt, uint32_t Mx, double beta, const double2 *__restrict__ in,
                            double2 *__restrict__ out, TileGeom tg, uint32_t nsweeps_arg, uint32_t kinds, RngKey key0,
-                           uint32_t pool_cap) {
+                           uint32_t pool_cap, int qoi_op, double *__restrict__ qoi_partial) {
   extern __shared__ double lds[];
+  __shared__ double qoi_red[NT / kWave];
   constexpr bool FIXED = TWC > 0;
   const uint32_t nsweeps = FIXED ? 1u : nsweeps_arg;
   const uint32_t H = 2 * nsweeps;
@@ -240,11 +241,24 @@ __global__ void __launch_bounds__(NT, HEAT ? (NT == 256 ? 4 : NT == 512 ? 2 : 1)
     }
   }
 
+  // Optional fused QoI of the final state (qoi/qft/qoiavgplaquette.cc:8-27, qoi2dsusceptibility.cc:8-27): the plaquette
+  // (i, j) needs theta(i+1, j, 1) and theta(i, j+1, 0); for the owned tile those are the column right of it and the row
+  // above it, which the last sweep's pruned regions bring to their final values (that is what they are for).  One
+  // partial per tile; lattice_finish_kernel sums them in tile order.
+  double acc[1] = {0.0};
   double2 *dst = out + (size_t)b * Mt * Mx;
   for_region<NT>(oh, ow, [&](uint32_t r, uint32_t c) {
     const uint32_t o = (r + H) * bw + (c + H);
     dst[(size_t)(j0 + r) * Mt + (i0 + c)] = make_double2(th0[o], th1[o]);
+    if (qoi_op) {
+      const double thp = th0[o] + th1[o + 1] - th0[o + bw] - th1[o];   // quenchedschwingeraction.cc:14-17
+      acc[0] += qoi_op == 3 ? cos_reduced(thp) : mod_2pi(thp);         // 3 = L_PLAQ, 4 = L_CHARGE
+    }
   });
+  if (qoi_op) {
+    block_sum<1>(acc, qoi_red);
+    if (threadIdx.x == 0) qoi_partial[(size_t)b * gridDim.x + blockIdx.x] = acc[0];
+  }
 }
 
 // ---- Schwinger overrelaxation, specialised ---------------------------------------------------------------
@@ -1027,28 +1041,29 @@ static SweepGeom choose_geometry(uint32_t Mt, uint32_t Mx, uint32_t nsweeps, uin
 
 template <bool SCHW, bool HEAT, int NT>
 static void launch_sweep_nt(const SweepGeom &g, dim3 grid, hipStream_t st, uint32_t Mt, uint32_t Mx, double coupling,
-                            const double *src, double *dst, uint32_t n, uint32_t kinds, RngKey key) {
+                            const double *src, double *dst, uint32_t n, uint32_t kinds, RngKey key, int qoi_op = 0,
+                            double *qoi_partial = nullptr) {
   if (SCHW) {
     // heat-bath launches: room for the retry pool behind the tile image, as many entries as still keep the workgroup's
     // LDS footprint within a quarter of the CU's 160 KiB (4 workgroups per CU), at least one wave's worth
     uint32_t cap = 0;
     size_t lds = g.lds_bytes;
     if (HEAT) {
-      const size_t quarter = 40 * 1024;
+      const size_t quarter = 40 * 1024 - 64;  // (the kernel's static LDS: the QoI reduction scratch)
       cap = 64;
       if (lds + HbPool::bytes(cap) <= quarter) cap = (uint32_t)((quarter - lds - 8) / 24);
       if (cap > 1024) cap = 1024;
       lds += HbPool::bytes(cap);
-      if (lds > 160 * 1024) { cap = 0; lds = g.lds_bytes; }
+      if (lds > 160 * 1024 - 256) { cap = 0; lds = g.lds_bytes; }
     }
     // single heat-bath sweep on a lattice the default tiles divide: compile-time geometry (bit-identical results)
     if (HEAT && NT == 256 && n == 1 && !g.overridden && g.tg.TW == 64 && g.tg.TH == 32 && Mt % 64 == 0 && Mx % 32 == 0 &&
         Mt >= 128 && Mx >= 64)
       hipLaunchKernelGGL((schwinger_sweep_kernel<HEAT, NT, 64, 32>), grid, dim3(NT), lds, st, Mt, Mx, coupling,
-                         (const double2 *)src, (double2 *)dst, g.tg, n, kinds, key, cap);
+                         (const double2 *)src, (double2 *)dst, g.tg, n, kinds, key, cap, qoi_op, qoi_partial);
     else
       hipLaunchKernelGGL((schwinger_sweep_kernel<HEAT, NT>), grid, dim3(NT), lds, st, Mt, Mx, coupling,
-                         (const double2 *)src, (double2 *)dst, g.tg, n, kinds, key, cap);
+                         (const double2 *)src, (double2 *)dst, g.tg, n, kinds, key, cap, qoi_op, qoi_partial);
   }
   else
     hipLaunchKernelGGL((gff_sweep_kernel<HEAT, NT>), grid, dim3(NT), g.lds_bytes, st, Mt, Mx, coupling, src, dst, g.tg, n,
@@ -1057,11 +1072,12 @@ static void launch_sweep_nt(const SweepGeom &g, dim3 grid, hipStream_t st, uint3
 
 template <bool SCHW, bool HEAT>
 static int launch_sweep(const SweepGeom &g, dim3 grid, hipStream_t st, uint32_t Mt, uint32_t Mx, double coupling,
-                        const double *src, double *dst, uint32_t n, uint32_t kinds, RngKey key) {
+                        const double *src, double *dst, uint32_t n, uint32_t kinds, RngKey key, int qoi_op = 0,
+                        double *qoi_partial = nullptr) {
   switch (g.NT) {
-    case 1024: launch_sweep_nt<SCHW, HEAT, 1024>(g, grid, st, Mt, Mx, coupling, src, dst, n, kinds, key); break;
-    case 512: launch_sweep_nt<SCHW, HEAT, 512>(g, grid, st, Mt, Mx, coupling, src, dst, n, kinds, key); break;
-    default: launch_sweep_nt<SCHW, HEAT, 256>(g, grid, st, Mt, Mx, coupling, src, dst, n, kinds, key);
+    case 1024: launch_sweep_nt<SCHW, HEAT, 1024>(g, grid, st, Mt, Mx, coupling, src, dst, n, kinds, key, qoi_op, qoi_partial); break;
+    case 512: launch_sweep_nt<SCHW, HEAT, 512>(g, grid, st, Mt, Mx, coupling, src, dst, n, kinds, key, qoi_op, qoi_partial); break;
+    default: launch_sweep_nt<SCHW, HEAT, 256>(g, grid, st, Mt, Mx, coupling, src, dst, n, kinds, key, qoi_op, qoi_partial);
   }
   MLMCPI_LAUNCH_CHECK("lattice sweep kernel");
   return MLMCPI_OK;
@@ -1070,7 +1086,8 @@ static int launch_sweep(const SweepGeom &g, dim3 grid, hipStream_t st, uint32_t 
 template <bool HEAT, int NT>
 static int allow_full_lds() {
   // tiles with deep halos may use the whole 160 KiB of LDS
-  MLMCPI_HIP_TRY(hipFuncSetAttribute((const void *)schwinger_sweep_kernel<HEAT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  // (the Schwinger kernel also holds NT / 64 doubles of static LDS for the fused QoI reduction)
+  MLMCPI_HIP_TRY(hipFuncSetAttribute((const void *)schwinger_sweep_kernel<HEAT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
   MLMCPI_HIP_TRY(hipFuncSetAttribute((const void *)gff_sweep_kernel<HEAT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   return MLMCPI_OK;
 }
@@ -1156,10 +1173,17 @@ int mlmcpi_lattice_initialise(const mlmcpi_lattice_action *act, double *d_phi, u
 // The launches read `src` and write `dst`; after each one src <- dst and dst <- the other work buffer.  d_phi is only
 // read unless it is also d_w1.  result_in (may be NULL: then the result is copied into d_phi, which must be writable):
 // 0 -> the result is in d_w0, 1 -> in d_w1, -1 -> no sweep was run (result is the input).
+// qoi_kind != 0 (1 average plaquette, 2 Q^2 / 4 pi^2): the QoI of the final state, summed inside the last launch (which
+// has to be a launch of schwinger_sweep_kernel, i.e. the draw must end with a heat-bath sweep), into d_qoi[b].
 static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, double *d_w0, double *d_w1, uint32_t B,
                            uint32_t n_overrelax, uint32_t n_heatbath, uint64_t seed, uint32_t chain0, uint32_t sweep0,
-                           uint32_t fuse, int32_t *result_in, void *stream) {
+                           uint32_t fuse, int32_t *result_in, void *stream, int qoi_kind = 0, double *d_qoi = nullptr) {
   if (int rc = check_lattice(act)) return rc;
+  if (qoi_kind) {
+    MLMCPI_REQUIRE(d_qoi && (qoi_kind == 1 || qoi_kind == 2), "bad QoI arguments");
+    if (act->kind != MLMCPI_SCHWINGER || n_heatbath == 0)
+      return fail(MLMCPI_ERR_UNSUPPORTED, "the fused QoI needs a Schwinger draw that ends with a heat-bath sweep");
+  }
   MLMCPI_REQUIRE(d_phi && d_w0 && d_w1 && d_phi != d_w0 && d_w0 != d_w1 && B > 0, "bad arguments");
   MLMCPI_REQUIRE(act->Mt % 2 == 0 && act->Mx % 2 == 0, "multicolour sweeps need even Mt, Mx (got %u x %u)", act->Mt,
                  act->Mx);
@@ -1190,7 +1214,7 @@ static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, doub
         if (s + q >= n_overrelax) kinds |= 1u << q;
       // Schwinger: two link angles per site; GFF heat bath: field + parked normal per site
       g = choose_geometry(act->Mt, act->Mx, n, (schw || kinds) ? 16 : 8);
-      if (g.lds_bytes <= 160 * 1024 || n == 1) break;
+      if (g.lds_bytes <= 160 * 1024 - 256 || n == 1) break;
       --n;
     }
     const RngKey key = make_key(seed, chain0, sweep0 + s);
@@ -1268,7 +1292,16 @@ static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, doub
       rc = MLMCPI_OK;
     } else
     // launches without a heat-bath sweep use the lean instantiation (no sampler code, fewer VGPRs)
-    if (schw)
+    if (schw && kinds && qoi_kind && s + n == total) {  // the last launch of the draw: sum the QoI while the tile is in LDS
+      void *partial = nullptr;
+      if (int rcs = scratch((size_t)B * grid.x * sizeof(double), &partial, st)) return rcs;
+      const int op = qoi_kind == 1 ? (int)L_PLAQ : (int)L_CHARGE;
+      rc = launch_sweep<true, true>(g, grid, st, act->Mt, act->Mx, act->beta, src, dst, n, kinds, key, op, (double *)partial);
+      if (rc) return rc;
+      hipLaunchKernelGGL(lattice_finish_kernel, dim3((B + 255) / 256), dim3(256), 0, st, (const double *)partial, grid.x, B, op,
+                         1.0 / ((double)act->Mx * act->Mt), d_qoi);
+      MLMCPI_LAUNCH_CHECK("lattice_finish_kernel");
+    } else if (schw)
       rc = kinds ? launch_sweep<true, true>(g, grid, st, act->Mt, act->Mx, act->beta, src, dst, n, kinds, key)
                  : launch_sweep<true, false>(g, grid, st, act->Mt, act->Mx, act->beta, src, dst, n, kinds, key);
     else
@@ -1309,6 +1342,15 @@ int mlmcpi_lattice_sweep_draw_from(const mlmcpi_lattice_action *act, const doubl
   // the input is only ever the `src` of the first launch (or a work buffer when the caller passes d_w1 == d_src)
   return sweep_draw_impl(act, const_cast<double *>(d_src), d_w0, d_w1, B, n_overrelax, n_heatbath, seed, chain0, sweep0, fuse,
                          result_in, stream);
+}
+
+int mlmcpi_lattice_sweep_draw_qoi(const mlmcpi_lattice_action *act, const double *d_src, double *d_w0, double *d_w1, uint32_t B,
+                                  uint32_t n_overrelax, uint32_t n_heatbath, uint64_t seed, uint32_t chain0, uint32_t sweep0,
+                                  uint32_t fuse, int32_t qoi_kind, double *d_qoi, int32_t *result_in, void *stream) {
+  MLMCPI_REQUIRE(result_in, "result_in is NULL");
+  MLMCPI_REQUIRE(qoi_kind == 1 || qoi_kind == 2, "qoi_kind %d: 1 = average plaquette, 2 = Q^2 / (4 pi^2)", qoi_kind);
+  return sweep_draw_impl(act, const_cast<double *>(d_src), d_w0, d_w1, B, n_overrelax, n_heatbath, seed, chain0, sweep0, fuse,
+                         result_in, stream, qoi_kind, d_qoi);
 }
 
 int mlmcpi_qoi_phi_squared(const double *d_phi, uint32_t n_vertices, uint32_t B, double *d_out, void *stream) {

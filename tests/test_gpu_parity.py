@@ -773,6 +773,25 @@ def test_schwinger_gaussian_cfa_twolevel_step_matches_oracle(gpu_ops, orc, Mt, M
         theta = step.theta.cpu().numpy().copy()
 
 
+@pytest.mark.parametrize("Mt,Mx,B,n_or,n_hb", [(1024, 1024, 2, 2, 1), (64, 64, 3, 0, 1), (48, 20, 2, 3, 2), (128, 64, 2, 1, 1)])
+def test_fused_qoi_equals_separate_evaluation(gpu_ops, Mt, Mx, B, n_or, n_hb):
+    """mlmcpi_lattice_sweep_draw_qoi: the QoI summed inside the draw's last launch equals the stand-alone QoI kernels on
+    the same result (average plaquette and Q^2 / 4 pi^2), and the state is the one the plain draw produces, bit for bit;
+    a draw that does not end with a heat-bath sweep is refused."""
+    from mlmcpathintegral_amd import abi
+    act = abi.lattice_action(abi.SCHWINGER, Mt, Mx, beta=1.0)
+    x0 = gpu_ops.lattice_initialise(act, B, SEED, 3)
+    plain = x0.clone()
+    gpu_ops.lattice_sweep_draw(act, plain, torch.empty_like(plain), n_or, n_hb, SEED, 3, 11)
+    for kind, ref in ((1, gpu_ops.qoi_avg_plaquette(plain, Mt, Mx)), (2, gpu_ops.qoi_2d_susceptibility(plain, Mt, Mx))):
+        src = x0.clone()
+        res, _, q = gpu_ops.lattice_sweep_draw_qoi(act, src, torch.empty_like(src), src, n_or, n_hb, SEED, 3, 11, kind)
+        assert torch.equal(res, plain)
+        assert_close(q.cpu().numpy(), ref.cpu().numpy(), tol=1e-12 if kind == 1 else 1e-10, what=f"fused QoI {kind}")
+    with pytest.raises(abi.MlmcpiError):
+        gpu_ops.lattice_sweep_draw_qoi(act, x0, torch.empty_like(x0), x0.clone(), 2, 0, SEED, 3, 11, 1)
+
+
 def test_schwinger_twolevel_step_errors(gpu_ops):
     from mlmcpathintegral_amd import abi
     f = abi.lattice_action(4, 16, 16, beta=1.0)
