@@ -159,9 +159,13 @@ int main(int argc, char **argv) {
     auto phi_state = std::make_shared<SampleState>(action->sample_size(), batch);
     DeviceVector q(batch), acc(5 * (size_t)batch);
     const unsigned n_samples = (unsigned)num("n_samples"), warmup = (unsigned)num("warmup");
+    auto sweeper = std::dynamic_pointer_cast<OverrelaxedHeatBathSampler>(sampler);
+    const int fused = (sweeper && batch >= 8) ? qoi->fused_kind() : 0;  // small batches are latency bound: separate QoI
     auto one = [&]() {
-      sampler->draw(phi_state);
-      qoi->evaluate_device(phi_state, (double *)q.ptr());
+      if (!(fused && sweeper->draw_with_qoi(phi_state, fused, (double *)q.ptr()))) {
+        sampler->draw(phi_state);
+        qoi->evaluate_device(phi_state, (double *)q.ptr());
+      }
       check(mlmcpi_stats_accumulate((double *)acc.ptr(), (const double *)q.ptr(), batch, nullptr), "stats_accumulate");
     };
     for (unsigned i = 0; i < warmup; ++i) one();

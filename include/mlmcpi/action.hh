@@ -54,6 +54,9 @@ public:
   virtual int sweep_from(const double *, double *, double *, unsigned, unsigned, unsigned, uint32_t) {
     fatal("overrelaxation update not implemented for this action");
   }
+  /** sweep_from with the QoI of the new sample summed inside the last launch (qoi_kind: QoI::fused_kind()); returns -1
+   *  when the action cannot fuse it (the caller then evaluates the QoI on its own) */
+  virtual int sweep_from_qoi(const double *, double *, double *, unsigned, unsigned, unsigned, uint32_t, int, double *) { return -1; }
   /** action.hh:130-143: transfers between this level and the next coarser / finer one */
   virtual void copy_from_coarse(const std::shared_ptr<SampleState>, std::shared_ptr<SampleState>) { fatal("cannot copy from coarse lattice."); }
   virtual void copy_from_fine(const std::shared_ptr<SampleState>, std::shared_ptr<SampleState>) { fatal("cannot copy from fine lattice."); }
@@ -274,6 +277,14 @@ public:
     int32_t where = 0;
     check(mlmcpi_lattice_sweep_draw_from(&abi, d_src, d_w0, d_w1, batch, n_or, n_hb, seed, chain0, sweep0, fuse, &where, nullptr),
           "lattice_sweep_draw_from");
+    return where;
+  }
+  int sweep_from_qoi(const double *d_src, double *d_w0, double *d_w1, unsigned batch, unsigned n_or, unsigned n_hb, uint32_t sweep0,
+                     int qoi_kind, double *d_q) override {
+    if (abi.kind != MLMCPI_SCHWINGER || n_hb == 0 || qoi_kind == 0) return -1;
+    int32_t where = 0;
+    check(mlmcpi_lattice_sweep_draw_qoi(&abi, d_src, d_w0, d_w1, batch, n_or, n_hb, seed, chain0, sweep0, fuse, qoi_kind, d_q, &where,
+                                        nullptr), "lattice_sweep_draw_qoi");
     return where;
   }
   /** quenchedschwingeraction.cc:92-195, gffaction.cc:97-118: `this` is the level being written to */

@@ -23,6 +23,8 @@ public:
   }
   /** d_out[b] = Q(chain b), enqueued on the default stream */
   virtual void evaluate_device(const std::shared_ptr<SampleState> phi_state, double *d_out) = 0;
+  /** selector of mlmcpi_lattice_sweep_draw_qoi for QoIs a sweep sampler can sum inside its last launch (0: none) */
+  virtual int fused_kind() const { return 0; }
 
 private:
   std::unique_ptr<DeviceVector> out;
@@ -64,6 +66,7 @@ private:
 class QoI2DSusceptibility : public QoI {
 public:
   explicit QoI2DSusceptibility(const std::shared_ptr<Lattice2D> lattice) : Mt_lat(lattice->getMt_lat()), Mx_lat(lattice->getMx_lat()) {}
+  int fused_kind() const override { return 2; }
   void evaluate_device(const std::shared_ptr<SampleState> phi, double *d_out) override {
     if (phi->size() != 2 * Mt_lat * Mx_lat) fatal("Evaluating QoI2DSusceptibility on state of wrong size.");
     check(mlmcpi_qoi_2d_susceptibility(phi->device(), Mt_lat, Mx_lat, phi->batch(), d_out, nullptr), "qoi_2d_susceptibility");
@@ -76,6 +79,7 @@ private:
 class QoIAvgPlaquette : public QoI {
 public:
   explicit QoIAvgPlaquette(const std::shared_ptr<Lattice2D> lattice) : Mt_lat(lattice->getMt_lat()), Mx_lat(lattice->getMx_lat()) {}
+  int fused_kind() const override { return 1; }
   void evaluate_device(const std::shared_ptr<SampleState> phi, double *d_out) override {
     if (phi->size() != 2 * Mt_lat * Mx_lat) fatal("Evaluating QoIAvgPlaquette on state of wrong size.");
     check(mlmcpi_qoi_avg_plaquette(phi->device(), Mt_lat, Mx_lat, phi->batch(), d_out, nullptr), "qoi_avg_plaquette");

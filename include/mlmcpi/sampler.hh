@@ -198,8 +198,16 @@ public:
     advance();
     if (phi_state != phi_state_cur) phi_state->share(*phi_state_cur);
   }
+  /** draw + QoI in one pass over the state: d_q[b] = the QoI (QoI::fused_kind()) of the new sample, summed inside the
+   *  draw's last launch.  Returns false (and does nothing) when the action cannot fuse it. */
+  bool draw_with_qoi(std::shared_ptr<SampleState> phi_state, int qoi_kind, double *d_q) {
+    if (!advance(qoi_kind, d_q)) return false;
+    if (phi_state != phi_state_cur) phi_state->share(*phi_state_cur);
+    return true;
+  }
   /** the draw without handing the sample out (callers that read current_state()) */
-  void advance() {
+  bool advance(int qoi_kind = 0, double *d_q = nullptr) {
+    if (qoi_kind && n_sweep_heatbath == 0) return false;
     if (n_sweep_overrelax + n_sweep_heatbath > 0) {
       std::shared_ptr<DeviceBuffer> src = phi_state_cur->buffer();
       // `src` is held by phi_state_cur, by this local variable and by the pool if it came from there: one holder more
@@ -209,14 +217,18 @@ public:
       const bool src_is_lent = src.use_count() > own;
       std::shared_ptr<DeviceBuffer> w0 = free_buffer(src, nullptr);
       std::shared_ptr<DeviceBuffer> w1 = src_is_lent ? free_buffer(src, w0) : src;
-      const int where = action->sweep_from(src->p, w0->p, w1->p, phi_state_cur->batch(), n_sweep_overrelax, n_sweep_heatbath,
-                                           sweep_counter);
+      const int where = qoi_kind ? action->sweep_from_qoi(src->p, w0->p, w1->p, phi_state_cur->batch(), n_sweep_overrelax,
+                                                          n_sweep_heatbath, sweep_counter, qoi_kind, d_q)
+                                 : action->sweep_from(src->p, w0->p, w1->p, phi_state_cur->batch(), n_sweep_overrelax,
+                                                      n_sweep_heatbath, sweep_counter);
+      if (where < 0) return false;
       phi_state_cur->adopt(where == 0 ? w0 : w1);
     }
     sweep_counter += n_sweep_overrelax + n_sweep_heatbath;
     accept = true;
     n_total_samples++;
     n_accepted_samples++;
+    return true;
   }
   void set_state(std::shared_ptr<SampleState> phi_state) override { phi_state_cur->data = phi_state->data; }
   std::shared_ptr<SampleState> current_state() { return phi_state_cur; }
