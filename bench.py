@@ -460,6 +460,7 @@ def stats_allreduce(packed, rank, world, local, backend, torch, dist, chains):
 
         def work():
             try:
+                torch.cuda.set_device(local)  # the current device is thread local: this thread starts on device 0
                 c = comm.Comm(rank, world, id128, local)
                 c.allreduce_sum_(buf)
                 torch.cuda.synchronize()

@@ -77,6 +77,11 @@ int mlmcpi_copy_h2d(void *d_dst, const void *src, size_t bytes, void *stream);
 int mlmcpi_copy_d2h(void *dst, const void *d_src, size_t bytes, void *stream);
 int mlmcpi_copy_d2d(void *d_dst, const void *d_src, size_t bytes, void *stream);
 int mlmcpi_stream_synchronize(void *stream);
+/* Tuning knobs -- they never change results.  Read from the environment once, at the first use in the process; this call
+ * changes one afterwards (value "" or NULL resets it): MLMCPI_SWEEP_TILE=TWxTHxNT (tile and workgroup size of the generic
+ * sweep kernels; also forces them), MLMCPI_OR_KERNEL=lds|patch (LDS-resident or register-tiled overrelaxation kernels),
+ * MLMCPI_OR_THREADS=256|512|1024 (workgroup size of the LDS-resident kernel). */
+int mlmcpi_set_option(const char *name, const char *value);
 
 /* ---- index maps (host, integer, bit-exact) --------------------------------------------------
  * lattice/lattice2d.hh:230-268 (vertex), :348-375 (link); rotated != 0 selects the 45-degree

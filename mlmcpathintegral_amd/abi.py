@@ -46,6 +46,7 @@ SIGNATURES = {
     "mlmcpi_copy_d2h": (_i, [_vp, _vp, _sz, _vp]),
     "mlmcpi_copy_d2d": (_i, [_vp, _vp, _sz, _vp]),
     "mlmcpi_stream_synchronize": (_i, [_vp]),
+    "mlmcpi_set_option": (_i, [C.c_char_p, C.c_char_p]),
     "mlmcpi_vertex_cart2lin": (_u32, [_u32, _u32, _i, _i, _i]),
     "mlmcpi_vertex_lin2cart": (None, [_u32, _u32, _i, _u32, C.POINTER(_i), C.POINTER(_i)]),
     "mlmcpi_link_cart2lin": (_u32, [_u32, _u32, _i, _i, _i]),
@@ -146,3 +147,8 @@ def path_action(kind, M, T_final, m0=1.0, mu2=1.0, lam=0.0, x0=0.0):
 
 def lattice_action(kind, Mt, Mx, beta=0.0, mass=0.0):
     return LatticeAction(kind, Mt, Mx, beta, mass)
+
+
+def set_option(name, value=""):
+    """tuning knob of the library (never changes results): see mlmcpi_set_option in include/mlmcpi_hip.h"""
+    call("mlmcpi_set_option", name.encode(), (value or "").encode())

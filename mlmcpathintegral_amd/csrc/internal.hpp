@@ -41,6 +41,15 @@ inline RngKey make_key(uint64_t seed, uint32_t chain0, uint32_t step) {
   return RngKey{(uint32_t)seed, (uint32_t)(seed >> 32), chain0, step};
 }
 
+// Tuning knobs (they never change results): read from the environment ONCE, at the first sweep call of the process, and
+// settable afterwards through mlmcpi_set_option (tests flip them between calls).
+struct Tuning {
+  uint32_t tile_w = 0, tile_h = 0, tile_nt = 0;  // MLMCPI_SWEEP_TILE=TWxTHxNT (0: default geometry)
+  bool or_lds = false;                           // MLMCPI_OR_KERNEL=lds: LDS-resident instead of register-tiled overrelaxation
+  uint32_t or_threads = 0;                       // MLMCPI_OR_THREADS (LDS-resident kernel's workgroup size; 0: default)
+};
+const Tuning &tuning();
+
 constexpr uint32_t kMaxFuse = 16;  // max sweeps fused in one launch (kinds travel in a bitmask)
 
 }  // namespace mlmcpi

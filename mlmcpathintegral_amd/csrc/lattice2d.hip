@@ -1020,13 +1020,10 @@ struct SweepGeom {
 static SweepGeom choose_geometry(uint32_t Mt, uint32_t Mx, uint32_t nsweeps, uint32_t bytes_per_cell) {
   uint32_t TW = 64, TH = 32, NT = 256;
   bool overridden = false;
-  if (const char *e = getenv("MLMCPI_SWEEP_TILE")) {
-    unsigned a = 0, b = 0, c = 0;
-    if (sscanf(e, "%ux%ux%u", &a, &b, &c) == 3 && a >= 2 && b >= 2 && a % 2 == 0 && b % 2 == 0 &&
-        (c == 256 || c == 512 || c == 1024)) {
-      TW = a; TH = b; NT = c;
-      overridden = true;
-    }
+  const Tuning &tune = tuning();
+  if (tune.tile_w) {
+    TW = tune.tile_w; TH = tune.tile_h; NT = tune.tile_nt;
+    overridden = true;
   }
   SweepGeom g;
   g.overridden = overridden;
@@ -1228,8 +1225,7 @@ static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, doub
       double2 *out2 = (double2 *)dst;
       // more fused sweeps -> larger LDS image -> fewer resident workgroups: keep the wave count per CU up
       // with wider workgroups (MLMCPI_OR_THREADS overrides: tuning knob)
-      const char *or_env = getenv("MLMCPI_OR_KERNEL");  // read per call: tests flip it
-      const bool use_patch = !(or_env && !strcmp(or_env, "lds"));
+      const bool use_patch = !tuning().or_lds;
       if (use_patch && n <= 4) {  // register-tiled kernel (MLMCPI_OR_KERNEL=lds selects the LDS-resident one)
         const uint32_t np = ((64 + 4 * n) / 2) * ((32 + 4 * n) / 2);
         const dim3 pblock((np + 63) / 64 * 64);
@@ -1246,7 +1242,7 @@ static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, doub
         continue;
       }
       uint32_t nt_or = n >= 4 ? 1024 : 512;  // measured best (tools/scan_or.sh): K <= 3: 512, K >= 4: 1024
-      if (const char *e = getenv("MLMCPI_OR_THREADS")) { unsigned v = (unsigned)atoi(e); if (v == 256 || v == 512 || v == 1024) nt_or = v; }
+      if (tuning().or_threads) nt_or = tuning().or_threads;
 #define MLMCPI_OR(KK, NN) hipLaunchKernelGGL((schwinger_or_kernel<64, 32, KK, NN>), sgrid, dim3(NN), lds, st, act->Mt, act->Mx, in2, out2, act->Mt / 64)
 #define MLMCPI_OR_K(KK) do { if (nt_or == 1024) MLMCPI_OR(KK, 1024); else if (nt_or == 512) MLMCPI_OR(KK, 512); else MLMCPI_OR(KK, 256); } while (0)
       switch (n) {
@@ -1265,8 +1261,7 @@ static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, doub
       const size_t lds = (size_t)(32 + 4 * n) * (64 + 4 * n + 1) * sizeof(double);
       dim3 sgrid((act->Mt / 64) * (act->Mx / 32), B);
       const double mu2 = gff_mu2(*act);
-      const char *or_env = getenv("MLMCPI_OR_KERNEL");
-      const bool use_gff_patch = !(or_env && !strcmp(or_env, "lds"));
+      const bool use_gff_patch = !tuning().or_lds;
       if (use_gff_patch) {  // register-tiled kernel (MLMCPI_OR_KERNEL=lds selects the LDS-resident one)
         const uint32_t np = ((64 + 4 * n) / 2) * ((32 + 4 * n) / 2);
         const dim3 pblock((np + 63) / 64 * 64);

@@ -3,9 +3,11 @@
 // lattice/lattice2d.cc:137-155), RNG test hooks.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
+#include <string>
 #include <vector>
 
 #include "internal.hpp"
@@ -66,6 +68,49 @@ int scratch(size_t bytes, void **d_ptr, hipStream_t stream) {
   }
   *d_ptr = slot->ptr;
   return MLMCPI_OK;
+}
+
+// ---- tuning knobs -----------------------------------------------------------------------------------
+namespace {
+std::mutex g_tuning_mutex;
+Tuning g_tuning;
+bool g_tuning_loaded = false;
+
+bool apply_option(Tuning &t, const char *name, const char *value) {
+  const std::string n = name ? name : "", v = value ? value : "";
+  if (n == "MLMCPI_SWEEP_TILE") {
+    unsigned a = 0, b = 0, c = 0;
+    t.tile_w = t.tile_h = t.tile_nt = 0;
+    if (v.empty()) return true;
+    if (sscanf(v.c_str(), "%ux%ux%u", &a, &b, &c) == 3 && a >= 2 && b >= 2 && a % 2 == 0 && b % 2 == 0 && (c == 256 || c == 512 || c == 1024)) {
+      t.tile_w = a; t.tile_h = b; t.tile_nt = c;
+      return true;
+    }
+    return false;
+  }
+  if (n == "MLMCPI_OR_KERNEL") {
+    t.or_lds = v == "lds";
+    return v.empty() || v == "lds" || v == "patch";
+  }
+  if (n == "MLMCPI_OR_THREADS") {
+    const unsigned x = (unsigned)atoi(v.c_str());
+    t.or_threads = (x == 256 || x == 512 || x == 1024) ? x : 0;
+    return v.empty() || t.or_threads != 0;
+  }
+  return false;
+}
+void load_tuning_locked() {
+  if (g_tuning_loaded) return;
+  for (const char *name : {"MLMCPI_SWEEP_TILE", "MLMCPI_OR_KERNEL", "MLMCPI_OR_THREADS"})
+    if (const char *e = getenv(name)) apply_option(g_tuning, name, e);
+  g_tuning_loaded = true;
+}
+}  // namespace
+
+const Tuning &tuning() {
+  std::lock_guard<std::mutex> lock(g_tuning_mutex);
+  load_tuning_locked();
+  return g_tuning;
 }
 
 // ---- test kernels ------------------------------------------------------------------------------
@@ -227,6 +272,13 @@ int mlmcpi_neighbours_2d(uint32_t Mt, uint32_t Mx, int rotated, uint32_t *out) {
       out[8 * ell + k] = mlmcpi_vertex_cart2lin(Mt, Mx, rotated, i + s[0], j + s[1]);
     }
   }
+  return MLMCPI_OK;
+}
+
+int mlmcpi_set_option(const char *name, const char *value) {
+  std::lock_guard<std::mutex> lock(g_tuning_mutex);
+  load_tuning_locked();
+  if (!apply_option(g_tuning, name, value)) return fail(MLMCPI_ERR_INVALID, "unknown option or value: %s=%s", name ? name : "(null)", value ? value : "(null)");
   return MLMCPI_OK;
 }
 

@@ -648,23 +648,23 @@ def test_schwinger_1024_properties(gpu_ops, orc, golden):
     gpu_ops.lattice_sweep_draw(act, b1, scratch, 4, 2, SEED, 0, 0, fuse=3)
     assert torch.equal(a, b1), "fused and unfused sweeps must agree bit for bit"
     # the specialised overrelaxation kernel (compile-time tile geometry) against the generic one
-    os.environ["MLMCPI_SWEEP_TILE"] = "64x32x256"
+    abi.set_option("MLMCPI_SWEEP_TILE", "64x32x256")
     try:
         gen = x.clone()
         gpu_ops.lattice_sweep_draw(act, gen, scratch, 4, 2, SEED, 0, 0, fuse=2)
     finally:
-        del os.environ["MLMCPI_SWEEP_TILE"]
+        abi.set_option("MLMCPI_SWEEP_TILE", "")
     assert torch.equal(a, gen), "specialised and generic sweep kernels must agree bit for bit"
     # library default (4 overrelaxation sweeps per launch, register-tiled kernel) and the LDS-resident kernel
     d4 = x.clone()
     gpu_ops.lattice_sweep_draw(act, d4, scratch, 4, 2, SEED, 0, 0, fuse=0)
     assert torch.equal(a, d4), "the default fusion depth must not change the result"
-    os.environ["MLMCPI_OR_KERNEL"] = "lds"
+    abi.set_option("MLMCPI_OR_KERNEL", "lds")
     try:
         lds4 = x.clone()
         gpu_ops.lattice_sweep_draw(act, lds4, scratch, 4, 2, SEED, 0, 0, fuse=4)
     finally:
-        del os.environ["MLMCPI_OR_KERNEL"]
+        abi.set_option("MLMCPI_OR_KERNEL", "")
     assert torch.equal(a, lds4), "register-tiled and LDS-resident overrelaxation kernels must agree bit for bit"
     single = x[1:2].clone()
     gpu_ops.lattice_sweep_draw(act, single, torch.empty_like(single), 4, 2, SEED, 1, 0, fuse=2)
@@ -692,19 +692,19 @@ def test_rotor_65536_and_gff_512_properties(gpu_ops):
     gpu_ops.lattice_sweep_draw(act, a, scratch, 6, 1, SEED, 0, 0, fuse=1)
     gpu_ops.lattice_sweep_draw(act, b, scratch, 6, 1, SEED, 0, 0, fuse=4)
     assert torch.equal(a, b)
-    os.environ["MLMCPI_SWEEP_TILE"] = "64x32x256"  # generic kernels
+    abi.set_option("MLMCPI_SWEEP_TILE", "64x32x256")  # generic kernels
     try:
         gen = phi.clone()
         gpu_ops.lattice_sweep_draw(act, gen, scratch, 6, 1, SEED, 0, 0, fuse=2)
     finally:
-        del os.environ["MLMCPI_SWEEP_TILE"]
+        abi.set_option("MLMCPI_SWEEP_TILE", "")
     assert torch.equal(a, gen), "specialised and generic GFF kernels must agree bit for bit"
-    os.environ["MLMCPI_OR_KERNEL"] = "lds"
+    abi.set_option("MLMCPI_OR_KERNEL", "lds")
     try:
         lds4 = phi.clone()
         gpu_ops.lattice_sweep_draw(act, lds4, scratch, 6, 1, SEED, 0, 0, fuse=4)
     finally:
-        del os.environ["MLMCPI_OR_KERNEL"]
+        abi.set_option("MLMCPI_OR_KERNEL", "")
     assert torch.equal(a, lds4), "register-tiled and LDS-resident GFF overrelaxation kernels must agree bit for bit"
     c = phi.clone()
     gpu_ops.lattice_sweep_draw(act, c, scratch, 6, 0, SEED, 0, 0, fuse=3)
