@@ -134,9 +134,14 @@ class SweepWorkload:
         self.x = ops.lattice_initialise(self.act, B, a.seed, chain0)
         self.scratch = torch.empty_like(self.x)
         self.acc = torch.zeros((B, 5), dtype=torch.float64, device="cuda")
-        self.fuse = a.fuse or 4  # library default
+        # the library's launch plan for the overrelaxation sweeps (lattice2d.hip, sweep_draw_impl): where the 4 x 4
+        # register-block kernel applies, up to 6 sweeps per launch in launches of equal depth (10 -> 5 + 5); otherwise
+        # launches of 4 and a remainder (10 -> 4 + 4 + 2)
+        self.blocks = (kind == "schwinger" and size % 64 == 0 and os.environ.get("MLMCPI_OR_KERNEL", "") in ("", "block")
+                       and not os.environ.get("MLMCPI_SWEEP_TILE"))
+        self.fuse = a.fuse or (6 if self.blocks else 4)
+        self.plan = or_plan(a.n_overrelax, self.fuse, self.blocks)   # [(depth, launches), ...], at most two entries
         self.sweep = 0
-        self.n_full = (a.n_overrelax // self.fuse) * self.fuse
         self.ev = {"or": [], "rem": [], "hb": [], "qoi": []}
 
     def qoi(self):
@@ -150,18 +155,19 @@ class SweepWorkload:
         if record:
             e = [E() for _ in range(5)]
             e[0].record()
-        # same arithmetic as one call with (n_overrelax, n_heatbath); split only to time the kernels (ping-pong form:
-        # the buffers swap roles instead of being copied back).  Overrelaxation sweeps: full launches of `fuse` sweeps
-        # (timed as one kernel) + a remainder launch.
-        cur, oth = ops.lattice_sweep_draw_pingpong(self.act, self.x, self.scratch, self.n_full, 0, a.seed, self.chain0,
-                                                   s, self.fuse)
+        # same arithmetic and the same launches as one call with (n_overrelax, n_heatbath); split only to time the
+        # kernels (ping-pong form: the buffers swap roles instead of being copied back).  Overrelaxation sweeps: one
+        # call per launch depth of the library's plan.
+        cur, oth, done = self.x, self.scratch, 0
+        for k, (depth, launches) in enumerate(self.plan):
+            cur, oth = ops.lattice_sweep_draw_pingpong(self.act, cur, oth, depth * launches, 0, a.seed, self.chain0,
+                                                       s + done, depth)
+            done += depth * launches
+            if record:
+                e[1 + k].record()
         if record:
-            e[1].record()
-        if a.n_overrelax - self.n_full:
-            cur, oth = ops.lattice_sweep_draw_pingpong(self.act, cur, oth, a.n_overrelax - self.n_full, 0, a.seed,
-                                                       self.chain0, s + self.n_full, self.fuse)
-        if record:
-            e[2].record()
+            for k in range(len(self.plan), 2):
+                e[1 + k].record()
         # fused QoI: one pass over the state less (-0.045 ms per step at 32 chains); a single chain is latency bound and
         # does better with the stand-alone reduction (0.122 vs 0.144 ms per step), so small batches keep it
         self.fused = self.kind == "schwinger" and a.n_heatbath > 0 and not a.no_fused_qoi and self.B >= 8
@@ -181,6 +187,26 @@ class SweepWorkload:
             self.ev["hb"].append((e[2], e[3]))
             self.ev["qoi"].append((e[3], e[4]))
         self.sweep = s + a.n_overrelax + a.n_heatbath
+
+
+def or_plan(n_overrelax, fuse, blocks):
+    """Launch depths of n_overrelax overrelaxation sweeps as sweep_draw_impl issues them, grouped: [(depth, launches)]."""
+    depths, rem = [], n_overrelax
+    while rem:
+        n = min(rem, fuse)
+        if blocks:
+            launches = -(-rem // fuse)
+            n = -(-rem // launches)
+        depths.append(n)
+        rem -= n
+    plan = []
+    for d in depths:
+        if plan and plan[-1][0] == d:
+            plan[-1] = (d, plan[-1][1] + 1)
+        else:
+            plan.append((d, 1))
+    assert len(plan) <= 2, plan
+    return plan
 
 
 def time_steps(torch, dist, world, step, steps, warmup):
@@ -509,20 +535,29 @@ def report_sweeps(result, a, W, size, B, world, step_ms, ms):
     """Per-kernel records and the roofline of the dominant kernel for the 2-D sweep workloads."""
     fuse, sites = W.fuse, W.sites
     state_rw = 16.0 * sites * B          # one read + one write of the whole state: the HBM floor of ANY launch
-    n_launch = a.n_overrelax // fuse     # full launches of `fuse` overrelaxation sweeps
-    rem = a.n_overrelax - n_launch * fuse
     special = size % 64 == 0 and fuse <= (6 if a.workload == "schwinger" else 4)
     lds_kernel = os.environ.get("MLMCPI_OR_KERNEL") == "lds"
+
+    def or_name(depth):
+        if a.workload == "schwinger":
+            if not special:
+                return "schwinger_sweep_kernel<false,256>"
+            if W.blocks:
+                return f"schwinger_or_block_kernel<{depth}>"
+            return (f"schwinger_or_patch_kernel<{depth}>" if depth <= 4 and not lds_kernel
+                    else f"schwinger_or_kernel<64,32,{depth},{1024 if depth >= 4 else 512}>")
+        if not special:
+            return "gff_sweep_kernel<false,256>"
+        return f"gff_or_patch_kernel<{depth}>" if not lds_kernel else f"gff_or_kernel<64,32,{depth},256>"
+
     if a.workload == "schwinger":
-        or_name = (f"schwinger_or_patch_kernel<{fuse}>" if fuse <= 4 and not lds_kernel
-                   else f"schwinger_or_kernel<64,32,{fuse},{1024 if fuse >= 4 else 512}>") if special else "schwinger_sweep_kernel<false,256>"
         hb_name = "schwinger_sweep_kernel<true,256,64,32>" if (size % 64 == 0 and size >= 128 and a.n_heatbath == 1) else "schwinger_sweep_kernel<true,256,0,0>"
     else:
-        or_name = (f"gff_or_patch_kernel<{fuse}>" if not lds_kernel else f"gff_or_kernel<64,32,{fuse},256>") if special else "gff_sweep_kernel<false,256>"
         hb_name = "gff_sweep_kernel<true,256>"
     result["config"] = {"workload": f"{a.workload} {size}x{size}, {a.n_overrelax} overrelaxation + {a.n_heatbath} heat-bath "
                                     "sweeps + QoI + record_sample per step, multicolour order",
                         "chains_per_gpu": B, "chains_total": B * world, "fuse": fuse,
+                        "overrelaxation_launches": [d for d, n in W.plan for _ in range(n)],
                         "parallelism": f"chains sharded over {world} GPU(s), no data-path collective"}
     kernels = []
 
@@ -548,13 +583,10 @@ def report_sweeps(result, a, W, size, B, world, step_ms, ms):
         return k
 
     wl = dict(workload=a.workload, size=size)
-    if n_launch:
-        record(or_name, f"{fuse} fused overrelaxation sweeps", W.ev["or"], n_launch, fuse, state_rw,
-               pmc_entry("entries", chains=B, fuse=fuse, kind="overrelax", **wl), pmc_entry("valu", kind="overrelax", fuse=fuse, **wl))
-    if rem:
-        rem_name = or_name.replace(f"<{fuse}>", f"<{rem}>") if "patch" in or_name else or_name
-        record(rem_name, f"{rem} fused overrelaxation sweeps (remainder launch)", W.ev["rem"], 1, rem, state_rw,
-               pmc_entry("entries", chains=B, fuse=rem, kind="overrelax", **wl), pmc_entry("valu", kind="overrelax", fuse=rem, **wl))
+    for k, (depth, launches) in enumerate(W.plan):
+        record(or_name(depth), f"{depth} fused overrelaxation sweeps", W.ev["or" if k == 0 else "rem"], launches, depth, state_rw,
+               pmc_entry("entries", chains=B, fuse=depth, kind="overrelax", **wl),
+               pmc_entry("valu", kind="overrelax", fuse=depth, **wl))
     if a.n_heatbath:
         record(hb_name, "heat-bath sweep", W.ev["hb"], a.n_heatbath, 1, state_rw,
                pmc_entry("entries", chains=B, fuse=1, kind="heatbath", **wl), pmc_entry("valu", kind="heatbath", **wl))
@@ -588,7 +620,7 @@ def report_sweeps(result, a, W, size, B, world, step_ms, ms):
     result["roofline"] = roof
     # whole step: 16 B x every update of the step against the step time, and the bytes the step's launches cannot avoid
     alg_step = 16.0 * sites * B * (a.n_overrelax + a.n_heatbath)
-    floor_step = state_rw * (n_launch + (1 if rem else 0) + a.n_heatbath) + (0.0 if fused else 0.5 * state_rw)
+    floor_step = state_rw * (sum(n for _, n in W.plan) + a.n_heatbath) + (0.0 if fused else 0.5 * state_rw)
     result["whole_step"] = {"algorithmic_bytes": alg_step, "algorithmic_GBps": alg_step / (step_ms * 1e-3) / 1e9,
                             "algorithmic_frac_of_peak": alg_step / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                             "hbm_floor_bytes": floor_step, "hbm_floor_GBps": floor_step / (step_ms * 1e-3) / 1e9,

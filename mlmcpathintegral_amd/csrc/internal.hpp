@@ -46,6 +46,7 @@ inline RngKey make_key(uint64_t seed, uint32_t chain0, uint32_t step) {
 struct Tuning {
   uint32_t tile_w = 0, tile_h = 0, tile_nt = 0;  // MLMCPI_SWEEP_TILE=TWxTHxNT (0: default geometry)
   bool or_lds = false;                           // MLMCPI_OR_KERNEL=lds: LDS-resident instead of register-tiled overrelaxation
+  bool or_patch = false;                         // MLMCPI_OR_KERNEL=patch: 2 x 2 register blocks on 64 x 32 tiles instead of 4 x 4 on 64 x 64
   uint32_t or_threads = 0;                       // MLMCPI_OR_THREADS (LDS-resident kernel's workgroup size; 0: default)
 };
 const Tuning &tuning();

@@ -502,6 +502,214 @@ __global__ void __launch_bounds__(1024)
   }
 }
 
+// ---- Schwinger overrelaxation, 4 x 4 register blocks on 64 x 64 tiles ------------------------------------------
+// The 2 x 2 kernel above recomputes (64 + 4K)(32 + 4K) / (64 * 32) = 1.875 x the owned updates at K = 4 and moves 24 B
+// through LDS per update.  Here a thread keeps a 4 x 4 block of vertices (32 link angles, 64 VGPRs) for all K sweeps and
+// the tile is 64 x 64: redundancy (64 + 4K)^2 / 64^2 = 1.56 at K = 4 (1.72 at K = 5, which the 1024-thread limit of the
+// 2 x 2 kernel could not reach), and LDS holds only the 20 values per block that a neighbouring block reads:
+//   TOP0[a], TOP1[a]   both links of the top row        (read by the block above as its row -1)
+//   BOT0[a]            mu = 0 links of the bottom row   (row PH of the block below)
+//   LEFT1[c]           mu = 1 links of the left column  (column PW of the block to the left)
+//   RIGHT0[c], RIGHT1[c]  both links of the right column (column -1 of the block to the right)
+// with the four corner values that belong to two of these lists stored once.  Per sweep a thread reads 32 and writes
+// 20 doubles for its 32 updates (13 B per update).  Planes are [value][block], so consecutive lanes touch consecutive
+// doubles.  Same updates in the same colour order with the same arithmetic as every other overrelaxation kernel here:
+// bit-identical results.  Block edges of the buffer read clamped neighbours, as in the 2 x 2 kernel: what they compute
+// is wrong, and never reaches the owned tile (the exact region shrinks by 2 sites per sweep from a halo of 2K).
+//
+// Measured on MI355X (1024 x 1024, 32 chains; tools/exp_or_block.py, timestamps taken inside the kernel): a sweep costs
+// 0.028 ms of the launch, which is the fp64 issue time of its 9 instructions per update, and the rest of the launch
+// (0.21 ms at K = 1, against 0.17 ms for a plain copy of the state) is the load and store phase of the workgroups,
+// which the two workgroups a CU holds overlap only partly with each other's sweeps.  Persistent workgroups and an
+// XCD-aware tile order changed nothing; writing the tile back in whole 1 KiB rows per wave instruction instead of
+// 16 B per lane at a 64 B stride took 0.02-0.035 ms off every launch (see the end of the kernel); doing the same for
+// the loads did not pay.  The K >= 4 launches run at the package power limit (1.37 kW, sclk 2.17-2.25 GHz).
+template <int K>
+struct OrBlockGeom {
+  static constexpr int TW = 64, TH = 64, PW = 4, PH = 4, H = 2 * K;
+  static constexpr int BW = TW + 2 * H, BH = TH + 2 * H, NPX = BW / PW, NPY = BH / PH, NP = NPX * NPY;
+  static constexpr int NT = (NP + 63) / 64 * 64;
+  static constexpr int NPLANE = 3 * PW + 3 * PH - 4;
+  static constexpr size_t lds_bytes = (size_t)NPLANE * NP * sizeof(double);
+  // plane numbers (corner values stored once)
+  static constexpr int top0(int a) { return a; }
+  static constexpr int top1(int a) { return PW + a; }
+  static constexpr int right0(int c) { return c == PH - 1 ? top0(PW - 1) : 3 * PW - 1 + (PH - 1) + c; }
+  static constexpr int right1(int c) { return c == PH - 1 ? top1(PW - 1) : 3 * PW - 1 + 2 * (PH - 1) + c; }
+  static constexpr int bot0(int a) { return a == PW - 1 ? right0(0) : 2 * PW + a; }
+  static constexpr int left1(int c) { return c == PH - 1 ? top1(0) : 3 * PW - 1 + c; }
+};
+
+template <int K>
+__global__ void __launch_bounds__(OrBlockGeom<K>::NT)
+    schwinger_or_block_kernel(uint32_t Mt, uint32_t Mx, const double2 *__restrict__ in, double2 *__restrict__ out,
+                              uint32_t tiles_x) {
+  using G = OrBlockGeom<K>;
+  constexpr int TW = G::TW, TH = G::TH, PW = G::PW, PH = G::PH, H = G::H, NPX = G::NPX, NPY = G::NPY, NP = G::NP;
+  extern __shared__ double lds[];
+  auto pl = [&](int p) { return lds + p * NP; };
+  const uint32_t tile = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
+  const uint32_t i0 = tx * TW, j0 = ty * TH;
+  const bool active = tid < NP;
+  const int pj = active ? (int)tid / NPX : 0, pi = active ? (int)tid - pj * NPX : 0;
+  const int me = active ? (int)tid : 0;  // idle threads of the last wave: every index is entry 0, nothing is written
+  // neighbour blocks, clamped into the buffer
+  const int dn = pj > 0 ? me - NPX : me, up = pj + 1 < NPY ? me + NPX : me;
+  const int lf = pi > 0 ? me - 1 : me, rt = pi + 1 < NPX ? me + 1 : me;
+  const int rtdn = (pi + 1 < NPX ? 1 : 0) + (pj > 0 ? -NPX : 0) + me;
+  const int lfup = (pi > 0 ? -1 : 0) + (pj + 1 < NPY ? NPX : 0) + me;
+  const double2 *src = in + (size_t)b * Mt * Mx;
+  double t0[PH][PW], t1[PH][PW];  // [c][a]: links of vertex (PW pi + a, PH pj + c)
+
+  // the block's columns in the lattice: H is even, so (gi, gi + 1) never straddles the wrap, (gi + 1, gi + 2) may
+  {
+    uint32_t gi[PW / 2], gj[PH];
+    gi[0] = (uint32_t)(((uint64_t)i0 + Mt - (H % Mt) + PW * pi) % Mt);
+    gj[0] = (uint32_t)(((uint64_t)j0 + Mx - (H % Mx) + PH * pj) % Mx);
+#pragma unroll
+    for (int a = 1; a < PW / 2; ++a) gi[a] = gi[a - 1] + 2 == Mt ? 0 : gi[a - 1] + 2;
+#pragma unroll
+    for (int c = 1; c < PH; ++c) gj[c] = gj[c - 1] + 1 == Mx ? 0 : gj[c - 1] + 1;
+#pragma unroll
+    for (int c = 0; c < PH; ++c)
+#pragma unroll
+      for (int a = 0; a < PW; a += 2) {
+        double2 v0 = make_double2(0, 0), v1 = v0;
+        if (active) {
+          v0 = src[(size_t)gj[c] * Mt + gi[a / 2]];
+          v1 = src[(size_t)gj[c] * Mt + gi[a / 2] + 1];
+        }
+        t0[c][a] = v0.x; t1[c][a] = v0.y; t0[c][a + 1] = v1.x; t1[c][a + 1] = v1.y;
+      }
+  }
+  // what a neighbour reads of link mu at (a, c): up to three lists, a corner value once
+  auto publish = [&](int mu, int a, int c, double v) {
+    const int p1 = c == PH - 1 ? (mu ? G::top1(a) : G::top0(a)) : -1;
+    const int p2 = mu == 0 ? (c == 0 ? G::bot0(a) : -1) : (a == 0 ? G::left1(c) : -1);
+    const int p3 = a == PW - 1 ? (mu ? G::right1(c) : G::right0(c)) : -1;
+    if (!active) return;
+    if (p1 >= 0) pl(p1)[me] = v;
+    if (p2 >= 0 && p2 != p1) pl(p2)[me] = v;
+    if (p3 >= 0 && p3 != p1 && p3 != p2) pl(p3)[me] = v;
+  };
+#pragma unroll
+  for (int c = 0; c < PH; ++c)
+#pragma unroll
+    for (int a = 0; a < PW; ++a) {
+      publish(0, a, c, t0[c][a]);
+      publish(1, a, c, t1[c][a]);
+    }
+  __syncthreads();
+
+  for (int s = 0; s < K; ++s) {
+    // row -1: t0(a, -1), t1(a, -1) for a = 0 .. PW (the last from the block below to the right);
+    // column PW: t1(PW, c) for c = -1 .. PH - 1 at index c + 1.  None of these changes during phases 0 and 1.
+    double dn0[PW], dn1[PW + 1], rt1[PH + 1];
+#pragma unroll
+    for (int a = 0; a < PW; ++a) {
+      dn0[a] = pl(G::top0(a))[dn];
+      dn1[a] = pl(G::top1(a))[dn];
+    }
+    dn1[PW] = pl(G::top1(0))[rtdn];
+    rt1[0] = dn1[PW];
+#pragma unroll
+    for (int c = 0; c < PH; ++c) rt1[c + 1] = pl(G::left1(c))[rt];
+    // phases 0, 1: mu = 0, even rows then odd rows
+    //   tp = t0(i, j+1) + t1(i, j) - t1(i+1, j),  tm = t0(i, j-1) + t1(i+1, j-1) - t1(i, j-1)
+    double up0[PW + 1];  // row PH: t0(a, PH) for a = -1 .. PW - 1 at index a + 1 (final after phase 0)
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+      if (par == 1) {
+#pragma unroll
+        for (int a = 0; a < PW; ++a) up0[a + 1] = pl(G::bot0(a))[up];
+        up0[0] = pl(G::bot0(PW - 1))[lfup];
+      }
+#pragma unroll
+      for (int c = par; c < PH; c += 2)
+#pragma unroll
+        for (int a = 0; a < PW; ++a) {
+          const double t0_up = c + 1 < PH ? t0[c + 1 < PH ? c + 1 : 0][a] : up0[a + 1];
+          const double t0_dn = c > 0 ? t0[c > 0 ? c - 1 : 0][a] : dn0[a];
+          const double t1_c = t1[c][a];
+          const double t1_r = a + 1 < PW ? t1[c][a + 1 < PW ? a + 1 : 0] : rt1[c + 1];
+          const double t1_dr = c > 0 ? (a + 1 < PW ? t1[c > 0 ? c - 1 : 0][a + 1 < PW ? a + 1 : 0] : rt1[c]) : dn1[a + 1];
+          const double t1_dc = c > 0 ? t1[c > 0 ? c - 1 : 0][a] : dn1[a];
+          const double tp = t0_up + t1_c - t1_r;
+          const double tm = t0_dn + t1_dr - t1_dc;
+          t0[c][a] = mod_2pi_fast((tp + tm) - t0[c][a]);
+          publish(0, a, c, t0[c][a]);
+        }
+      __syncthreads();
+    }
+    // column -1: t0(-1, c) for c = 0 .. PH (the last is up0[0]), t1(-1, c); final after phase 1
+    double lf0[PH + 1], lf1[PH];
+#pragma unroll
+    for (int c = 0; c < PH; ++c) {
+      lf0[c] = pl(G::right0(c))[lf];
+      lf1[c] = pl(G::right1(c))[lf];
+    }
+    lf0[PH] = up0[0];
+    // phases 2, 3: mu = 1, even columns then odd columns
+    //   tp = t0(i, j) + t1(i+1, j) - t0(i, j+1),  tm = t0(i-1, j+1) + t1(i-1, j) - t0(i-1, j)
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+      if (par == 1) {  // the right neighbour's column 0 changed in phase 2
+#pragma unroll
+        for (int c = 0; c < PH; ++c) rt1[c + 1] = pl(G::left1(c))[rt];
+      }
+#pragma unroll
+      for (int a = par; a < PW; a += 2)
+#pragma unroll
+        for (int c = 0; c < PH; ++c) {
+          const double t0_c = t0[c][a];
+          const double t1_r = a + 1 < PW ? t1[c][a + 1 < PW ? a + 1 : 0] : rt1[c + 1];
+          const double t0_u = c + 1 < PH ? t0[c + 1 < PH ? c + 1 : 0][a] : up0[a + 1];
+          const double t0_lu = a > 0 ? (c + 1 < PH ? t0[c + 1 < PH ? c + 1 : 0][a > 0 ? a - 1 : 0] : up0[a]) : lf0[c + 1];
+          const double t1_l = a > 0 ? t1[c][a > 0 ? a - 1 : 0] : lf1[c];
+          const double t0_l = a > 0 ? t0[c][a > 0 ? a - 1 : 0] : lf0[c];
+          const double tp = t0_c + t1_r - t0_u;
+          const double tm = t0_lu + t1_l - t0_l;
+          t1[c][a] = mod_2pi_fast((tp + tm) - t1[c][a]);
+          publish(1, a, c, t1[c][a]);
+        }
+      __syncthreads();
+    }
+  }
+
+  // Owned vertices: buffer columns [H, H + TW), rows [H, H + TH).  A thread holds PW consecutive vertices of a row
+  // (64 B), so storing block-wise would make every wave instruction write 64 x 16 B at a 64 B stride.  Instead each wave
+  // transposes through LDS (the plane area is dead after the last barrier; wave-private staging, no workgroup barrier):
+  // per block row c the owners put their four vertices down, and the wave writes the 256 vertices back as 4 coalesced
+  // instructions -- lane l takes vertex l & 3 of block 16 i + (l >> 2), i = 0 .. 3.
+  static_assert(PW == 4, "the coalesced side moves 4 vertices per block row");
+  const uint32_t wave0 = tid & ~63u, lane = tid & 63u;
+  double2 *stage = reinterpret_cast<double2 *>(lds) + (wave0 / 64) * (64 * PW);
+  double2 *dst = out + (size_t)b * Mt * Mx;
+  int uq[4], ur[4];  // tile coordinates of the vertex this lane writes for i = 0 .. 3 (row c = 0); uq < 0: none
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int bt = (int)wave0 + 16 * i + (int)(lane >> 2);
+    const int bj = bt / NPX, bi = bt - bj * NPX;
+    uq[i] = PW * bi + (int)(lane & 3) - H;
+    ur[i] = PH * bj - H;
+    if (bt >= NP || uq[i] >= TW) uq[i] = -1;
+  }
+#pragma unroll
+  for (int c = 0; c < PH; ++c) {
+#pragma unroll
+    for (int a = 0; a < PW; ++a) stage[PW * lane + a] = make_double2(t0[c][a], t1[c][a]);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const double2 w = stage[64 * i + lane];
+      const int r = ur[i] + c;
+      if (uq[i] >= 0 && r >= 0 && r < TH) dst[(size_t)(j0 + r) * Mt + (i0 + uq[i])] = w;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // ---- GFF sweeps --------------------------------------------------------------------------------------
 // Red/black order: (i+j) even, then odd.  gffaction.cc:33-42 (heat bath), :68-77 (overrelaxation);
 // Delta is summed in the order of the reference's neighbour table (+i, -i, +j, -j).
@@ -854,13 +1062,16 @@ __global__ void __launch_bounds__(256) schwinger_reduce_band_kernel(uint32_t Mt,
   if (threadIdx.x == 0) partial[(size_t)b * gridDim.x + blockIdx.x] = acc[0];
 }
 
-__global__ void lattice_finish_kernel(const double *__restrict__ partial, uint32_t nsplit, uint32_t B, int op,
-                                      double scale, double *__restrict__ out) {
-  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(256) lattice_finish_kernel(const double *__restrict__ partial, uint32_t nsplit, uint32_t B,
+                                                              int op, double scale, double *__restrict__ out) {
+  // one wave per chain: lane l sums partials l, l + 64, ... in order, then a fixed shuffle tree -- the result depends on
+  // nsplit only, never on the launch
+  const uint32_t b = blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64, lane = threadIdx.x % 64;
   if (b >= B) return;
   double s = 0.0;
-  for (uint32_t k = 0; k < nsplit; ++k) s += partial[(size_t)b * nsplit + k];
-  out[b] = (op == L_CHARGE) ? (1. / (4. * kPi * kPi)) * s * s : scale * s;  // qoi2dsusceptibility.cc:26
+  for (uint32_t k = lane; k < nsplit; k += 64) s += partial[(size_t)b * nsplit + k];
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if (lane == 0) out[b] = (op == L_CHARGE) ? (1. / (4. * kPi * kPi)) * s * s : scale * s;  // qoi2dsusceptibility.cc:26
 }
 
 // gffaction.cc:80-94
@@ -1001,7 +1212,7 @@ static int launch_lattice_reduce(uint32_t Mt, uint32_t Mx, double mu2, const dou
     hipLaunchKernelGGL((lattice_reduce_kernel<OP>), dim3(nsplit, B), dim3(256), 0, st, Mt, Mx, mu2, d_state, (double *)ws);
     MLMCPI_LAUNCH_CHECK("lattice_reduce_kernel");
   }
-  hipLaunchKernelGGL(lattice_finish_kernel, dim3((B + 255) / 256), dim3(256), 0, st, (const double *)ws, nsplit, B, OP,
+  hipLaunchKernelGGL(lattice_finish_kernel, dim3((B + 3) / 4), dim3(256), 0, st, (const double *)ws, nsplit, B, OP,
                      scale, d_out);
   MLMCPI_LAUNCH_CHECK("lattice_finish_kernel");
   return MLMCPI_OK;
@@ -1109,6 +1320,8 @@ static int init_sweep_kernels() {
   MLMCPI_OR_ATTR(5, 256); MLMCPI_OR_ATTR(5, 512); MLMCPI_OR_ATTR(5, 1024);
   MLMCPI_OR_ATTR(6, 256); MLMCPI_OR_ATTR(6, 512); MLMCPI_OR_ATTR(6, 1024);
 #undef MLMCPI_OR_ATTR
+  MLMCPI_HIP_TRY(hipFuncSetAttribute((const void *)schwinger_or_block_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)OrBlockGeom<5>::lds_bytes));
+  MLMCPI_HIP_TRY(hipFuncSetAttribute((const void *)schwinger_or_block_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)OrBlockGeom<6>::lds_bytes));
   g_lds_attr_set[dev] = true;
   return MLMCPI_OK;
 }
@@ -1184,7 +1397,12 @@ static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, doub
   MLMCPI_REQUIRE(d_phi && d_w0 && d_w1 && d_phi != d_w0 && d_w0 != d_w1 && B > 0, "bad arguments");
   MLMCPI_REQUIRE(act->Mt % 2 == 0 && act->Mx % 2 == 0, "multicolour sweeps need even Mt, Mx (got %u x %u)", act->Mt,
                  act->Mx);
-  if (fuse == 0) fuse = 4;  // library default: best measured whole-step time (tools/scan_fuse.sh)
+  // library default: best measured whole-step time -- up to 6 sweeps per launch where the 4 x 4
+  // register-block kernel applies, 4 otherwise
+  const Tuning &tune = tuning();
+  const bool or_blocks = act->kind == MLMCPI_SCHWINGER && !tune.or_lds && !tune.or_patch && !tune.tile_w &&
+                         act->Mt % 64 == 0 && act->Mx % 64 == 0;
+  if (fuse == 0) fuse = or_blocks ? 6 : 4;
   if (fuse > kMaxFuse) fuse = kMaxFuse;
   hipStream_t st = as_stream(stream);
   const bool schw = act->kind == MLMCPI_SCHWINGER;
@@ -1202,7 +1420,14 @@ static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, doub
     // halo recomputation (cheap for them) for passes.  A heat-bath sweep is bound by its sampler arithmetic, which a
     // wider halo would only multiply, so it always gets a launch of its own (halo 2).
     uint32_t n = 1;
-    if (s < n_overrelax) n = n_overrelax - s < fuse ? n_overrelax - s : fuse;
+    if (s < n_overrelax) {
+      const uint32_t rem = n_overrelax - s;
+      n = rem < fuse ? rem : fuse;
+      if (or_blocks) {  // as few launches as `fuse` allows, of equal depth (10 sweeps, fuse 6: 5 + 5, not 6 + 4)
+        const uint32_t launches = (rem + fuse - 1) / fuse;
+        n = (rem + launches - 1) / launches;
+      }
+    }
     SweepGeom g;
     uint32_t kinds = 0;
     for (;;) {  // shrink the fused count until the tile + halo fits in LDS
@@ -1226,6 +1451,23 @@ static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, doub
       // more fused sweeps -> larger LDS image -> fewer resident workgroups: keep the wave count per CU up
       // with wider workgroups (MLMCPI_OR_THREADS overrides: tuning knob)
       const bool use_patch = !tuning().or_lds;
+      if (or_blocks) {  // 4 x 4 register blocks on 64 x 64 tiles (n <= 6)
+        dim3 bgrid((act->Mt / 64) * (act->Mx / 64), B);
+#define MLMCPI_OR_BLOCK(KK) hipLaunchKernelGGL((schwinger_or_block_kernel<KK>), bgrid, dim3(OrBlockGeom<KK>::NT), OrBlockGeom<KK>::lds_bytes, st, act->Mt, act->Mx, in2, out2, act->Mt / 64)
+        switch (n) {
+          case 1: MLMCPI_OR_BLOCK(1); break;
+          case 2: MLMCPI_OR_BLOCK(2); break;
+          case 3: MLMCPI_OR_BLOCK(3); break;
+          case 4: MLMCPI_OR_BLOCK(4); break;
+          case 5: MLMCPI_OR_BLOCK(5); break;
+          default: MLMCPI_OR_BLOCK(6);
+        }
+#undef MLMCPI_OR_BLOCK
+        MLMCPI_LAUNCH_CHECK("schwinger_or_block_kernel");
+        advance();
+        s += n;
+        continue;
+      }
       if (use_patch && n <= 4) {  // register-tiled kernel (MLMCPI_OR_KERNEL=lds selects the LDS-resident one)
         const uint32_t np = ((64 + 4 * n) / 2) * ((32 + 4 * n) / 2);
         const dim3 pblock((np + 63) / 64 * 64);
@@ -1293,7 +1535,7 @@ static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, doub
       const int op = qoi_kind == 1 ? (int)L_PLAQ : (int)L_CHARGE;
       rc = launch_sweep<true, true>(g, grid, st, act->Mt, act->Mx, act->beta, src, dst, n, kinds, key, op, (double *)partial);
       if (rc) return rc;
-      hipLaunchKernelGGL(lattice_finish_kernel, dim3((B + 255) / 256), dim3(256), 0, st, (const double *)partial, grid.x, B, op,
+      hipLaunchKernelGGL(lattice_finish_kernel, dim3((B + 3) / 4), dim3(256), 0, st, (const double *)partial, grid.x, B, op,
                          1.0 / ((double)act->Mx * act->Mt), d_qoi);
       MLMCPI_LAUNCH_CHECK("lattice_finish_kernel");
     } else if (schw)

@@ -90,12 +90,13 @@ bool apply_option(Tuning &t, const char *name, const char *value) {
   }
   if (n == "MLMCPI_OR_KERNEL") {
     t.or_lds = v == "lds";
-    return v.empty() || v == "lds" || v == "patch";
+    t.or_patch = v == "patch";
+    return v.empty() || v == "lds" || v == "patch" || v == "block";
   }
   if (n == "MLMCPI_OR_THREADS") {
     const unsigned x = (unsigned)atoi(v.c_str());
-    t.or_threads = (x == 256 || x == 512 || x == 1024) ? x : 0;
-    return v.empty() || t.or_threads != 0;
+    t.or_threads = x;
+    return true;
   }
   return false;
 }

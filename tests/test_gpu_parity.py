@@ -655,7 +655,7 @@ def test_schwinger_1024_properties(gpu_ops, orc, golden):
     finally:
         abi.set_option("MLMCPI_SWEEP_TILE", "")
     assert torch.equal(a, gen), "specialised and generic sweep kernels must agree bit for bit"
-    # library default (4 overrelaxation sweeps per launch, register-tiled kernel) and the LDS-resident kernel
+    # library default (up to 6 overrelaxation sweeps per launch, 4 x 4 register-block kernel) and the LDS-resident kernel
     d4 = x.clone()
     gpu_ops.lattice_sweep_draw(act, d4, scratch, 4, 2, SEED, 0, 0, fuse=0)
     assert torch.equal(a, d4), "the default fusion depth must not change the result"
@@ -666,6 +666,18 @@ def test_schwinger_1024_properties(gpu_ops, orc, golden):
     finally:
         abi.set_option("MLMCPI_OR_KERNEL", "")
     assert torch.equal(a, lds4), "register-tiled and LDS-resident overrelaxation kernels must agree bit for bit"
+    abi.set_option("MLMCPI_OR_KERNEL", "patch")  # 2 x 2 register blocks on 64 x 32 tiles (the default is 4 x 4 on 64 x 64)
+    try:
+        p4 = x.clone()
+        gpu_ops.lattice_sweep_draw(act, p4, scratch, 4, 2, SEED, 0, 0, fuse=4)
+    finally:
+        abi.set_option("MLMCPI_OR_KERNEL", "")
+    assert torch.equal(a, p4), "4 x 4 and 2 x 2 register-block overrelaxation kernels must agree bit for bit"
+    for n in (5, 6, 10):  # every depth of the 4 x 4 kernel (10 sweeps: 5 + 5) against single-sweep launches
+        u, v = x.clone(), x.clone()
+        gpu_ops.lattice_sweep_draw(act, u, scratch, n, 0, SEED, 0, 0, fuse=1)
+        gpu_ops.lattice_sweep_draw(act, v, scratch, n, 0, SEED, 0, 0, fuse=0)
+        assert torch.equal(u, v), f"{n} overrelaxation sweeps: default launch plan differs from single sweeps"
     single = x[1:2].clone()
     gpu_ops.lattice_sweep_draw(act, single, torch.empty_like(single), 4, 2, SEED, 1, 0, fuse=2)
     assert torch.equal(single[0], a[1]), "a chain's result must not depend on the batch it runs in"

@@ -23,12 +23,12 @@ for w, e in S.items():
             tot_ns += k["avg_ns"] * k["calls"]
         short = name.replace("mlmcpi::", "")
         kind = None
-        if "or_patch_kernel" in short or "or_kernel" in short or "sweep_kernel<false" in short:
+        if "or_patch_kernel" in short or "or_block_kernel" in short or "or_kernel" in short or "sweep_kernel<false" in short:
             kind = "overrelax"
         elif "sweep_kernel<true" in short:
             kind = "heatbath"
         fuse = 1
-        if "or_patch_kernel<" in short:
+        if "or_patch_kernel<" in short or "or_block_kernel<" in short:
             fuse = int(short.split("<")[1].split(">")[0])
         if kind and w in ("schwinger", "gff", "rotor_sweep"):
             if "hbm_bytes_per_launch" in k:
