@@ -281,7 +281,8 @@ public:
   }
   int sweep_from_qoi(const double *d_src, double *d_w0, double *d_w1, unsigned batch, unsigned n_or, unsigned n_hb, uint32_t sweep0,
                      int qoi_kind, double *d_q) override {
-    if (abi.kind != MLMCPI_SCHWINGER || n_hb == 0 || qoi_kind == 0) return -1;
+    // kinds 1, 2 (plaquette QoIs) belong to the Schwinger action, 3 (phi^2) to the GFF
+    if (n_hb == 0 || qoi_kind == 0 || (qoi_kind == 3) != (abi.kind == MLMCPI_GFF)) return -1;
     int32_t where = 0;
     check(mlmcpi_lattice_sweep_draw_qoi(&abi, d_src, d_w0, d_w1, batch, n_or, n_hb, seed, chain0, sweep0, fuse, qoi_kind, d_q, &where,
                                         nullptr), "lattice_sweep_draw_qoi");
@@ -375,6 +376,11 @@ public:
   int sweep_from(const double *d_src, double *d_w0, double *d_w1, unsigned batch, unsigned n_or, unsigned n_hb, uint32_t sweep0) override {
     if (!plain()) fatal("heat bath / overrelaxation sweeps of the GFF action are only built for the plain level");
     return QFTAction::sweep_from(d_src, d_w0, d_w1, batch, n_or, n_hb, sweep0);
+  }
+  int sweep_from_qoi(const double *d_src, double *d_w0, double *d_w1, unsigned batch, unsigned n_or, unsigned n_hb, uint32_t sweep0,
+                     int qoi_kind, double *d_q) override {
+    if (!plain()) fatal("heat bath / overrelaxation sweeps of the GFF action are only built for the plain level");
+    return QFTAction::sweep_from_qoi(d_src, d_w0, d_w1, batch, n_or, n_hb, sweep0, qoi_kind, d_q);
   }
   /** GFFAction::draw (gffaction.cc:200-213): exact draw + n_gibbs_smooth Gibbs sweeps; `step` numbers the draws */
   void draw_level(std::shared_ptr<SampleState> phi, uint32_t step) const {

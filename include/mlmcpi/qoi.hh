@@ -92,6 +92,7 @@ private:
 class QoI2DPhiSquared : public QoI {
 public:
   explicit QoI2DPhiSquared(const std::shared_ptr<Lattice2D> lattice) : M_lat(lattice->getNvertices()) {}
+  int fused_kind() const override { return 3; }
   void evaluate_device(const std::shared_ptr<SampleState> phi, double *d_out) override {
     check(mlmcpi_qoi_phi_squared(phi->device(), M_lat, phi->batch(), d_out, nullptr), "qoi_phi_squared");
   }

@@ -219,9 +219,10 @@ int mlmcpi_lattice_sweep_draw_from(const mlmcpi_lattice_action *act, const doubl
 /* mlmcpi_lattice_sweep_draw_from with the QoI of the new sample summed inside the draw's last launch, while the tile is
  * still in LDS: Sampler::draw + QoI::evaluate of the loop at montecarlo/montecarlosinglelevel.cc:59-77 in one pass over
  * the state instead of two.  qoi_kind 1 = QoIAvgPlaquette (qoi/qft/qoiavgplaquette.cc:8-27), 2 = QoI2DSusceptibility
- * (qoi/qft/qoi2dsusceptibility.cc:8-27); d_qoi[b].  Quenched Schwinger action, n_heatbath >= 1 (the draw has to end with a
- * heat-bath sweep: MLMCPI_ERR_UNSUPPORTED otherwise, and the caller evaluates the QoI separately).  Same values as
- * mlmcpi_qoi_* on the result up to the order of the summation. */
+ * (qoi/qft/qoi2dsusceptibility.cc:8-27), both for the quenched Schwinger action; 3 = QoI2DPhiSquared
+ * (qoi/qft/qoi2dphisquared.cc:8-15) for the GFF action; d_qoi[b].  n_heatbath >= 1 (the draw has to end with a heat-bath
+ * sweep) and a QoI of the action at hand: MLMCPI_ERR_UNSUPPORTED otherwise, and the caller evaluates the QoI
+ * separately.  Same values as mlmcpi_qoi_* on the result up to the order of the summation. */
 int mlmcpi_lattice_sweep_draw_qoi(const mlmcpi_lattice_action *act, const double *d_src, double *d_w0, double *d_w1, uint32_t B,
                                   uint32_t n_overrelax, uint32_t n_heatbath, uint64_t seed, uint32_t chain0, uint32_t sweep0,
                                   uint32_t fuse, int32_t qoi_kind, double *d_qoi, int32_t *result_in, void *stream);

@@ -716,8 +716,10 @@ __global__ void __launch_bounds__(OrBlockGeom<K>::NT)
 template <bool HEAT, int NT>
 __global__ void __launch_bounds__(NT)
     gff_sweep_kernel(uint32_t Mt, uint32_t Mx, double mu2, const double *__restrict__ in, double *__restrict__ out,
-                     TileGeom tg, uint32_t nsweeps, uint32_t kinds, RngKey key0) {
+                     TileGeom tg, uint32_t nsweeps, uint32_t kinds, RngKey key0, int qoi_op = 0,
+                     double *__restrict__ qoi_partial = nullptr) {
   extern __shared__ double lds[];
+  __shared__ double qoi_red[NT / 64];
   const uint32_t H = 2 * nsweeps;
   const uint32_t tile = blockIdx.x, b = blockIdx.y;
   const uint32_t ty = tile / tg.tiles_x, tx = tile - ty * tg.tiles_x;
@@ -812,8 +814,19 @@ __global__ void __launch_bounds__(NT)
     }
   }
 
+  // Optional fused QoI of the final state (qoi/qft/qoi2dphisquared.cc:8-15): phi^2 summed over the owned sites while the
+  // tile is in LDS, one partial per tile; lattice_finish_kernel sums them in tile order.
+  double acc[1] = {0.0};
   double *dst = out + (size_t)b * Mt * Mx;
-  for_region<NT>(oh, ow, [&](uint32_t r, uint32_t c) { dst[(size_t)(j0 + r) * Mt + (i0 + c)] = phi[(r + H) * bw + (c + H)]; });
+  for_region<NT>(oh, ow, [&](uint32_t r, uint32_t c) {
+    const double v = phi[(r + H) * bw + (c + H)];
+    dst[(size_t)(j0 + r) * Mt + (i0 + c)] = v;
+    if (qoi_op) acc[0] += v * v;
+  });
+  if (qoi_op) {
+    block_sum<1>(acc, qoi_red);
+    if (threadIdx.x == 0) qoi_partial[(size_t)b * gridDim.x + blockIdx.x] = acc[0];
+  }
 }
 
 // ---- GFF overrelaxation, specialised --------------------------------------------------------------------
@@ -957,6 +970,138 @@ __global__ void __launch_bounds__(1024)
     const size_t o0 = (size_t)(j0 + 2 * pj - H) * Mt + (i0 + 2 * pi - H);
     *(double2 *)(dst + o0) = make_double2(p[0][0], p[0][1]);
     *(double2 *)(dst + o0 + Mt) = make_double2(p[1][0], p[1][1]);
+  }
+}
+
+// ---- GFF overrelaxation, 4 x 4 register blocks on 64 x 64 tiles ------------------------------------------------
+// The construction of schwinger_or_block_kernel for the scalar field: a thread keeps 16 sites for all K sweeps, LDS
+// carries the 12 sites on the rim of each block (TOP[a], BOT[a], LEFT[c], RIGHT[c], corners once), a colour phase reads
+// the 8 neighbour values across the block's edges that belong to the other colour.  Redundancy (64 + 4K)^2 / 64^2
+// (1.72 at K = 5) instead of 1.875 at K = 4 on 64 x 32 tiles, 1.75 LDS accesses per update instead of 3, three
+// workgroups per CU.  Same sums in the same order as gff_or_patch_kernel: bit-identical.
+template <int K>
+struct GffBlockGeom {
+  static constexpr int TW = 64, TH = 64, PW = 4, PH = 4, H = 2 * K;
+  static constexpr int BW = TW + 2 * H, BH = TH + 2 * H, NPX = BW / PW, NPY = BH / PH, NP = NPX * NPY;
+  static constexpr int NT = (NP + 63) / 64 * 64;
+  static constexpr int NPLANE = 2 * PW + 2 * (PH - 2);
+  static constexpr size_t lds_bytes = (size_t)NPLANE * NP * sizeof(double);
+  static constexpr int top(int a) { return a; }
+  static constexpr int bot(int a) { return PW + a; }
+  static constexpr int left(int c) { return c == 0 ? bot(0) : c == PH - 1 ? top(0) : 2 * PW + (c - 1); }
+  static constexpr int right(int c) { return c == 0 ? bot(PW - 1) : c == PH - 1 ? top(PW - 1) : 2 * PW + (PH - 2) + (c - 1); }
+};
+
+template <int K>
+__global__ void __launch_bounds__(GffBlockGeom<K>::NT)
+    gff_or_block_kernel(uint32_t Mt, uint32_t Mx, double mu2, const double *__restrict__ in, double *__restrict__ out,
+                        uint32_t tiles_x) {
+  using G = GffBlockGeom<K>;
+  constexpr int TW = G::TW, TH = G::TH, PW = G::PW, PH = G::PH, H = G::H, NPX = G::NPX, NPY = G::NPY, NP = G::NP;
+  static_assert(PW == 4 && PH == 4, "the write-back moves 4 sites per block row");
+  extern __shared__ double lds[];
+  auto pl = [&](int p) { return lds + p * NP; };
+  const uint32_t tile = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
+  const uint32_t i0 = tx * TW, j0 = ty * TH;
+  const bool active = tid < NP;
+  const int pj = active ? (int)tid / NPX : 0, pi = active ? (int)tid - pj * NPX : 0;
+  const int me = active ? (int)tid : 0;  // idle threads of the last wave: every index is entry 0, nothing is written
+  const int dn = pj > 0 ? me - NPX : me, up = pj + 1 < NPY ? me + NPX : me;
+  const int lf = pi > 0 ? me - 1 : me, rt = pi + 1 < NPX ? me + 1 : me;
+  const double *src = in + (size_t)b * Mt * Mx;
+  const double two_over_kappa = 2. / (4. + mu2);
+  double p[PH][PW];  // [c][a]: site (PW pi + a, PH pj + c)
+  {
+    uint32_t gi[PW / 2], gj[PH];  // H is even: a pair of sites (gi, gi + 1) never straddles the wrap
+    gi[0] = (uint32_t)(((uint64_t)i0 + Mt - (H % Mt) + PW * pi) % Mt);
+    gj[0] = (uint32_t)(((uint64_t)j0 + Mx - (H % Mx) + PH * pj) % Mx);
+#pragma unroll
+    for (int a = 1; a < PW / 2; ++a) gi[a] = gi[a - 1] + 2 == Mt ? 0 : gi[a - 1] + 2;
+#pragma unroll
+    for (int c = 1; c < PH; ++c) gj[c] = gj[c - 1] + 1 == Mx ? 0 : gj[c - 1] + 1;
+#pragma unroll
+    for (int c = 0; c < PH; ++c)
+#pragma unroll
+      for (int a = 0; a < PW; a += 2) {
+        const double2 v = active ? *(const double2 *)(src + (size_t)gj[c] * Mt + gi[a / 2]) : make_double2(0, 0);
+        p[c][a] = v.x;
+        p[c][a + 1] = v.y;
+      }
+  }
+  auto publish = [&](int a, int c, double v) {  // rim sites: a corner belongs to a row and a column, stored once
+    const int p1 = c == PH - 1 ? G::top(a) : c == 0 ? G::bot(a) : -1;
+    const int p2 = a == 0 ? G::left(c) : a == PW - 1 ? G::right(c) : -1;
+    if (!active) return;
+    if (p1 >= 0) pl(p1)[me] = v;
+    if (p2 >= 0 && p2 != p1) pl(p2)[me] = v;
+  };
+#pragma unroll
+  for (int c = 0; c < PH; ++c)
+#pragma unroll
+    for (int a = 0; a < PW; ++a) publish(a, c, p[c][a]);
+  __syncthreads();
+
+  for (int s = 0; s < K; ++s) {
+#pragma unroll
+    for (int col = 0; col < 2; ++col) {
+      // neighbour values across the block's edges (they have the other colour: unchanged during this phase)
+      double e_lf[PH], e_rt[PH], e_dn[PW], e_up[PW];
+#pragma unroll
+      for (int c = 0; c < PH; ++c) {
+        if (((0 + c) & 1) == col) e_lf[c] = pl(G::right(c))[lf];
+        if (((PW - 1 + c) & 1) == col) e_rt[c] = pl(G::left(c))[rt];
+      }
+#pragma unroll
+      for (int a = 0; a < PW; ++a) {
+        if (((a + 0) & 1) == col) e_dn[a] = pl(G::top(a))[dn];
+        if (((a + PH - 1) & 1) == col) e_up[a] = pl(G::bot(a))[up];
+      }
+#pragma unroll
+      for (int c = 0; c < PH; ++c)
+#pragma unroll
+        for (int a = 0; a < PW; ++a) {
+          if (((a + c) & 1) != col) continue;
+          // gffaction.cc:68-77, Delta summed in the order of the reference's neighbour table (+i, -i, +j, -j)
+          double Delta = 0.0;
+          Delta += a + 1 < PW ? p[c][a + 1 < PW ? a + 1 : 0] : e_rt[c];
+          Delta += a > 0 ? p[c][a > 0 ? a - 1 : 0] : e_lf[c];
+          Delta += c + 1 < PH ? p[c + 1 < PH ? c + 1 : 0][a] : e_up[a];
+          Delta += c > 0 ? p[c > 0 ? c - 1 : 0][a] : e_dn[a];
+          p[c][a] = fma(two_over_kappa, Delta, -p[c][a]);
+          publish(a, c, p[c][a]);
+        }
+      __syncthreads();
+    }
+  }
+
+  // Owned sites: buffer columns [H, H + TW), rows [H, H + TH), written back through a per-wave transposition in LDS (the
+  // planes are dead after the last barrier) so that a wave instruction covers whole rows: per block row the owners put
+  // their 4 sites down as two double2, and lane l writes the pair (l & 1) of block 32 i + (l >> 1), i = 0, 1.
+  const uint32_t wave0 = tid & ~63u, lane = tid & 63u;
+  double2 *stage = reinterpret_cast<double2 *>(lds) + (wave0 / 64) * 128;
+  double *dst = out + (size_t)b * Mt * Mx;
+  int uq[2], ur[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int bt = (int)wave0 + 32 * i + (int)(lane >> 1);
+    const int bj = bt / NPX, bi = bt - bj * NPX;
+    uq[i] = PW * bi + 2 * (int)(lane & 1) - H;  // even, and TW is even: the pair is owned as a whole or not at all
+    ur[i] = PH * bj - H;
+    if (bt >= NP || uq[i] >= TW) uq[i] = -1;
+  }
+#pragma unroll
+  for (int c = 0; c < PH; ++c) {
+    stage[2 * lane] = make_double2(p[c][0], p[c][1]);
+    stage[2 * lane + 1] = make_double2(p[c][2], p[c][3]);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const double2 w = stage[64 * i + lane];
+      const int r = ur[i] + c;
+      if (uq[i] >= 0 && r >= 0 && r < TH) *(double2 *)(dst + (size_t)(j0 + r) * Mt + (i0 + uq[i])) = w;
+    }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -1275,7 +1420,7 @@ static void launch_sweep_nt(const SweepGeom &g, dim3 grid, hipStream_t st, uint3
   }
   else
     hipLaunchKernelGGL((gff_sweep_kernel<HEAT, NT>), grid, dim3(NT), g.lds_bytes, st, Mt, Mx, coupling, src, dst, g.tg, n,
-                       kinds, key);
+                       kinds, key, qoi_op, qoi_partial);
 }
 
 template <bool SCHW, bool HEAT>
@@ -1294,9 +1439,9 @@ static int launch_sweep(const SweepGeom &g, dim3 grid, hipStream_t st, uint32_t 
 template <bool HEAT, int NT>
 static int allow_full_lds() {
   // tiles with deep halos may use the whole 160 KiB of LDS
-  // (the Schwinger kernel also holds NT / 64 doubles of static LDS for the fused QoI reduction)
+  // (the kernels also hold NT / 64 doubles of static LDS for the fused QoI reduction)
   MLMCPI_HIP_TRY(hipFuncSetAttribute((const void *)schwinger_sweep_kernel<HEAT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-  MLMCPI_HIP_TRY(hipFuncSetAttribute((const void *)gff_sweep_kernel<HEAT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  MLMCPI_HIP_TRY(hipFuncSetAttribute((const void *)gff_sweep_kernel<HEAT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
   return MLMCPI_OK;
 }
 
@@ -1390,9 +1535,10 @@ static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, doub
                            uint32_t fuse, int32_t *result_in, void *stream, int qoi_kind = 0, double *d_qoi = nullptr) {
   if (int rc = check_lattice(act)) return rc;
   if (qoi_kind) {
-    MLMCPI_REQUIRE(d_qoi && (qoi_kind == 1 || qoi_kind == 2), "bad QoI arguments");
-    if (act->kind != MLMCPI_SCHWINGER || n_heatbath == 0)
-      return fail(MLMCPI_ERR_UNSUPPORTED, "the fused QoI needs a Schwinger draw that ends with a heat-bath sweep");
+    MLMCPI_REQUIRE(d_qoi && qoi_kind >= 1 && qoi_kind <= 3, "bad QoI arguments");
+    if ((qoi_kind == 3) != (act->kind == MLMCPI_GFF))
+      return fail(MLMCPI_ERR_UNSUPPORTED, "fused QoI %d does not belong to this action", qoi_kind);
+    if (n_heatbath == 0) return fail(MLMCPI_ERR_UNSUPPORTED, "the fused QoI needs a draw that ends with a heat-bath sweep");
   }
   MLMCPI_REQUIRE(d_phi && d_w0 && d_w1 && d_phi != d_w0 && d_w0 != d_w1 && B > 0, "bad arguments");
   MLMCPI_REQUIRE(act->Mt % 2 == 0 && act->Mx % 2 == 0, "multicolour sweeps need even Mt, Mx (got %u x %u)", act->Mt,
@@ -1400,8 +1546,7 @@ static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, doub
   // library default: best measured whole-step time -- up to 6 sweeps per launch where the 4 x 4
   // register-block kernel applies, 4 otherwise
   const Tuning &tune = tuning();
-  const bool or_blocks = act->kind == MLMCPI_SCHWINGER && !tune.or_lds && !tune.or_patch && !tune.tile_w &&
-                         act->Mt % 64 == 0 && act->Mx % 64 == 0;
+  const bool or_blocks = !tune.or_lds && !tune.or_patch && !tune.tile_w && act->Mt % 64 == 0 && act->Mx % 64 == 0;
   if (fuse == 0) fuse = or_blocks ? 6 : 4;
   if (fuse > kMaxFuse) fuse = kMaxFuse;
   hipStream_t st = as_stream(stream);
@@ -1499,11 +1644,28 @@ static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, doub
 #undef MLMCPI_OR
       MLMCPI_LAUNCH_CHECK("schwinger_or_kernel");
       rc = MLMCPI_OK;
-    } else if (!schw && !kinds && !g.overridden && act->Mt % 64 == 0 && act->Mx % 32 == 0 && n <= 4) {
+    } else if (!schw && !kinds && !g.overridden && act->Mt % 64 == 0 && act->Mx % 32 == 0 && n <= (or_blocks ? 6u : 4u)) {
       const size_t lds = (size_t)(32 + 4 * n) * (64 + 4 * n + 1) * sizeof(double);
       dim3 sgrid((act->Mt / 64) * (act->Mx / 32), B);
       const double mu2 = gff_mu2(*act);
       const bool use_gff_patch = !tuning().or_lds;
+      if (or_blocks) {  // 4 x 4 register blocks on 64 x 64 tiles (n <= 6)
+        dim3 bgrid((act->Mt / 64) * (act->Mx / 64), B);
+#define MLMCPI_GFF_BLOCK(KK) hipLaunchKernelGGL((gff_or_block_kernel<KK>), bgrid, dim3(GffBlockGeom<KK>::NT), GffBlockGeom<KK>::lds_bytes, st, act->Mt, act->Mx, mu2, (const double *)src, dst, act->Mt / 64)
+        switch (n) {
+          case 1: MLMCPI_GFF_BLOCK(1); break;
+          case 2: MLMCPI_GFF_BLOCK(2); break;
+          case 3: MLMCPI_GFF_BLOCK(3); break;
+          case 4: MLMCPI_GFF_BLOCK(4); break;
+          case 5: MLMCPI_GFF_BLOCK(5); break;
+          default: MLMCPI_GFF_BLOCK(6);
+        }
+#undef MLMCPI_GFF_BLOCK
+        MLMCPI_LAUNCH_CHECK("gff_or_block_kernel");
+        advance();
+        s += n;
+        continue;
+      }
       if (use_gff_patch) {  // register-tiled kernel (MLMCPI_OR_KERNEL=lds selects the LDS-resident one)
         const uint32_t np = ((64 + 4 * n) / 2) * ((32 + 4 * n) / 2);
         const dim3 pblock((np + 63) / 64 * 64);
@@ -1529,11 +1691,12 @@ static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, doub
       rc = MLMCPI_OK;
     } else
     // launches without a heat-bath sweep use the lean instantiation (no sampler code, fewer VGPRs)
-    if (schw && kinds && qoi_kind && s + n == total) {  // the last launch of the draw: sum the QoI while the tile is in LDS
+    if (kinds && qoi_kind && s + n == total) {  // the last launch of the draw: sum the QoI while the tile is in LDS
       void *partial = nullptr;
       if (int rcs = scratch((size_t)B * grid.x * sizeof(double), &partial, st)) return rcs;
-      const int op = qoi_kind == 1 ? (int)L_PLAQ : (int)L_CHARGE;
-      rc = launch_sweep<true, true>(g, grid, st, act->Mt, act->Mx, act->beta, src, dst, n, kinds, key, op, (double *)partial);
+      const int op = qoi_kind == 1 ? (int)L_PLAQ : qoi_kind == 2 ? (int)L_CHARGE : (int)L_PHI2;
+      rc = schw ? launch_sweep<true, true>(g, grid, st, act->Mt, act->Mx, act->beta, src, dst, n, kinds, key, op, (double *)partial)
+                : launch_sweep<false, true>(g, grid, st, act->Mt, act->Mx, gff_mu2(*act), src, dst, n, kinds, key, op, (double *)partial);
       if (rc) return rc;
       hipLaunchKernelGGL(lattice_finish_kernel, dim3((B + 3) / 4), dim3(256), 0, st, (const double *)partial, grid.x, B, op,
                          1.0 / ((double)act->Mx * act->Mt), d_qoi);
@@ -1585,7 +1748,7 @@ int mlmcpi_lattice_sweep_draw_qoi(const mlmcpi_lattice_action *act, const double
                                   uint32_t n_overrelax, uint32_t n_heatbath, uint64_t seed, uint32_t chain0, uint32_t sweep0,
                                   uint32_t fuse, int32_t qoi_kind, double *d_qoi, int32_t *result_in, void *stream) {
   MLMCPI_REQUIRE(result_in, "result_in is NULL");
-  MLMCPI_REQUIRE(qoi_kind == 1 || qoi_kind == 2, "qoi_kind %d: 1 = average plaquette, 2 = Q^2 / (4 pi^2)", qoi_kind);
+  MLMCPI_REQUIRE(qoi_kind >= 1 && qoi_kind <= 3, "qoi_kind %d: 1 = average plaquette, 2 = Q^2 / (4 pi^2), 3 = phi^2 (GFF)", qoi_kind);
   return sweep_draw_impl(act, const_cast<double *>(d_src), d_w0, d_w1, B, n_overrelax, n_heatbath, seed, chain0, sweep0, fuse,
                          result_in, stream, qoi_kind, d_qoi);
 }

@@ -718,6 +718,18 @@ def test_rotor_65536_and_gff_512_properties(gpu_ops):
     finally:
         abi.set_option("MLMCPI_OR_KERNEL", "")
     assert torch.equal(a, lds4), "register-tiled and LDS-resident GFF overrelaxation kernels must agree bit for bit"
+    abi.set_option("MLMCPI_OR_KERNEL", "patch")  # 2 x 2 register blocks on 64 x 32 tiles (the default is 4 x 4 on 64 x 64)
+    try:
+        p4 = phi.clone()
+        gpu_ops.lattice_sweep_draw(act, p4, scratch, 6, 1, SEED, 0, 0, fuse=4)
+    finally:
+        abi.set_option("MLMCPI_OR_KERNEL", "")
+    assert torch.equal(a, p4), "4 x 4 and 2 x 2 register-block GFF overrelaxation kernels must agree bit for bit"
+    for n in (5, 6, 10):  # every depth of the 4 x 4 kernel against single-sweep launches
+        u, v = phi.clone(), phi.clone()
+        gpu_ops.lattice_sweep_draw(act, u, scratch, n, 0, SEED, 0, 0, fuse=1)
+        gpu_ops.lattice_sweep_draw(act, v, scratch, n, 0, SEED, 0, 0, fuse=0)
+        assert torch.equal(u, v), f"GFF, {n} overrelaxation sweeps: default launch plan differs from single sweeps"
     c = phi.clone()
     gpu_ops.lattice_sweep_draw(act, c, scratch, 6, 0, SEED, 0, 0, fuse=3)
     assert_close(gpu_ops.lattice_evaluate(act, c).cpu().numpy(), S0, tol=1e-11, what="GFF OR conserves S")
@@ -802,6 +814,24 @@ def test_fused_qoi_equals_separate_evaluation(gpu_ops, Mt, Mx, B, n_or, n_hb):
         assert_close(q.cpu().numpy(), ref.cpu().numpy(), tol=1e-12 if kind == 1 else 1e-10, what=f"fused QoI {kind}")
     with pytest.raises(abi.MlmcpiError):
         gpu_ops.lattice_sweep_draw_qoi(act, x0, torch.empty_like(x0), x0.clone(), 2, 0, SEED, 3, 11, 1)
+    with pytest.raises(abi.MlmcpiError):  # phi^2 is the GFF's QoI
+        gpu_ops.lattice_sweep_draw_qoi(act, x0, torch.empty_like(x0), x0.clone(), n_or, n_hb, SEED, 3, 11, 3)
+
+
+@pytest.mark.parametrize("M,B,n_or,n_hb", [(512, 3, 5, 1), (64, 2, 0, 1), (20, 2, 3, 2), (192, 2, 1, 1)])
+def test_fused_gff_qoi_equals_separate_evaluation(gpu_ops, M, B, n_or, n_hb):
+    """The same for the GFF action: QoI2DPhiSquared (qoi kind 3) summed inside the heat-bath launch."""
+    from mlmcpathintegral_amd import abi
+    act = abi.lattice_action(abi.GFF, M, M, mass=10.0)
+    x0 = gpu_ops.lattice_initialise(act, B, SEED, 3)
+    plain = x0.clone()
+    gpu_ops.lattice_sweep_draw(act, plain, torch.empty_like(plain), n_or, n_hb, SEED, 3, 11)
+    src = x0.clone()
+    res, _, q = gpu_ops.lattice_sweep_draw_qoi(act, src, torch.empty_like(src), src, n_or, n_hb, SEED, 3, 11, 3)
+    assert torch.equal(res, plain)
+    assert_close(q.cpu().numpy(), gpu_ops.qoi_phi_squared(plain).cpu().numpy(), tol=1e-12, what="fused phi^2")
+    with pytest.raises(abi.MlmcpiError):  # the plaquette QoIs belong to the Schwinger action
+        gpu_ops.lattice_sweep_draw_qoi(act, x0, torch.empty_like(x0), x0.clone(), n_or, n_hb, SEED, 3, 11, 1)
 
 
 def test_schwinger_twolevel_step_errors(gpu_ops):
