@@ -95,8 +95,8 @@ bool apply_option(Tuning &t, const char *name, const char *value) {
   }
   if (n == "MLMCPI_OR_THREADS") {
     const unsigned x = (unsigned)atoi(v.c_str());
-    t.or_threads = x;
-    return true;
+    t.or_threads = (x == 256 || x == 512 || x == 1024) ? x : 0;
+    return v.empty() || t.or_threads != 0;
   }
   return false;
 }
