@@ -168,9 +168,8 @@ class SweepWorkload:
         if record:
             for k in range(len(self.plan), 2):
                 e[1 + k].record()
-        # fused QoI: one pass over the state less (-0.045 ms per step at 32 chains); a single chain is latency bound and
-        # does better with the stand-alone reduction (0.122 vs 0.144 ms per step), so small batches keep it
-        self.fused = a.n_heatbath > 0 and not a.no_fused_qoi and self.B >= 8
+        # fused QoI: one pass over the state less (-0.045 ms per step at 32 chains, -0.006 ms at one chain)
+        self.fused = a.n_heatbath > 0 and not a.no_fused_qoi
         if self.fused:  # sampler->draw's last launch sums the QoI of the new sample while the tile is in LDS
             self.x, self.scratch, q = ops.lattice_sweep_draw_qoi(self.act, cur, oth, cur, 0, a.n_heatbath, a.seed, self.chain0,
                                                                  s + a.n_overrelax, 1 if self.kind == "schwinger" else 3,
@@ -536,7 +535,7 @@ def report_sweeps(result, a, W, size, B, world, step_ms, ms):
     """Per-kernel records and the roofline of the dominant kernel for the 2-D sweep workloads."""
     fuse, sites = W.fuse, W.sites
     state_rw = 16.0 * sites * B          # one read + one write of the whole state: the HBM floor of ANY launch
-    special = size % 64 == 0 and fuse <= (6 if (a.workload == "schwinger" or W.blocks) else 4)
+    special = size % 64 == 0 and fuse <= (6 if (a.workload == "schwinger" or W.blocks) else 4) and not os.environ.get("MLMCPI_SWEEP_TILE")
     lds_kernel = os.environ.get("MLMCPI_OR_KERNEL") == "lds"
 
     def or_name(depth):
@@ -554,7 +553,8 @@ def report_sweeps(result, a, W, size, B, world, step_ms, ms):
         return f"gff_or_patch_kernel<{depth}>" if not lds_kernel else f"gff_or_kernel<64,32,{depth},256>"
 
     if a.workload == "schwinger":
-        hb_name = "schwinger_sweep_kernel<true,256,64,32>" if (size % 64 == 0 and size >= 128 and a.n_heatbath == 1) else "schwinger_sweep_kernel<true,256,0,0>"
+        fixed = size % 64 == 0 and size >= 128 and a.n_heatbath == 1 and not os.environ.get("MLMCPI_SWEEP_TILE")
+        hb_name = "schwinger_sweep_kernel<true,256,64,32>" if fixed else "schwinger_sweep_kernel<true,256,0,0>"
     else:
         hb_name = "gff_sweep_kernel<true,256>"
     result["config"] = {"workload": f"{a.workload} {size}x{size}, {a.n_overrelax} overrelaxation + {a.n_heatbath} heat-bath "

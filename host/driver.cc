@@ -160,7 +160,7 @@ int main(int argc, char **argv) {
     DeviceVector q(batch), acc(5 * (size_t)batch);
     const unsigned n_samples = (unsigned)num("n_samples"), warmup = (unsigned)num("warmup");
     auto sweeper = std::dynamic_pointer_cast<OverrelaxedHeatBathSampler>(sampler);
-    const int fused = (sweeper && batch >= 8) ? qoi->fused_kind() : 0;  // small batches are latency bound: separate QoI
+    const int fused = sweeper ? qoi->fused_kind() : 0;
     auto one = [&]() {
       if (!(fused && sweeper->draw_with_qoi(phi_state, fused, (double *)q.ptr()))) {
         sampler->draw(phi_state);

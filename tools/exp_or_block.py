@@ -36,13 +36,13 @@ def timeit(K, n=20):
     for _ in range(n): ops.lattice_sweep_draw_pingpong(act, x, s, K, 0, seed, 0, 0, K)
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
-variants = (("block", "3"), ("block", "2"), ("block", "1"), ("block", "0"))
-for rep in range(2):
+for rep in range(2):  # the variants alternate inside one process: clocks and box are the same for both
     for K in range(1, 7):
         out = []
-        for kernel, direct in variants:
-            abi.set_option("MLMCPI_OR_KERNEL", kernel); abi.set_option("MLMCPI_OR_THREADS", direct)
+        for kernel in ("patch", "block"):
+            if kernel == "patch" and K > 4: out.append("   -  "); continue
+            abi.set_option("MLMCPI_OR_KERNEL", kernel)
             out.append(f"{timeit(K):.4f}")
-        print(f"rep {rep} K={K}: direct {out[0]}  coalesced loads {out[1]}  coalesced stores {out[2]}  both {out[3]}")
-abi.set_option("MLMCPI_OR_KERNEL", ""); abi.set_option("MLMCPI_OR_THREADS", "")
+        print(f"rep {rep} K={K}: 2x2 patch {out[0]}  4x4 blocks {out[1]} ms/launch")
+abi.set_option("MLMCPI_OR_KERNEL", "")
 sys.exit(1 if bad else 0)
