@@ -568,7 +568,8 @@ def report_sweeps(result, a, W, size, B, world, step_ms, ms):
         fixed = size % 64 == 0 and size >= 128 and a.n_heatbath == 1 and not os.environ.get("MLMCPI_SWEEP_TILE")
         hb_name = "schwinger_sweep_kernel<true,256,64,32>" if fixed else "schwinger_sweep_kernel<true,256,0,0>"
     else:
-        hb_name = "gff_sweep_kernel<true,256>"
+        fixed = size % 64 == 0 and size >= 128 and a.n_heatbath == 1 and not os.environ.get("MLMCPI_SWEEP_TILE")
+        hb_name = "gff_sweep_kernel<true,256,64,32>" if fixed else "gff_sweep_kernel<true,256,0,0>"
     result["config"] = {"workload": f"{a.workload} {size}x{size}, {a.n_overrelax} overrelaxation + {a.n_heatbath} heat-bath "
                                     "sweeps + QoI + record_sample per step, multicolour order",
                         "chains_per_gpu": B, "chains_total": B * world, "fuse": fuse,

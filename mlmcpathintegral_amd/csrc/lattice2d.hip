@@ -713,18 +713,29 @@ __global__ void __launch_bounds__(OrBlockGeom<K>::NT)
 // ---- GFF sweeps --------------------------------------------------------------------------------------
 // Red/black order: (i+j) even, then odd.  gffaction.cc:33-42 (heat bath), :68-77 (overrelaxation);
 // Delta is summed in the order of the reference's neighbour table (+i, -i, +j, -j).
-template <bool HEAT, int NT>
+// TWC x THC > 0: single-sweep launch on a lattice that the TWC x THC tiles divide and that is wider than a buffer: tile and
+// buffer extents are compile-time constants, as in schwinger_sweep_kernel (same updates, bit-identical results).
+template <bool HEAT, int NT, int TWC = 0, int THC = 0>
 __global__ void __launch_bounds__(NT)
     gff_sweep_kernel(uint32_t Mt, uint32_t Mx, double mu2, const double *__restrict__ in, double *__restrict__ out,
-                     TileGeom tg, uint32_t nsweeps, uint32_t kinds, RngKey key0, int qoi_op = 0,
+                     TileGeom tg, uint32_t nsweeps_arg, uint32_t kinds, RngKey key0, int qoi_op = 0,
                      double *__restrict__ qoi_partial = nullptr) {
   extern __shared__ double lds[];
   __shared__ double qoi_red[NT / 64];
+  constexpr bool FIXED = TWC > 0;
+  const uint32_t nsweeps = FIXED ? 1u : nsweeps_arg;
   const uint32_t H = 2 * nsweeps;
   const uint32_t tile = blockIdx.x, b = blockIdx.y;
   const uint32_t ty = tile / tg.tiles_x, tx = tile - ty * tg.tiles_x;
-  const uint32_t i0 = tx * tg.TW, j0 = ty * tg.TH;
-  const uint32_t ow = min(tg.TW, Mt - i0), oh = min(tg.TH, Mx - j0);
+  const uint32_t i0 = tx * (FIXED ? TWC : tg.TW), j0 = ty * (FIXED ? THC : tg.TH);
+  const uint32_t ow = FIXED ? TWC : min(tg.TW, Mt - i0), oh = FIXED ? THC : min(tg.TH, Mx - j0);
+  auto wrap = [&](uint32_t base, uint32_t off, uint32_t n) {  // lattice coordinate of a buffer coordinate
+    if (FIXED) {
+      const uint32_t v = base + off;
+      return v >= n ? v - n : v;
+    }
+    return wrap_add(base, off, n);
+  };
   const uint32_t bw = ow + 2 * H, bh = oh + 2 * H;
   double *phi = lds;
   double *nrm = lds + (size_t)bw * bh;  // HEAT only: the second normal of each Box-Muller pair, by cell
@@ -736,12 +747,12 @@ __global__ void __launch_bounds__(NT)
   const double inv_kappa = 1. / (4. + mu2), two_over_kappa = 2. / (4. + mu2), sigma = 1. / sqrt(4. + mu2);
 
   stage_region<NT, (NT >= 1024 ? 3 : 5), double>(
-      bh, bw, [&](uint32_t r, uint32_t c) { return src[(size_t)wrap_add(sr, r, Mx) * Mt + wrap_add(sc, c, Mt)]; },
+      bh, bw, [&](uint32_t r, uint32_t c) { return src[(size_t)wrap(sr, r, Mx) * Mt + wrap(sc, c, Mt)]; },
       [&](uint32_t r, uint32_t c, double v) { phi[r * bw + c] = v; });
   __syncthreads();
 
   for (uint32_t s = 0; s < nsweeps; ++s) {
-    const bool heat = HEAT && ((kinds >> s) & 1u);
+    const bool heat = HEAT && (FIXED || ((kinds >> s) & 1u));
     RngKey skey = key;
     skey.step += s;
     for (uint32_t colour = 0; colour < 2; ++colour) {
@@ -761,7 +772,7 @@ __global__ void __launch_bounds__(NT)
         return Delta;
       };
       auto draw_pair = [&](uint32_t r, uint32_t c, bool park) {  // returns this cell's normal
-        const uint32_t ell = wrap_add(sr, r, Mx) * Mt + wrap_add(sc, c, Mt);
+        const uint32_t ell = wrap(sr, r, Mx) * Mt + wrap(sc, c, Mt);
         double n0, n1;
         rng_normals(skey, ell >> 1, P_GFF_NORMAL, 0, n0, n1);
         if (park) nrm[r * bw + (c ^ 1u)] = (ell & 1u) ? n0 : n1;
@@ -1418,6 +1429,11 @@ static void launch_sweep_nt(const SweepGeom &g, dim3 grid, hipStream_t st, uint3
       hipLaunchKernelGGL((schwinger_sweep_kernel<HEAT, NT>), grid, dim3(NT), lds, st, Mt, Mx, coupling,
                          (const double2 *)src, (double2 *)dst, g.tg, n, kinds, key, cap, qoi_op, qoi_partial);
   }
+  else
+  if (HEAT && NT == 256 && n == 1 && (kinds & 1u) && !g.overridden && g.tg.TW == 64 && g.tg.TH == 32 && Mt % 64 == 0 &&
+      Mx % 32 == 0 && Mt >= 128 && Mx >= 64)  // single heat-bath sweep: compile-time geometry (bit-identical results)
+    hipLaunchKernelGGL((gff_sweep_kernel<HEAT, NT, 64, 32>), grid, dim3(NT), g.lds_bytes, st, Mt, Mx, coupling, src, dst, g.tg,
+                       n, kinds, key, qoi_op, qoi_partial);
   else
     hipLaunchKernelGGL((gff_sweep_kernel<HEAT, NT>), grid, dim3(NT), g.lds_bytes, st, Mt, Mx, coupling, src, dst, g.tg, n,
                        kinds, key, qoi_op, qoi_partial);
