@@ -764,6 +764,21 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 // Sum over the workgroup in a fixed order (lane tree, then waves 0..n-1): bitwise reproducible.
 // `scratch` needs blockDim.x/64 doubles per value.  Result valid in thread 0.
+// Rotate a value through the 64 lanes of a wave by one lane (DPP wave_ror:1 / wave_rol:1, gfx9 family): no LDS, no
+// barrier.  "up": lane l receives the value of lane l - 1 and lane 0 that of lane 63; "down": lane l receives lane l + 1.
+__device__ __forceinline__ double wave_rotate_up(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x13C, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x13C, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_rotate_down(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x134, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x134, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+
 template <int NV>
 __device__ __forceinline__ void block_sum(double (&v)[NV], double *scratch) {
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave, nwave = (blockDim.x + kWave - 1) / kWave;

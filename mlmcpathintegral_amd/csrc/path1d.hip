@@ -294,7 +294,16 @@ __global__ void __launch_bounds__(R >= 8 ? 512 : 1024)
 #pragma unroll
   for (int r = 0; r < R; ++r) xc[r] = xb[kbase + r];
   int buf = 0;
+  // A chain that one wave holds (M = 64 R: BASELINE config 1, M_lat = 128) exchanges its boundary values by rotating the
+  // wave one lane with DPP (wave_ror / wave_rol wrap around, which is the periodic boundary): four v_mov_b32_dpp instead
+  // of two LDS writes, a barrier and two LDS reads per leapfrog step -- the step of such a chain is nothing but this latency.
+  const bool one_wave = NT == kWave;
   auto exchange = [&](const double (&v)[R], double &xl, double &xr) {
+    if (one_wave) {
+      xl = wave_rotate_up(v[R - 1]);  // lane t gets lane t - 1 (lane 0: lane 63)
+      xr = wave_rotate_down(v[0]);    // lane t gets lane t + 1 (lane 63: lane 0)
+      return;
+    }
     ex_first[buf * NT + t] = v[0];
     ex_last[buf * NT + t] = v[R - 1];
     __syncthreads();
