@@ -471,7 +471,13 @@ def main():
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
+        if _STUCK_THREADS:  # a rank with a thread wedged inside a collective must not wait for runtime teardown
+            sys.stdout.flush()
+            os._exit(0)
         dist.destroy_process_group()
+
+
+_STUCK_THREADS = []
 
 
 def stats_allreduce(packed, rank, world, local, backend, torch, dist, chains):
@@ -511,6 +517,7 @@ def stats_allreduce(packed, rank, world, local, backend, torch, dist, chains):
         t.join(timeout=90.0)
         if t.is_alive():
             out["err"] = "timed out after 90 s"
+            _STUCK_THREADS.append(t)  # still inside the RCCL call: main() leaves through os._exit once its line is out
     except Exception as e:  # noqa: BLE001
         out["err"] = repr(e)[:200]
     ok = torch.tensor([1.0 if out.get("ok") else 0.0], device="cuda")
