@@ -79,3 +79,21 @@ def test_bench_refuses_a_rank_count_it_did_not_run():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-cpu-baseline"], env=env,
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 2 and "started 3 rank" in r.stderr
+
+
+def test_overrelaxation_launch_plan_mirrors_the_library():
+    """bench.or_plan restates sweep_draw_impl's launch depths (lattice2d.hip): register-block kernels take up to `fuse`
+    sweeps per launch in launches of equal depth, the others launches of `fuse` and a remainder."""
+    import bench
+    assert bench.or_plan(10, 6, True) == [(5, 2)]
+    assert bench.or_plan(12, 6, True) == [(6, 2)]
+    assert bench.or_plan(7, 6, True) == [(4, 1), (3, 1)]
+    assert bench.or_plan(10, 4, True) == [(4, 1), (3, 2)]
+    assert bench.or_plan(10, 4, False) == [(4, 2), (2, 1)]
+    assert bench.or_plan(3, 4, False) == [(3, 1)]
+    assert bench.or_plan(0, 6, True) == []
+    for n in range(0, 40):
+        for fuse in (1, 2, 4, 6):
+            for blocks in (False, True):
+                plan = bench.or_plan(n, fuse, blocks)
+                assert sum(d * k for d, k in plan) == n and all(1 <= d <= fuse for d, _ in plan)

@@ -18,7 +18,7 @@ class Half:
         self.sweep = 0
     def draw(self, n_or=10, n_hb=1):
         with torch.cuda.stream(self.stream):
-            self.x, self.s = ops.lattice_sweep_draw_pingpong(act, self.x, self.s, n_or, n_hb, seed, self.chain0, self.sweep, 4)
+            self.x, self.s = ops.lattice_sweep_draw_pingpong(act, self.x, self.s, n_or, n_hb, seed, self.chain0, self.sweep, 0)
             self.sweep += n_or + n_hb
             ops.stats_accumulate(self.acc, ops.qoi_avg_plaquette(self.x, size, size))
 
