@@ -438,6 +438,34 @@ int main(int argc, char **argv) {
     EXPECT(s.pool_size() <= 4, "sampler buffer pool grew to %zu", s.pool_size());
     std::printf(" zero-copy OverrelaxedHeatBathSampler: 7 draws identical to in-place sweeps, lent sample intact, pool %zu buffers\n", s.pool_size());
   }
+  // ---- draw + QoI in one pass (Sampler::draw_with_qoi): same numbers as QoI::evaluate_device on the sample it returns -------
+  {
+    auto lat = std::make_shared<Lattice2D>(128, 128, CoarsenBoth);
+    OverrelaxedHeatBathParameters hb;
+    hb.n_sweep_heatbath = 1; hb.n_sweep_overrelax = 5; hb.n_burnin = 0; hb.batch = 3;
+    auto check_fused = [&](std::shared_ptr<Action> act, std::shared_ptr<QoI> qoi, const char *what) {
+      OverrelaxedHeatBathSampler s(act, hb);
+      auto x = std::make_shared<SampleState>(act->sample_size(), 3);
+      DeviceVector dq(3), dref(3);
+      double worst = 0.0;
+      for (int d = 0; d < 3; ++d) {
+        const bool fused = s.draw_with_qoi(x, qoi->fused_kind(), (double *)dq.ptr());
+        EXPECT(fused, "%s: draw_with_qoi refused", what);
+        qoi->evaluate_device(x, (double *)dref.ptr());
+        const auto a = dq.download<double>(), b = dref.download<double>();
+        for (int c = 0; c < 3; ++c) worst = std::fmax(worst, std::fabs(a[c] - b[c]) / std::fmax(1.0, std::fabs(b[c])));
+      }
+      EXPECT(worst < 1e-10, "%s: fused QoI differs from evaluate_device by %g", what, worst);
+      std::printf(" draw_with_qoi (%s): 3 draws x 3 chains, largest relative difference to evaluate_device %.1e\n", what, worst);
+    };
+    auto schw = std::make_shared<QuenchedSchwingerAction>(lat, nullptr, RenormalisationNone, 1.0);
+    schw->set_seed(91, 0);
+    check_fused(schw, std::make_shared<QoIAvgPlaquette>(lat), "Schwinger, average plaquette");
+    check_fused(schw, std::make_shared<QoI2DSusceptibility>(lat), "Schwinger, topological susceptibility");
+    auto gff = std::make_shared<GFFAction>(lat, nullptr, 10.0);
+    gff->set_seed(92, 0);
+    check_fused(gff, std::make_shared<QoI2DPhiSquared>(lat), "GFF, phi^2");
+  }
   // ---- cross-rank statistics: 2 ranks (threads of this process, one GPU) through MonteCarloSingleLevel -------------------------
   {
     const int W = 2;
