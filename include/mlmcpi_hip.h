@@ -198,7 +198,8 @@ int mlmcpi_lattice_initialise(const mlmcpi_lattice_action *act, double *d_phi, u
  * distribution/expcosdistribution.hh:51-65), multicolour order (GFF: (i+j) even, odd; Schwinger:
  * mu=0 & j even, mu=0 & j odd, mu=1 & i even, mu=1 & i odd).  Mt and Mx must be even.  Sweep s
  * uses Philox step sweep0 + s.  d_phi is updated in place; d_scratch has the same size.
- * `fuse` = max number of consecutive overrelaxation sweeps fused into one launch (0 = library default, 4; heat-bath
+ * `fuse` = max number of consecutive overrelaxation sweeps fused into one launch (0 = library default: 6, in launches
+ * of equal depth, on lattices that 64 x 64 tiles divide, 4 otherwise; heat-bath
  *   sweeps always get a launch of their own);
  * results do not depend on it. */
 int mlmcpi_lattice_sweep_draw(const mlmcpi_lattice_action *act, double *d_phi, double *d_scratch, uint32_t B,
