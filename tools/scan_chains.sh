@@ -1,4 +1,8 @@
-for B in 1 2 4 8 16 32 64; do
-timeout -k 10 200 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --chains $B | python -c "
-import json,sys; r=json.loads(sys.stdin.read()); print('chains $B value %.1f G/s'%(r['value']/1e9),'ms/step %.3f'%r['ms_per_step'],'OR launch %.3f ms'%r['roofline']['launch_ms'], 'frac %.3f'%r['roofline']['frac'],'HB %.3f ms'%r['heatbath']['launch_ms'])" || exit 1
+#!/bin/bash
+# Step time against the number of chains per GPU, default workload.
+for B in 1 2 4 8 16 32 64 128; do
+timeout -k 10 200 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra-points --chains $B 2>/dev/null | python -c "
+import json,sys
+r=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][-1])
+print('chains $B', '%.1f G/s' % (r['value']/1e9), '%.4f ms/step' % r['ms_per_step'], [(k['kernel'], round(k['launch_ms'], 4), k['launches_per_step']) for k in r['kernels']])" || exit 1
 done

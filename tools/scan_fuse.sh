@@ -1,2 +1,6 @@
-for f in 1 2 3 4 5; do python bench.py --steps 6 --warmup 2 --no-cpu-baseline --fuse $f | python -c "
-import json,sys; r=json.loads(sys.stdin.read()); print('fuse',r['config']['fuse'],'value %.1f G/s'%(r['value']/1e9),'OR launch %.3f ms'%r['roofline']['launch_ms'],'OR %.1f G upd/s'%(r['roofline']['updates_per_s']/1e9),'frac %.3f'%r['roofline']['frac'],'HB %.2f ms'%r['heatbath']['launch_ms'])"; done
+#!/bin/bash
+# Step time against the most overrelaxation sweeps per launch (--fuse; 0 = library default), default workload.
+for f in 0 1 2 3 4 5 6; do python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra-points --fuse $f 2>/dev/null | python -c "
+import json,sys
+r=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][-1])
+print('fuse $f', 'launches', r['config']['overrelaxation_launches'], '%.3f ms/step' % r['ms_per_step'], '%.1f G/s' % (r['value']/1e9), [(k['kernel'], round(k['launch_ms'], 4), k['launches_per_step']) for k in r['kernels'][:-1]])"; done
