@@ -83,7 +83,8 @@ enum ReduceOp { R_ENERGY = 0, R_XSQUARED = 1, R_WINDING = 2 };
 // action/qm/qmaction.cc:16-24, without materialising the copy)
 template <int KIND, int OP>
 __global__ void __launch_bounds__(256) path_reduce_kernel(PathP P, const double *__restrict__ x,
-                                                          double *__restrict__ partial, uint32_t stride) {
+                                                          double *__restrict__ partial, uint32_t stride, double scale,
+                                                          double *__restrict__ out) {
   __shared__ double red[4];
   const uint32_t b = blockIdx.y, M = P.M;
   const double *xb = x + (size_t)b * M * stride;
@@ -97,7 +98,11 @@ __global__ void __launch_bounds__(256) path_reduce_kernel(PathP P, const double 
     if (OP == R_WINDING) acc[0] += mod_2pi(xj - xl);
   }
   block_sum<1>(acc, red);
-  if (threadIdx.x == 0) partial[(size_t)b * gridDim.x + blockIdx.x] = acc[0];
+  if (threadIdx.x != 0) return;
+  if (gridDim.x == 1)  // one workgroup per chain: the sum is complete, finish here (what path_finish_kernel does)
+    out[b] = (OP == R_WINDING) ? (1. / (4. * kPi * kPi)) * (acc[0] * acc[0]) * scale : scale * acc[0];
+  else
+    partial[(size_t)b * gridDim.x + blockIdx.x] = acc[0];
 }
 
 // out[b] = finish(sum_s partial[b][s]); one thread per chain, fixed summation order
@@ -156,7 +161,7 @@ __global__ void __launch_bounds__(R >= 8 ? 512 : 1024)
                           uint32_t halo, uint32_t nt, double dt, RngKey key0) {
   extern __shared__ double lds[];  // [2][2][NT] boundary exchange | 4*NT/64 reduction scratch | [R][NT] staging
   const uint32_t b = blockIdx.y, seg = blockIdx.x, t = threadIdx.x, NT = blockDim.x, M = P.M;
-  if (done[b]) return;  // reference: repetitions after an acceptance are not run (hmcsampler.cc:10-12)
+  if (done && done[b]) return;  // reference: repetitions after an acceptance are not run (hmcsampler.cc:10-12); null: none yet
   const bool periodic = (halo == 0);
   const uint32_t o0 = seg * owned_len;
   const uint32_t olen = min(owned_len, M - o0);
@@ -422,7 +427,7 @@ __global__ void __launch_bounds__(256)
                       const double *__restrict__ partials, uint32_t nseg, const int32_t *__restrict__ done_in,
                       int32_t *__restrict__ done_out, double *__restrict__ energies, RngKey key0) {
   const uint32_t b = blockIdx.y;
-  if (done_in[b]) {
+  if (done_in && done_in[b]) {  // (null: first repetition, no chain has accepted yet)
     if (blockIdx.x == 0 && threadIdx.x == 0) done_out[b] = 1;
     return;
   }
@@ -685,15 +690,16 @@ static int launch_reduce(const PathP &P, const double *d_x, uint32_t B, double s
   dim3 grid(nsplit, B), block(256);
   switch (P.kind) {
     case MLMCPI_HARMONIC:
-      hipLaunchKernelGGL((path_reduce_kernel<MLMCPI_HARMONIC, OP>), grid, block, 0, st, P, d_x, (double *)ws, stride);
+      hipLaunchKernelGGL((path_reduce_kernel<MLMCPI_HARMONIC, OP>), grid, block, 0, st, P, d_x, (double *)ws, stride, scale, d_out);
       break;
     case MLMCPI_QUARTIC:
-      hipLaunchKernelGGL((path_reduce_kernel<MLMCPI_QUARTIC, OP>), grid, block, 0, st, P, d_x, (double *)ws, stride);
+      hipLaunchKernelGGL((path_reduce_kernel<MLMCPI_QUARTIC, OP>), grid, block, 0, st, P, d_x, (double *)ws, stride, scale, d_out);
       break;
     default:
-      hipLaunchKernelGGL((path_reduce_kernel<MLMCPI_ROTOR, OP>), grid, block, 0, st, P, d_x, (double *)ws, stride);
+      hipLaunchKernelGGL((path_reduce_kernel<MLMCPI_ROTOR, OP>), grid, block, 0, st, P, d_x, (double *)ws, stride, scale, d_out);
   }
   MLMCPI_LAUNCH_CHECK("path_reduce_kernel");
+  if (nsplit == 1) return MLMCPI_OK;
   hipLaunchKernelGGL(path_finish_kernel, dim3((B + 255) / 256), dim3(256), 0, st, (const double *)ws, nsplit, B, OP,
                      scale, d_out);
   MLMCPI_LAUNCH_CHECK("path_finish_kernel");
@@ -845,11 +851,12 @@ int mlmcpi_path_hmc_draw(const mlmcpi_path_action *act, double *d_x, uint32_t B,
   double *partials = (double *)w;
   w += align256((size_t)B * pl.nseg * 4 * 8);
   int32_t *flags = (int32_t *)w;  // [2][B]
-  MLMCPI_HIP_TRY(hipMemsetAsync(flags, 0, (size_t)2 * B * 4, st));
+  // accept flags ping-pong between the two halves of `flags`; the first repetition has none to read (null) and the last
+  // one writes the caller's array directly: a draw is n_rep x (trajectory, accept) and nothing else on the stream
   const uint32_t copy_blocks = choose_split(P.M, B);
   for (uint32_t r = 0; r < n_rep; ++r) {
-    const int32_t *done_in = flags + (size_t)(r & 1) * B;
-    int32_t *done_out = flags + (size_t)((r + 1) & 1) * B;
+    const int32_t *done_in = r == 0 ? nullptr : flags + (size_t)(r & 1) * B;
+    int32_t *done_out = (r + 1 == n_rep && d_accept) ? d_accept : flags + (size_t)((r + 1) & 1) * B;
     RngKey key = make_key(seed, chain0, traj0 + r);
     int rc;
     switch (P.kind) {
@@ -862,8 +869,6 @@ int mlmcpi_path_hmc_draw(const mlmcpi_path_action *act, double *d_x, uint32_t B,
                        (const double *)x_trial, (const double *)partials, pl.nseg, done_in, done_out, d_energies, key);
     MLMCPI_LAUNCH_CHECK("hmc_accept_kernel");
   }
-  if (d_accept)
-    MLMCPI_HIP_TRY(hipMemcpyAsync(d_accept, flags + (size_t)(n_rep & 1) * B, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
   return MLMCPI_OK;
 }
 
