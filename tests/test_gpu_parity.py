@@ -477,13 +477,15 @@ SWEEP_CASES = [
     ("schwinger", 64, 32, dict(beta=1.0), 2),
     ("schwinger", 128, 64, dict(beta=1.0), 2),  # 2 x 2 tiles of the specialised overrelaxation kernel
     ("schwinger", 130, 70, dict(beta=1.0), 1),
+    ("schwinger", 64, 64, dict(beta=2.0), 2),    # one 64 x 64 tile of the 4 x 4 register-block kernel: the buffer wraps onto itself
+    ("schwinger", 192, 128, dict(beta=1.0), 1),  # 3 x 2 tiles of it
     ("schwinger", 16, 16, dict(beta=0.0), 2),    # flat conditionals: kappa is clamped, the draw is uniform
     ("schwinger", 16, 16, dict(beta=40.0), 2),   # sharply peaked conditionals (kappa up to 80)
     ("gff", 16, 16, dict(mass=0.0), 2),          # massless field: kappa = 4
 ]
 
 
-@pytest.mark.parametrize("fuse", [1, 3, 0])  # 0 = library default (4 overrelaxation sweeps per launch)
+@pytest.mark.parametrize("fuse", [1, 3, 0])  # 0 = library default (up to 6 overrelaxation sweeps per launch)
 @pytest.mark.parametrize("kind,Mt,Mx,kw,B", SWEEP_CASES)
 def test_lattice_sweeps_match_oracle(gpu_ops, orc, kind, Mt, Mx, kw, B, fuse):
     act, A = make_lattice(orc, kind, Mt, Mx, **kw)
@@ -493,7 +495,7 @@ def test_lattice_sweeps_match_oracle(gpu_ops, orc, kind, Mt, Mx, kw, B, fuse):
     xd, scratch = dev(x0), torch.empty((B, n), dtype=torch.float64, device="cuda")
     xo = x0.copy()
     sweep = 100
-    for n_or, n_hb in ((1, 0), (5, 0), (0, 1), (2, 1), (4, 2)):
+    for n_or, n_hb in ((1, 0), (5, 0), (0, 1), (2, 1), (4, 2), (6, 1)):
         xd.copy_(dev(xo))  # every case starts from identical inputs on both sides
         gpu_ops.lattice_sweep_draw(act, xd, scratch, n_or, n_hb, SEED, 11, sweep, fuse=fuse)
         for b in range(B):
