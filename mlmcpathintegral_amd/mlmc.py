@@ -81,6 +81,7 @@ class PathMLMC:
         # stable leapfrog step ~ a^(1/2) for the kinetic term and acceptance ~ M dt^4: scale gently with the level
         self.dts = [dt0 * (2.0 ** (0.25 * l)) for l in range(n_level)]
         self.n_level, self.rank, self.world, self.B = n_level, rank, world, B
+        self.concurrent_levels, self._streams = True, {}
         self.shares = chains.partition_instances(level_costs(self.acts, nt, n_sub), B, world)
         self.levels = {l: PathLevel(self.acts, l, nb, nt, self.dts, seed, chain0=c0, n_sub=n_sub)
                        for l, (c0, nb) in self.shares[rank].items()}
@@ -96,9 +97,29 @@ class PathMLMC:
             lv.thermalise(n)
 
     def pass_(self, n_samples):
-        for lv in self.levels.values():
-            for _ in range(n_samples):
-                lv.sample()
+        """n_samples Y samples of every level instance this rank owns.  The instances are independent, and the coarse ones
+        are too small to fill the GPU on their own (2048 sites x 512 chains): each level runs on a HIP stream of its own,
+        forked from and joined to the caller's stream, so their kernels overlap (the library's work buffers are per
+        stream).  Results do not depend on it."""
+        if len(self.levels) < 2 or not self.concurrent_levels:
+            for lv in self.levels.values():
+                for _ in range(n_samples):
+                    lv.sample()
+            return
+        main = torch.cuda.current_stream()
+        if not self._streams:
+            self._streams = {l: torch.cuda.Stream() for l in self.levels}
+        fork = torch.cuda.Event()
+        fork.record(main)
+        for l, lv in self.levels.items():
+            st = self._streams[l]
+            st.wait_event(fork)
+            with torch.cuda.stream(st):
+                for _ in range(n_samples):
+                    lv.sample()
+            join = torch.cuda.Event()
+            join.record(st)
+            main.wait_event(join)
 
     def packed_finest(self):
         """per-chain moment rows of the finest level instance this rank owns (zeros if it owns none)"""
