@@ -72,6 +72,9 @@ def spawn_ranks(a):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
+    # The host driver of this pool supports dmabuf IPC only: with the legacy IPC mode RCCL's intra-node transport (and
+    # any sharing of device memory between the ranks' processes) fails in hipIpcGetMemHandle.  The image exports it
+    # already; set here too so that a shell without it still starts ranks that can talk.
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return subprocess.call(cmd, env=env)
 
@@ -80,7 +83,7 @@ def build_id():
     """Identifies the kernel build the committed PMC figures belong to: hash of the kernel sources."""
     h = hashlib.sha1()
     d = os.path.join(ROOT, "mlmcpathintegral_amd", "csrc")
-    for f in ("device_common.hpp", "internal.hpp", "lattice2d.hip", "path1d.hip", "runtime.hip"):
+    for f in ("device_common.hpp", "internal.hpp", "lattice2d.hip", "path1d.hip", "runtime.hip", "gff_levels.hip", "comm_rccl.cc"):
         with open(os.path.join(d, f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:12]
@@ -280,6 +283,26 @@ def main():
     coll_device = "cuda" if backend == "nccl" else "cpu"
     chain0 = rank * B  # global chain indices of this rank: [chain0, chain0 + B)
 
+    # The statistics exchange of an N-rank run, set up and PROVEN here, on the main thread, before anything is timed:
+    # the library's own communicator (libmlmcpi_rccl.so: ncclCommInitRank / ncclAllReduce through include/mlmcpi_comm.h,
+    # the calls mlmcpi::RcclExchange makes for the C++ classes).  comm.establish ends the run on EVERY rank with status 3
+    # (message on stderr) if any rank fails to build it or the check all-reduce does not return what N ranks must
+    # produce, and with a traceback + status 1 if a collective hangs.  No fallback path exists.
+    exchange, rccl = None, None
+    if world > 1:
+        from mlmcpathintegral_amd import comm
+        if backend == "nccl":
+            exchange, chk = comm.establish(rank, world, dist, torch,
+                                           lambda: comm.make_rccl_exchange(rank, world, local, dist, torch),
+                                           prepare=comm.open_runtime, agree_device="cuda")
+            rccl = {"ranks": chk["ranks"], "lib": comm.library_path(), "runtime": comm.runtime_path(),
+                    "allreduce_check": chk["allreduce_check"], "expected": chk["expected"],
+                    "rendezvous": "128-byte id broadcast with torch.distributed"}
+        else:
+            exchange, chk = comm.establish(rank, world, dist, torch, lambda: TorchExchange(torch, dist))
+            rccl = {"ranks": chk["ranks"], "lib": None, "runtime": None, "allreduce_check": chk["allreduce_check"],
+                    "expected": chk["expected"], "rehearsal": f"torch.distributed {backend}: NOT an RCCL run"}
+
     ev = lambda: torch.cuda.Event(enable_timing=True)
     events = []
     extra = {}
@@ -322,6 +345,7 @@ def main():
         n_level = 5
         est = mlmc.PathMLMC(abi.QUARTIC, size, size / 8.0, n_level, B, nt=a.nt, dt0=a.dt or 0.02, seed=a.seed, rank=rank,
                             world=world, n_sub=2, params=dict(lam=1.0, x0=1.0))
+        est.exchange = exchange  # the level-table all-reduce goes through the same communicator
         est.thermalise(64)
         units_per_step = 0  # site-steps per step over all ranks: HMC of the feeding level + two-level pass
         for l in range(n_level):
@@ -390,15 +414,20 @@ def main():
             del Wx
         extra["single_chain"]["note"] = "BASELINE configs[3] read literally: one chain per GPU (16 MiB state, cache resident)"
 
-    # the one collective: packed per-chain moments of the QoI, summed over ranks (RCCL)
-    packed, collective = stats_allreduce(chains.pack_moments(acc_of()), rank, world, local, backend, torch, dist, chains)
-    if a.workload == "quartic_mlmc":
-        mlmc_q, mlmc_e, mlmc_t = est.estimate(device=coll_device)  # the level-table exchange (RCCL when world > 1)
-        mlmc_t = mlmc_t.cpu()
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
+    # the one collective: packed per-chain moments of the QoI, summed over ranks through the exchange proven above; the
+    # slowest rank's time travels in the same buffer (one slot per rank, max of the sums)
+    packed = chains.pack_moments(acc_of()).cpu()
+    collective = "none (one rank)"
     if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed = float(tmax.item())
+        slots = [0.0] * world
+        slots[rank] = elapsed
+        red = exchange.allreduce_sum_host(packed.tolist() + slots)
+        packed = torch.tensor(red[:packed.numel()], dtype=torch.float64)
+        elapsed = max(red[packed.numel():])
+        collective = (f"mlmcpi_comm_allreduce_sum_host_f64 (libmlmcpi_rccl.so: ncclAllReduce, {rccl['ranks']} ranks)"
+                      if backend == "nccl" else f"torch.distributed all_reduce ({backend} rehearsal, {rccl['ranks']} ranks)")
+    if a.workload == "quartic_mlmc":
+        mlmc_q, mlmc_e, mlmc_t = est.estimate()  # the level-table exchange, through est.exchange when world > 1
     qoi_mean = float(packed[1] / packed[0]) if float(packed[0]) > 0 else None
 
     if rank == 0:
@@ -420,6 +449,7 @@ def main():
             "data": "synthetic",
             "step_includes": ["sampler->draw", "qoi->evaluate", "stats->record_sample"],
             "stats_collective": collective,
+            "rccl": rccl,
             "kernel_build": build_id(),
         }
         if a.workload in ("schwinger", "gff"):
@@ -471,61 +501,25 @@ def main():
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
-        if _STUCK_THREADS:  # a rank with a thread wedged inside a collective must not wait for runtime teardown
-            sys.stdout.flush()
-            os._exit(0)
+        if hasattr(exchange, "close"):
+            exchange.close()
         dist.destroy_process_group()
 
 
-_STUCK_THREADS = []
+class TorchExchange:
+    """Stand-in for comm.Comm in rehearsals of the N-rank path on a box with fewer GPUs than ranks
+    (MLMCPI_BENCH_BACKEND=gloo): the same two calls over torch.distributed.  Never used by an RCCL run."""
 
+    def __init__(self, torch, dist):
+        self.torch, self.dist = torch, dist
 
-def stats_allreduce(packed, rank, world, local, backend, torch, dist, chains):
-    """Sum of the packed statistics buffer over ranks.  With RCCL ranks it goes through the library's own C entry point
-    (include/mlmcpi_comm.h, libmlmcpi_rccl.so: ncclAllReduce on the RCCL runtime this process already carries) -- the
-    same call the C++ Statistics / MonteCarlo classes make through mlmcpi::RcclExchange; torch.distributed only carries
-    the 128-byte rendezvous id.  Should that path fail or stall on any rank, every rank falls back to
-    torch.distributed's all_reduce (same RCCL underneath) and says so."""
-    if world == 1:
-        return packed.cpu(), "none (one rank)"
-    if backend != "nccl":
-        return chains.allreduce_moments(packed.cpu()), f"torch.distributed all_reduce ({backend} rehearsal)"
-    import threading
-    from mlmcpathintegral_amd import comm
-    how, out = "", {}
-    try:
-        comm.open_runtime()
-        idt = torch.zeros(comm.ID_BYTES, dtype=torch.uint8, device="cuda")
-        if rank == 0:
-            idt.copy_(torch.frombuffer(bytearray(comm.unique_id()), dtype=torch.uint8))
-        dist.broadcast(idt, src=0)
-        id128 = bytes(idt.cpu().tolist())
-        buf = packed.detach().clone().contiguous()
+    def allreduce_sum_host(self, values):
+        t = self.torch.tensor(values, dtype=self.torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return t.tolist()
 
-        def work():
-            try:
-                torch.cuda.set_device(local)  # the current device is thread local: this thread starts on device 0
-                c = comm.Comm(rank, world, id128, local)
-                c.allreduce_sum_(buf)
-                torch.cuda.synchronize()
-                out["ok"] = True
-                out["comm"] = c
-            except Exception as e:  # noqa: BLE001 -- any failure means: fall back
-                out["err"] = repr(e)[:200]
-        t = threading.Thread(target=work, daemon=True)
-        t.start()
-        t.join(timeout=90.0)
-        if t.is_alive():
-            out["err"] = "timed out after 90 s"
-            _STUCK_THREADS.append(t)  # still inside the RCCL call: main() leaves through os._exit once its line is out
-    except Exception as e:  # noqa: BLE001
-        out["err"] = repr(e)[:200]
-    ok = torch.tensor([1.0 if out.get("ok") else 0.0], device="cuda")
-    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-    if float(ok.item()) == 1.0:
-        return buf.cpu(), "mlmcpi_comm_allreduce_sum_f64 (libmlmcpi_rccl.so: ncclAllReduce over xGMI; rendezvous id via torch.distributed)"
-    red = chains.allreduce_moments(packed.detach().clone())
-    return red.cpu(), f"torch.distributed all_reduce (fallback; libmlmcpi_rccl.so path: {out.get('err', 'failed on another rank')})"
+    def size(self):
+        return self.dist.get_world_size()
 
 
 def register_resident_roofline(kernel, launch_ms, floor_bytes, streaming_bytes, valu, note):

@@ -14,7 +14,10 @@
 //           prints link-updates/s of the C++ path)
 // Several ranks (one process per GPU): start N copies with RANK / WORLD_SIZE / LOCAL_RANK set (torchrun, mpirun, a
 // shell loop); they meet through RCCL (mlmcpi::RcclExchange, rendezvous file $MLMCPI_ID_FILE or
-// /dev/shm/mlmcpi_id_$MASTER_PORT); rank r samples chain(s) r * batch ...
+// /dev/shm/mlmcpi_id_<launcher pid>_$MASTER_PORT) and verify the group (RcclExchange::verify) or exit non-zero; rank r
+// samples chain(s) r * batch ...
+#include <unistd.h>
+
 #include <chrono>
 #include <cstring>
 #include <map>
@@ -43,8 +46,13 @@ int main(int argc, char **argv) {
   if (world > 1) {
     check(mlmcpi_set_device(local_rank), "mlmcpi_set_device");
     const char *idf = std::getenv("MLMCPI_ID_FILE");
-    const std::string id_file = idf ? idf : std::string("/dev/shm/mlmcpi_id_") + (std::getenv("MASTER_PORT") ? std::getenv("MASTER_PORT") : "0");
-    exchange = std::make_shared<RcclExchange>(rank, world, id_file, local_rank);
+    // unique per launch: the launcher's pid (the ranks are its children) and its port; a file a dead run left behind is
+    // rejected by mlmcpi_comm_init_file in any case (it names its writer)
+    const std::string id_file = idf ? idf : std::string("/dev/shm/mlmcpi_id_") + std::to_string((long)getppid()) + "_" +
+                                                (std::getenv("MASTER_PORT") ? std::getenv("MASTER_PORT") : "0");
+    auto rccl = std::make_shared<RcclExchange>(rank, world, id_file, local_rank);
+    rccl->verify(world);  // the communicator's own rank count and a sum over ranks, or message + exit(EXIT_FAILURE)
+    exchange = rccl;
     if (rank != 0) std::cout.setstate(std::ios_base::failbit);  // mpi_parallel::cout: the master prints
   }
   std::shared_ptr<Action> action;
@@ -190,7 +198,7 @@ int main(int argc, char **argv) {
     const bool sweeping = o["sampler"] == "heatbath";
     const double units = sweeping ? (double)action->sample_size() * sweeps : (double)action->sample_size() * (num("nt") + 1);
     std::cout << std::setprecision(6) << "{\"driver\": \"host/driver (C++ Sampler::draw + QoI::evaluate_device + stats_accumulate)\", "
-              << "\"ranks\": " << world << ", \"batch\": " << batch << ", \"samples\": " << n_samples
+              << "\"ranks\": " << (exchange ? exchange->size() : 1) << ", \"batch\": " << batch << ", \"samples\": " << n_samples
               << ", \"ms_per_sample\": " << 1e3 * tot[2] / n_samples << ", \"updates_per_s\": " << std::scientific
               << units * batch * world * n_samples / tot[2] << std::fixed << ", \"qoi_mean\": " << tot[1] / tot[0] << "}" << std::endl;
     return 0;

@@ -1,4 +1,5 @@
-// stats_check.cc -- CPU-only harness for the cross-rank statistics of include/mlmcpi/statistics.hh (no GPU, no RCCL):
+// stats_check.cc -- CPU-only harness for the cross-rank statistics of include/mlmcpi/statistics.hh (no GPU; RCCL only in
+// the --rccl-join mode):
 //   stats_check single  K NBURN            < samples      one rank
 //   stats_check threads W K NBURN          < samples      W ranks as threads (ThreadExchange); sample i goes to rank i % W
 //   stats_check loop    W K NMIN EPS N     synthetic AR(1) chains: the do-while of MonteCarloSingleLevel::evaluate
@@ -29,6 +30,15 @@ static void dump(const Statistics &s) {
 int main(int argc, char **argv) {
   if (argc < 2) return 2;
   const std::string mode = argv[1];
+  if (mode == "--rccl-join" && argc >= 6) {
+    // stats_check --rccl-join PATH RANK WORLD TIMEOUT_S: join an RCCL group through the rendezvous file, the way host/driver
+    // does.  Used by the tests for the failure convention (an unusable file is "ERROR: ..." + EXIT_FAILURE before RCCL or a
+    // GPU is touched); with a live group it verifies it and prints the communicator's rank count.
+    RcclExchange ex(std::atoi(argv[3]), std::atoi(argv[4]), std::string(argv[2]), 0, std::atof(argv[5]));
+    ex.verify(std::atoi(argv[4]));
+    std::printf("%d\n", ex.size());
+    return 0;
+  }
   if (mode == "single" || mode == "threads") {
     const int W = mode == "threads" ? std::atoi(argv[2]) : 1;
     const unsigned K = std::atoi(argv[mode == "threads" ? 3 : 2]), nburn = std::atoi(argv[mode == "threads" ? 4 : 3]);

@@ -65,6 +65,19 @@ public:
   void allreduce_sum(double *buf, size_t n) override {
     if (mlmcpi_comm_allreduce_sum_host_f64(comm, buf, n)) die("mlmcpi_comm_allreduce_sum_host_f64");
   }
+  /** Proof that the group that formed is the one asked for, before any result depends on it: the communicator's own
+   *  count (ncclCommCount) equals `expected` and one all-reduce of (1, rank) returns (N, N (N - 1) / 2).  Otherwise
+   *  message + exit, like every other failure of this class: a run either has its N ranks or a non-zero status. */
+  void verify(int expected) {
+    const int n = size(), r = rank();
+    double probe[2] = {1.0, (double)r};
+    allreduce_sum(probe, 2);
+    if (n != expected || probe[0] != (double)expected || probe[1] != 0.5 * expected * (expected - 1.0)) {
+      std::fprintf(stderr, "ERROR: RcclExchange: asked for %d ranks, communicator reports %d, sum of ones %g, sum of ranks %g\n",
+                   expected, n, probe[0], probe[1]);
+      std::exit(EXIT_FAILURE);
+    }
+  }
 
 private:
   static void die(const char *what) {  // the reference's convention: message + exit (mpi/mpi_wrapper.cc:174-177)

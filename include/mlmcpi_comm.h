@@ -32,6 +32,9 @@ const char *mlmcpi_comm_last_error(void);
  * /opt/rocm/lib/librccl.so.1.  Idempotent; the other entry points call it with NULL when it has not been called. */
 int mlmcpi_comm_load(const char *path);
 
+/* File the RCCL runtime in use was mapped from (dladdr of its ncclAllReduce); "" before mlmcpi_comm_load.  For run records. */
+const char *mlmcpi_comm_runtime(void);
+
 /* rank 0: a fresh 128-byte rendezvous id (ncclGetUniqueId), to be handed to every rank by whatever channel the host
  * program has (MPI_Bcast in the reference's tree, torch.distributed in bench.py, a file: mlmcpi_comm_init_file) */
 int mlmcpi_comm_unique_id(void *id128);
@@ -39,10 +42,15 @@ int mlmcpi_comm_unique_id(void *id128);
 /* Join the communicator of `world` ranks on HIP device `device` (ncclCommInitRank).  Collective over all ranks. */
 int mlmcpi_comm_init(int rank, int world, const void *id128, int device, mlmcpi_comm **out);
 
-/* The same with a file as the rendezvous channel: rank 0 writes the id to `path` (atomically), the others wait up to
- * timeout_s seconds for it.  For C++ hosts started as N processes without MPI (host/driver). */
+/* The same with a file as the rendezvous channel: rank 0 removes whatever lies at `path`, then writes the id there
+ * (atomically) together with its own pid and process start time; the others wait up to timeout_s seconds for a record
+ * whose writer is still alive -- a file left behind by a run that died is never accepted.  `path` must be on a file
+ * system all ranks of the node see (/dev/shm) and should be unique per launch (host/driver puts the launcher's pid in
+ * the name).  For C++ hosts started as N processes without MPI (host/driver). */
 int mlmcpi_comm_init_file(int rank, int world, const char *path, int device, double timeout_s, mlmcpi_comm **out);
 
+/* rank and number of ranks as the COMMUNICATOR reports them (ncclCommUserRank / ncclCommCount) -- not an echo of the
+ * arguments of mlmcpi_comm_init: a caller can check that the group that formed is the one it asked for */
 int mlmcpi_comm_rank(const mlmcpi_comm *c, int *rank);
 int mlmcpi_comm_size(const mlmcpi_comm *c, int *size);
 

@@ -53,21 +53,12 @@ def summarise(packed, n_chains_total=None, chain_means=None):
     return out
 
 
-# ---- level sharding of the multilevel estimator -------------------------------------------
-# Levels are independent estimators (montecarlomultilevel.cc:27-45): level l runs on rank l % world.  Once per pass of
-# the do-while of montecarlomultilevel.cc:115-165 the ranks exchange a table [n_level, 5] =
-# (samples, mean, variance, tau_int, cost): every rank fills the rows of its levels, leaves the others zero, and one
-# all-reduce(SUM) of the table (= the all-gather of disjoint rows) gives every rank the whole picture.  This is the
-# same contract as LevelExchange::allreduce_sum in include/mlmcpi/multilevel.hh.
+# ---- the level table of the multilevel estimator (montecarlomultilevel.cc:115-165) -----------------------------------------
+# Once per pass of the do-while the ranks need, per level, (samples, mean, variance, tau_int, cost).  Rows of levels a
+# rank does not hold are zero, and one all-reduce(SUM) gives every rank the whole table -- the contract of
+# LevelExchange::allreduce_sum in include/mlmcpi/multilevel.hh.  Which rank holds what is decided by
+# partition_instances below (equal-cost shares of (level, chain) pairs).
 N_LEVEL_FIELDS = 5
-
-
-def level_owner(level, world):
-    return level % world
-
-
-def owned_levels(n_level, rank, world):
-    return [l for l in range(n_level) if level_owner(l, world) == rank]
 
 
 def level_table(n_level, rows, device="cpu"):

@@ -1,5 +1,8 @@
 // comm_rccl.cc -- libmlmcpi_rccl.so: the statistics all-reduce on RCCL (include/mlmcpi_comm.h).
 // The RCCL runtime is opened with dlopen; only its public header is used at build time.
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE  // dladdr
+#endif
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -39,6 +42,8 @@ struct Rccl {
   ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
 } g_rccl;
 std::mutex g_load_mutex;
@@ -64,6 +69,8 @@ int load(const char *path) {
   SYM(CommInitRank, "ncclCommInitRank");
   SYM(AllReduce, "ncclAllReduce");
   SYM(CommDestroy, "ncclCommDestroy");
+  SYM(CommCount, "ncclCommCount");
+  SYM(CommUserRank, "ncclCommUserRank");
   SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
   g_rccl.handle = h;
@@ -97,6 +104,14 @@ extern "C" {
 const char *mlmcpi_comm_last_error(void) { return g_err.c_str(); }
 
 int mlmcpi_comm_load(const char *path) { return load(path); }
+
+const char *mlmcpi_comm_runtime(void) {
+  static thread_local std::string where;
+  where.clear();
+  Dl_info info;
+  if (g_rccl.handle && g_rccl.AllReduce && dladdr((void *)g_rccl.AllReduce, &info) && info.dli_fname) where = info.dli_fname;
+  return where.c_str();
+}
 
 int mlmcpi_comm_unique_id(void *id128) {
   if (!id128) return fail(ERR_INVALID, "id128 is NULL");
@@ -132,14 +147,57 @@ int mlmcpi_comm_init(int rank, int world, const void *id128, int device, mlmcpi_
   return OK;
 }
 
+// The rendezvous file.  A run that dies before rank 0 removes its file leaves it behind, and the next run's ranks > 0
+// would read the old id at once and sit in ncclCommInitRank with mismatched ids for ever.  So the file
+// names its writer -- pid and the start time of that pid (/proc/<pid>/stat, field 22) -- and a reader accepts it only
+// while that very process is alive: a file left by a dead run is ignored until the live rank 0 replaces it (rename is
+// atomic).  Rank 0 also removes whatever it finds at `path` before it writes.  Same node by construction (one process
+// per GPU of one node, /dev/shm or any local path).
+namespace {
+struct IdFile {
+  char magic[8];               // "MLMCPI1\0"
+  int64_t pid;                 // the writer (rank 0)
+  uint64_t start_ticks;        // its start time in clock ticks since boot
+  char id[MLMCPI_COMM_ID_BYTES];
+};
+const char kIdMagic[8] = {'M', 'L', 'M', 'C', 'P', 'I', '1', 0};
+
+// start time of process `pid` (0: no such process)
+uint64_t process_start_ticks(int64_t pid) {
+  char name[64], buf[1024];
+  snprintf(name, sizeof name, "/proc/%lld/stat", (long long)pid);
+  FILE *f = fopen(name, "r");
+  if (!f) return 0;
+  const size_t got = fread(buf, 1, sizeof buf - 1, f);
+  fclose(f);
+  buf[got] = 0;
+  char *p = strrchr(buf, ')');  // the command name (field 2) may contain anything; the fields resume after its ')'
+  if (!p) return 0;
+  unsigned long long ticks = 0;
+  int field = 2;
+  for (char *tok = strtok(p + 1, " "); tok; tok = strtok(nullptr, " "))
+    if (++field == 22) {  // starttime
+      if (sscanf(tok, "%llu", &ticks) != 1) return 0;
+      break;
+    }
+  if (field != 22) return 0;
+  return ticks ? ticks : 1;
+}
+}  // namespace
+
 int mlmcpi_comm_init_file(int rank, int world, const char *path, int device, double timeout_s, mlmcpi_comm **out) {
   if (!path || !*path) return fail(ERR_INVALID, "rendezvous path is empty");
-  char id[MLMCPI_COMM_ID_BYTES];
+  IdFile rec;
   if (rank == 0) {
-    if (int rc = mlmcpi_comm_unique_id(id)) return rc;
-    const std::string tmp = std::string(path) + ".tmp";
+    unlink(path);  // whatever an earlier run left here
+    memset(&rec, 0, sizeof rec);
+    memcpy(rec.magic, kIdMagic, sizeof rec.magic);
+    rec.pid = (int64_t)getpid();
+    rec.start_ticks = process_start_ticks(rec.pid);
+    if (int rc = mlmcpi_comm_unique_id(rec.id)) return rc;
+    const std::string tmp = std::string(path) + ".tmp." + std::to_string((long long)rec.pid);
     FILE *f = fopen(tmp.c_str(), "wb");
-    if (!f || fwrite(id, 1, sizeof id, f) != sizeof id) {
+    if (!f || fwrite(&rec, 1, sizeof rec, f) != sizeof rec) {
       if (f) fclose(f);
       return fail(ERR_INVALID, "cannot write the rendezvous id to %s", tmp.c_str());
     }
@@ -147,32 +205,36 @@ int mlmcpi_comm_init_file(int rank, int world, const char *path, int device, dou
     if (rename(tmp.c_str(), path) != 0) return fail(ERR_INVALID, "cannot rename %s to %s", tmp.c_str(), path);
   } else {
     const auto t0 = std::chrono::steady_clock::now();
+    std::string why = "no file";
     for (;;) {
       FILE *f = fopen(path, "rb");
       if (f) {
-        const size_t got = fread(id, 1, sizeof id, f);
+        const size_t got = fread(&rec, 1, sizeof rec, f);
         fclose(f);
-        if (got == sizeof id) break;
+        if (got != sizeof rec || memcmp(rec.magic, kIdMagic, sizeof rec.magic) != 0) why = "not a rendezvous record";
+        else if (rec.start_ticks == 0 || process_start_ticks(rec.pid) != rec.start_ticks) why = "stale: its writer is gone";
+        else break;
       }
       if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s)
-        return fail(ERR_INVALID, "rank %d: no rendezvous id at %s after %.0f s", rank, path, timeout_s);
+        return fail(ERR_INVALID, "rank %d: no usable rendezvous id at %s after %.0f s (%s)", rank, path, timeout_s, why.c_str());
       std::this_thread::sleep_for(std::chrono::milliseconds(20));
     }
   }
-  const int rc = mlmcpi_comm_init(rank, world, id, device, out);
+  const int rc = mlmcpi_comm_init(rank, world, rec.id, device, out);
   if (rc == OK && rank == 0) unlink(path);  // every rank has joined once ncclCommInitRank returns on rank 0
   return rc;
 }
 
+// What the COMMUNICATOR says (ncclCommUserRank / ncclCommCount), not what the caller passed to mlmcpi_comm_init
 int mlmcpi_comm_rank(const mlmcpi_comm *c, int *rank) {
   if (!c || !rank) return fail(ERR_INVALID, "bad arguments");
-  *rank = c->rank;
+  NCCL_TRY(g_rccl.CommUserRank(c->comm, rank));
   return OK;
 }
 
 int mlmcpi_comm_size(const mlmcpi_comm *c, int *size) {
   if (!c || !size) return fail(ERR_INVALID, "bad arguments");
-  *size = c->world;
+  NCCL_TRY(g_rccl.CommCount(c->comm, size));
   return OK;
 }
 

@@ -468,8 +468,12 @@ struct HbPool {
 
 template <int NT, int S, class Setup, class Commit>
 __device__ __forceinline__ void heatbath_cells(uint32_t total, const RngKey &key, HbPool &pool, Setup setup, Commit commit) {
-  for (uint32_t b0 = 0; b0 < total; b0 += S * NT) {  // uniform trip count: the barrier below needs every thread
+  for (uint32_t b0 = 0; b0 < total; b0 += S * NT) {  // uniform trip count: the barriers below need every thread
     uint32_t *cnt = pool.count() + (pool.use & 1u);
+    // The other counter (the one of the previous and of the next use) is cleared HERE: after wave 0's read of it in the
+    // previous use's drain (thread 0 is in wave 0: program order) and before the barrier of this use, which every push
+    // of the next use follows.
+    if (pool.cap && threadIdx.x == 0) pool.count()[(pool.use + 1u) & 1u] = 0;
 #pragma unroll
     for (int m = 0; m < S; ++m) {
       const uint32_t idx = b0 + m * NT + threadIdx.x;
@@ -494,8 +498,6 @@ __device__ __forceinline__ void heatbath_cells(uint32_t total, const RngKey &key
     }
     if (pool.cap) {
       __syncthreads();
-      // the other counter: last read before the barrier that ended its use, next written after the one that ends this use
-      if (threadIdx.x == 0) pool.count()[(pool.use + 1u) & 1u] = 0;
       if (threadIdx.x < kWave) {  // wave 0 finishes the pooled cells, one per lane
         const uint32_t filled = min(*cnt, pool.cap);
         for (uint32_t e = threadIdx.x; e < filled; e += kWave) {
@@ -509,6 +511,9 @@ __device__ __forceinline__ void heatbath_cells(uint32_t total, const RngKey &key
         }
       }
       ++pool.use;
+      // Another pass of this phase follows (more than S NT cells: tiles larger than the default): its pushes reuse the
+      // entry arrays wave 0 is still draining, so it waits.  (Between two phases the caller's own barrier does that.)
+      if (b0 + S * NT < total) __syncthreads();
     }
   }
 }

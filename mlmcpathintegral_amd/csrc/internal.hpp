@@ -49,7 +49,7 @@ struct Tuning {
   bool or_patch = false;                         // MLMCPI_OR_KERNEL=patch: 2 x 2 register blocks on 64 x 32 tiles instead of 4 x 4 on 64 x 64
   uint32_t or_threads = 0;                       // MLMCPI_OR_THREADS (LDS-resident kernel's workgroup size; 0: default)
 };
-const Tuning &tuning();
+Tuning tuning();  // a copy taken under the lock: callers snapshot it once per call
 
 constexpr uint32_t kMaxFuse = 16;  // max sweeps fused in one launch (kinds travel in a bitmask)
 

@@ -1384,10 +1384,9 @@ struct SweepGeom {
 // Tile shape and workgroup size for a launch of `nsweeps` fused sweeps.  Default: 64 x 32 owned sites,
 // 256 threads (4 workgroups per CU at one sweep).  MLMCPI_SWEEP_TILE=TWxTHxNT overrides (tuning knob;
 // results never depend on it).
-static SweepGeom choose_geometry(uint32_t Mt, uint32_t Mx, uint32_t nsweeps, uint32_t bytes_per_cell) {
+static SweepGeom choose_geometry(const Tuning &tune, uint32_t Mt, uint32_t Mx, uint32_t nsweeps, uint32_t bytes_per_cell) {
   uint32_t TW = 64, TH = 32, NT = 256;
   bool overridden = false;
-  const Tuning &tune = tuning();
   if (tune.tile_w) {
     TW = tune.tile_w; TH = tune.tile_h; NT = tune.tile_nt;
     overridden = true;
@@ -1561,7 +1560,7 @@ static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, doub
                  act->Mx);
   // library default: best measured whole-step time -- up to 6 sweeps per launch where the 4 x 4
   // register-block kernel applies, 4 otherwise
-  const Tuning &tune = tuning();
+  const Tuning tune = tuning();  // ONE snapshot per draw: mlmcpi_set_option on another thread cannot split a launch plan
   const bool or_blocks = !tune.or_lds && !tune.or_patch && !tune.tile_w && act->Mt % 64 == 0 && act->Mx % 64 == 0;
   if (fuse == 0) fuse = or_blocks ? 6 : 4;
   if (fuse > kMaxFuse) fuse = kMaxFuse;
@@ -1596,7 +1595,7 @@ static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, doub
       for (uint32_t q = 0; q < n; ++q)
         if (s + q >= n_overrelax) kinds |= 1u << q;
       // Schwinger: two link angles per site; GFF heat bath: field + parked normal per site
-      g = choose_geometry(act->Mt, act->Mx, n, (schw || kinds) ? 16 : 8);
+      g = choose_geometry(tune, act->Mt, act->Mx, n, (schw || kinds) ? 16 : 8);
       if (g.lds_bytes <= 160 * 1024 - 256 || n == 1) break;
       --n;
     }
@@ -1611,7 +1610,7 @@ static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, doub
       double2 *out2 = (double2 *)dst;
       // more fused sweeps -> larger LDS image -> fewer resident workgroups: keep the wave count per CU up
       // with wider workgroups (MLMCPI_OR_THREADS overrides: tuning knob)
-      const bool use_patch = !tuning().or_lds;
+      const bool use_patch = !tune.or_lds;
       if (or_blocks) {  // 4 x 4 register blocks on 64 x 64 tiles (n <= 6)
         dim3 bgrid((act->Mt / 64) * (act->Mx / 64), B);
 #define MLMCPI_OR_BLOCK(KK) hipLaunchKernelGGL((schwinger_or_block_kernel<KK>), bgrid, dim3(OrBlockGeom<KK>::NT), OrBlockGeom<KK>::lds_bytes, st, act->Mt, act->Mx, in2, out2, act->Mt / 64)
@@ -1645,7 +1644,7 @@ static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, doub
         continue;
       }
       uint32_t nt_or = n >= 4 ? 1024 : 512;  // measured best (tools/scan_or.sh): K <= 3: 512, K >= 4: 1024
-      if (tuning().or_threads) nt_or = tuning().or_threads;
+      if (tune.or_threads) nt_or = tune.or_threads;
 #define MLMCPI_OR(KK, NN) hipLaunchKernelGGL((schwinger_or_kernel<64, 32, KK, NN>), sgrid, dim3(NN), lds, st, act->Mt, act->Mx, in2, out2, act->Mt / 64)
 #define MLMCPI_OR_K(KK) do { if (nt_or == 1024) MLMCPI_OR(KK, 1024); else if (nt_or == 512) MLMCPI_OR(KK, 512); else MLMCPI_OR(KK, 256); } while (0)
       switch (n) {
@@ -1664,7 +1663,7 @@ static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, doub
       const size_t lds = (size_t)(32 + 4 * n) * (64 + 4 * n + 1) * sizeof(double);
       dim3 sgrid((act->Mt / 64) * (act->Mx / 32), B);
       const double mu2 = gff_mu2(*act);
-      const bool use_gff_patch = !tuning().or_lds;
+      const bool use_gff_patch = !tune.or_lds;
       if (or_blocks) {  // 4 x 4 register blocks on 64 x 64 tiles (n <= 6)
         dim3 bgrid((act->Mt / 64) * (act->Mx / 64), B);
 #define MLMCPI_GFF_BLOCK(KK) hipLaunchKernelGGL((gff_or_block_kernel<KK>), bgrid, dim3(GffBlockGeom<KK>::NT), GffBlockGeom<KK>::lds_bytes, st, act->Mt, act->Mx, mu2, (const double *)src, dst, act->Mt / 64)

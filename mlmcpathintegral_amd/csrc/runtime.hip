@@ -108,7 +108,7 @@ void load_tuning_locked() {
 }
 }  // namespace
 
-const Tuning &tuning() {
+Tuning tuning() {
   std::lock_guard<std::mutex> lock(g_tuning_mutex);
   load_tuning_locked();
   return g_tuning;

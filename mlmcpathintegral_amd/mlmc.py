@@ -82,6 +82,7 @@ class PathMLMC:
         self.dts = [dt0 * (2.0 ** (0.25 * l)) for l in range(n_level)]
         self.n_level, self.rank, self.world, self.B = n_level, rank, world, B
         self.concurrent_levels, self._streams = True, {}
+        self.exchange = None  # object with allreduce_sum_host(list) -> list (comm.Comm); None: torch.distributed if initialised
         self.shares = chains.partition_instances(level_costs(self.acts, nt, n_sub), B, world)
         self.levels = {l: PathLevel(self.acts, l, nb, nt, self.dts, seed, chain0=c0, n_sub=n_sub)
                        for l, (c0, nb) in self.shares[rank].items()}
@@ -130,6 +131,9 @@ class PathMLMC:
     def table(self, device="cpu"):
         """[n_level, 5] (samples, mean, variance, tau_int, cost), identical on every rank: one all-reduce of the sums"""
         s = chains.level_sums(self.n_level, {l: lv.sums() for l, lv in self.levels.items()}, device=device)
+        if self.exchange is not None and self.world > 1:  # the library communicator (RCCL through the C ABI)
+            flat = self.exchange.allreduce_sum_host(s.reshape(-1).tolist())
+            return chains.finish_level_sums(torch.tensor(flat, dtype=torch.float64).reshape(s.shape))
         return chains.finish_level_sums(chains.allreduce_level_table(s))
 
     def estimate(self, device="cpu"):

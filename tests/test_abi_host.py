@@ -35,12 +35,45 @@ def test_comm_library_exports_every_declared_symbol():
     text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "mlmcpi_comm.h")).read(), flags=re.S)
     names = sorted(set(re.findall(r"\b(mlmcpi_comm_[a-z0-9_]+)\s*\(", text)))
     lib = comm.load()
-    assert len(names) == 10 and set(names) == set(comm.SIGNATURES)
+    assert len(names) == 11 and set(names) == set(comm.SIGNATURES)
     for n in names:
         assert hasattr(lib, n), f"libmlmcpi_rccl.so lacks {n}"
     # bad arguments are rejected before anything touches RCCL or a GPU
     h = C.c_void_p()
     assert lib.mlmcpi_comm_init(3, 2, b"x" * 128, 0, C.byref(h)) == -1 and b"rank 3 of 2" in lib.mlmcpi_comm_last_error()
+
+
+def test_rendezvous_file_of_a_dead_run_is_rejected(tmp_path):
+    """a rendezvous file left behind by a run that died must not be accepted by the next run's ranks > 0
+    (they would sit in ncclCommInitRank with a mismatched id for ever).  mlmcpi_comm_init_file accepts a record only
+    while the process that wrote it is alive; an r02-format file (the bare 128-byte id) is not a record at all.  Both
+    are decided before RCCL or a GPU is touched."""
+    import struct
+    import subprocess
+    import sys
+    from mlmcpathintegral_amd import comm
+    lib = comm.load()
+    h = C.c_void_p()
+    # (a) a record whose writer is gone: a pid that has just exited, with a made-up start time
+    dead = subprocess.Popen([sys.executable, "-c", "pass"])
+    dead.wait()
+    stale = tmp_path / "stale_id"
+    stale.write_bytes(b"MLMCPI1\0" + struct.pack("<qQ", dead.pid, 12345) + b"\x01" * 128)
+    rc = lib.mlmcpi_comm_init_file(1, 2, str(stale).encode(), 0, 0.3, C.byref(h))
+    assert rc == -1 and b"stale: its writer is gone" in lib.mlmcpi_comm_last_error(), lib.mlmcpi_comm_last_error()
+    # (b) same pid as a LIVE process but another start time (pid reuse): still stale
+    reused = tmp_path / "reused_id"
+    reused.write_bytes(b"MLMCPI1\0" + struct.pack("<qQ", os.getpid(), 1) + b"\x01" * 128)
+    rc = lib.mlmcpi_comm_init_file(1, 2, str(reused).encode(), 0, 0.3, C.byref(h))
+    assert rc == -1 and b"stale" in lib.mlmcpi_comm_last_error()
+    # (c) the old format
+    old = tmp_path / "old_id"
+    old.write_bytes(b"\x02" * 128)
+    rc = lib.mlmcpi_comm_init_file(1, 2, str(old).encode(), 0, 0.3, C.byref(h))
+    assert rc == -1 and b"not a rendezvous record" in lib.mlmcpi_comm_last_error()
+    # (d) nothing there
+    rc = lib.mlmcpi_comm_init_file(1, 2, str(tmp_path / "none").encode(), 0, 0.2, C.byref(h))
+    assert rc == -1 and b"no file" in lib.mlmcpi_comm_last_error()
 
 
 def test_no_silent_cpu_fallback():

@@ -509,6 +509,26 @@ def test_lattice_sweeps_match_oracle(gpu_ops, orc, kind, Mt, Mx, kw, B, fuse):
             assert_close(got, xo, tol=1e-11, what=f"sweeps ({n_or},{n_hb}) fuse={fuse}")
 
 
+@pytest.mark.parametrize("tile", ["64x64x256", "128x32x256", "128x64x256"])
+def test_heatbath_retry_pool_with_several_passes_per_phase(gpu_ops, tile):
+    """tiles with more than 5 x 256 cells per colour phase make heatbath_cells take several passes, i.e.
+    several uses of the LDS retry pool per phase (counters and entry arrays are reused): the result must be the one
+    of the default geometry (one pass per phase), bit for bit, at the small kappa (many retries) of beta = 0.3 too."""
+    from mlmcpathintegral_amd import abi
+    for beta, Mt in ((1.0, 256), (0.3, 128)):
+        act = abi.lattice_action(4, Mt, Mt, beta=beta)
+        x = gpu_ops.lattice_initialise(act, 3, SEED, chain0=0)
+        want, scratch = x.clone(), torch.empty_like(x)
+        gpu_ops.lattice_sweep_draw(act, want, scratch, 1, 3, SEED, 0, 7, fuse=1)
+        abi.set_option("MLMCPI_SWEEP_TILE", tile)
+        try:
+            got = x.clone()
+            gpu_ops.lattice_sweep_draw(act, got, scratch, 1, 3, SEED, 0, 7, fuse=1)
+        finally:
+            abi.set_option("MLMCPI_SWEEP_TILE", "")
+        assert torch.equal(want, got), f"tile {tile}, beta {beta}: heat-bath result depends on the tile geometry"
+
+
 @pytest.mark.parametrize("rt,rx", [(2, 2), (2, 1), (1, 2)])
 def test_level_transfers_match_oracle(gpu_ops, orc, golden, rt, rx):
     """Action::copy_from_fine / copy_from_coarse (Schwinger, GFF, 1-D paths) against the oracle, plus the

@@ -100,6 +100,46 @@ def test_comm_single_rank_on_gpu():
     c.close()
 
 
+@pytest.mark.gpu
+def test_driver_two_ranks_over_rccl_when_two_gpus_are_visible():
+    """ADVICE r02: the N > 1 RCCL path of the C++ host (RcclExchange over the rendezvous file, RcclExchange::verify)
+    must RUN wherever two GPUs are visible: two driver processes, one per GPU, throughput mode; the line rank 0 prints
+    names the rank count the communicator reports.  (One-GPU boxes: nothing to run -- RCCL allows one rank per GPU.)"""
+    import json
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU visible: RCCL allows one rank per GPU")
+    if not os.path.exists(EXE):
+        build()
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [os.path.join(ROOT, "host", "driver"), "--method", "throughput", "--action", "schwinger", "--Mt_lat", "256",
+           "--sampler", "heatbath", "--batch", "4", "--n_samples", "10", "--n_burnin", "10"]
+    procs = [subprocess.Popen(cmd, env=dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_PORT=str(port),
+                                            HSA_ENABLE_IPC_MODE_LEGACY="0"),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert [p.returncode for p in procs] == [0, 0], outs
+    line = json.loads([l for l in outs[0][0].splitlines() if l.startswith("{")][-1])
+    assert line["ranks"] == 2 and 0.40 < line["qoi_mean"] < 0.49
+
+
+def test_rccl_exchange_failure_is_fatal_for_the_driver(tmp_path):
+    """A rank that cannot join (here: the only file at the rendezvous path was left by a dead run, and no rank 0 comes)
+    ends with "ERROR: ..." and EXIT_FAILURE -- the reference's convention (mpi/mpi_wrapper.cc:174-177) -- instead of
+    waiting in ncclCommInitRank.  CPU only: the failure comes before anything touches RCCL or a GPU."""
+    import struct
+    if not os.path.exists(os.path.join(ROOT, "host", "stats_check")):
+        build()
+    stale = tmp_path / "id"
+    stale.write_bytes(b"MLMCPI1\0" + struct.pack("<qQ", 1 << 22, 1) + b"\x00" * 128)
+    r = subprocess.run([os.path.join(ROOT, "host", "stats_check"), "--rccl-join", str(stale), "1", "2", "0.5"],
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "ERROR: mlmcpi_comm_init_file" in r.stderr and "stale" in r.stderr, r.stderr
+
+
 def test_driver_rejects_unknown_options():
     r = subprocess.run([os.path.join(ROOT, "host", "driver"), "--no_such_option", "1"], capture_output=True, text=True, timeout=60)
     assert r.returncode == 1 and "unknown option" in r.stderr
