@@ -342,6 +342,14 @@ int mlmcpi_test_expcos(uint64_t seed, uint32_t chain, uint32_t step, double beta
                        const double *d_xm, uint32_t n, double *d_out, void *stream);
 int mlmcpi_test_expsin2(uint64_t seed, uint32_t chain, uint32_t step, const double *d_sigma, uint32_t n,
                         double *d_out, void *stream);
+/* d_out[k] = a heat-bath draw for site k of the stream between x_p = d_xp[k] and x_m = d_xm[k], conditional
+ * exp(scale / 2 [cos(x - x_p) + cos(x - x_m)]), from the tabulated step-envelope sampler the sweeps use for actions with
+ * scale = 2 beta (Schwinger) or 2 m0 / a (rotor) <= 4 */
+int mlmcpi_test_vs_draw(uint64_t seed, uint32_t chain, uint32_t step, double scale, const double *d_xp, const double *d_xm,
+                        uint32_t n, double *d_out, void *stream);
+/* that sampler's table for an action of the given scale (host only, no GPU needed): sel[8][64] = bin of a selector
+ * value per concentration class, lw[8][8] = log2 of the acceptance factor of a bin */
+int mlmcpi_vs_table(double scale, uint8_t *sel, float *lw);
 
 #ifdef __cplusplus
 }

@@ -518,6 +518,236 @@ __device__ __forceinline__ void heatbath_cells(uint32_t total, const RngKey &key
   }
 }
 
+// ---- heat-bath angle draws, tabulated step envelope (launches whose concentrations stay below kVsKappaMax) ----------
+// The wrapped-Cauchy sampler above pays, per draw, an envelope square root, a division and an fp64 cosine per attempt
+// and an arccosine for the accepted one: ~300 fp64-class instructions of a ~520-instruction cell (388 lane
+// instructions per link update, the heat bath = half the step).  For moderate concentrations -- the Schwinger model at
+// beta <= 2, the rotor at 2 m0 / a <= 4: every BASELINE configuration -- the same von Mises law p(x) ~ exp(kappa cos x)
+// is drawn here from a piecewise-constant envelope taken from a small table, so that an attempt costs no fp64
+// arithmetic at all and the accepted angle is a linear function of random bits:
+//     bins of |x|     edges (0, 1, 2, 3, 4, 6, 8, 12, 16) pi/16: eight bins, finer where the density is high;
+//     bin k is proposed with probability q_k / 64 (six random bits through a 64-entry selector), |x| uniform inside it
+//                     (46 random bits), sign from one more bit;
+//     accepted with probability  exp(kappa (cos x - 1)) 2^lw[k],   2^lw[k] = (w_k / q_k) / max_j (H_j w_j / q_j),
+// i.e. target / (proposal density x envelope constant), H_j = the target at the left edge of bin j (its maximum there).
+// The q_k follow the shape of the target, which depends on kappa; so there are kVsClasses tables, for eight ranges of
+// kappa, and a cell picks its table by an exact fp64 comparison: with t = |(x_m - x_p)/(4 pi)| reduced to [0, 1/2],
+// kappa = scale |cos(2 pi t)| = scale sin(2 pi v), v = |t - 1/4| in [0, 1/4], class = floor(32 v): the table of class c
+// is built for kappa_min = scale sin(2 pi c / 32) and is a valid envelope for every larger kappa (the normalised target
+// only gets narrower).  Acceptance 0.70 ... 0.89 (0.79 on average; wrapped Cauchy: 0.82).  The tables are built by the
+// host for the action's scale (runtime.hip, vs_build_tables; exported as mlmcpi_vs_table so that the oracle's own
+// construction can be compared with it) and copied to LDS by the kernels: 512 selector bytes + 64 floats.
+// The test is screened in fp32 (24 bits of |x|, one polynomial cosine, v_exp_f32) against the 11 leading bits of u2 with a
+// guard band that covers every fp32 rounding on the way; when the band does not decide (one attempt in ~10^3), the exact
+// fp64 test with the full u2 takes over, as for the wrapped-Cauchy sampler, so the decision is always the one of the
+// exact test -- which is what the oracle computes (oracle.cc, dev_vonmises_table).  Random numbers: the same Philox
+// calls and bit fields as above (word pair = one attempt; bit 0 sign, bits 1..11 leading bits of u2, bits 12..63: six
+// selector bits on top of 46 position bits).
+constexpr double kVsKappaMax = 4.0;  // host rule (lattice2d.hip / path1d.hip; the oracle applies the same): kappa_max <= 4
+constexpr int kVsClasses = 8, kVsBins = 8, kVsSel = 64;
+constexpr uint32_t kVsTableBytes = kVsClasses * kVsSel + kVsClasses * kVsBins * 4;  // selector bytes | lw floats
+
+struct VsTable {  // in LDS
+  const uint8_t *sel;  // [class][64]: bin of a selector value
+  const float *lw;     // [class][8]: log2 of the acceptance factor of a bin
+  // threads 0 .. 191 copy the action's table from global memory (visible after the caller's next barrier)
+  __device__ static VsTable stage(void *lds, const uint32_t *__restrict__ d_table) {
+    if (d_table && threadIdx.x < kVsTableBytes / 4) ((uint32_t *)lds)[threadIdx.x] = d_table[threadIdx.x];
+    return VsTable{(const uint8_t *)lds, (const float *)((const uint8_t *)lds + kVsClasses * kVsSel)};
+  }
+};
+// left edge and width of bin k in units of pi/16: edges 0 1 2 3 4 6 8 12, widths 1 1 1 1 2 2 4 4
+__device__ __forceinline__ uint32_t vs_edge16(uint32_t k) { return (0xC8643210u >> (4u * k)) & 15u; }
+__device__ __forceinline__ uint32_t vs_width16(uint32_t k) { return 1u << ((k >> 1) > 1u ? (k >> 1) - 1u : 0u); }
+
+// cos(x), x in [0, pi], fp32: sin(pi/2 - x) by its Taylor polynomial to x^11 (truncation 6e-8, rounding ~1e-7)
+__device__ __forceinline__ float cosf_0_pi(float x) {
+  const float y = 1.57079633f - x, y2 = y * y;
+  float p = -2.50521084e-08f;          // -1/11!
+  p = fmaf(p, y2, 2.75573192e-06f);    //  1/9!
+  p = fmaf(p, y2, -1.98412698e-04f);   // -1/7!
+  p = fmaf(p, y2, 8.33333333e-03f);    //  1/5!
+  p = fmaf(p, y2, -1.66666667e-01f);   // -1/3!
+  return fmaf(y * y2, p, y);
+}
+
+struct VsCell {
+  double centre;   // the draw is mod_2pi(centre +- |x|)
+  float kp;        // kappa log2(e), fp32: screening only
+  uint32_t cls;    // which table
+  uint32_t site;   // Philox counter word 0
+};
+
+// Cell set-up shared by the Schwinger links (x_p, x_m = the two staple sums, scale = 2 beta) and the rotor sites
+// (x_p, x_m = the neighbours, scale = 2 m0 / a): conditional exp(scale/2 [cos(x - x_p) + cos(x - x_m)])
+// = exp(kappa cos(x - centre)), kappa = scale |cos((x_m - x_p)/2)|, centre = (x_p + x_m)/2 (+ pi where the cosine is
+// negative, i.e. for t > 1/4: an exact fp64 comparison); kappa itself is needed in fp32 only.
+__device__ __forceinline__ void vs_cell(double scale, double x_p, double x_m, VsCell &c) {
+  const double v = (x_m - x_p) * (0.25 / kPi);
+  const double t = fabs(v - rint(v));
+  c.centre = fma(0.5, x_p + x_m, t > 0.25 ? kPi : 0.0);
+  const double w = fabs(t - 0.25);                                   // [0, 1/4]; NaN for a NaN state
+  c.cls = min((uint32_t)(32.0 * w), (uint32_t)(kVsClasses - 1));    // (uint32_t)NaN = 0
+  c.kp = fmaxf((float)scale * fabsf(cosf_0_pi(6.28318531f * (float)t)), 0.0f) * 1.44269504f;   // fmaxf: NaN -> 0
+}
+__device__ __forceinline__ double vs_kappa_exact(double scale, double x_p, double x_m) {
+  return vm_clamp(scale * fabs(cos_half(x_m - x_p)));
+}
+
+// |x| of the attempt (lo, hi), fp64: (pi/16) (edge + width pos), pos = the 46 bits below the selector
+__device__ __forceinline__ double vs_theta(uint32_t lo, uint32_t hi, uint32_t bin) {
+  // mantissa = 000000 | 46 position bits: m = 1 + pos / 64
+  const double m = __hiloint2double((int)(((hi >> 12) & 0x3FFFu) | 0x3FF00000u), (int)__builtin_amdgcn_alignbit(hi, lo, 12));
+  const double w64 = (double)(64u * vs_width16(bin)), e = (double)vs_edge16(bin);
+  return (kPi / 16.0) * fma(w64, m, e - w64);   // one rounding of edge + width pos, as in the oracle
+}
+
+// screening decision of one attempt: 1 accepted, 0 rejected, -1 open; `bin` comes back for the caller
+__device__ __forceinline__ int vs_try(uint32_t lo, uint32_t hi, float kp, uint32_t cls, const VsTable &tab, uint32_t &bin) {
+  bin = tab.sel[cls * kVsSel + (hi >> 26)];
+  const float posf = (float)((hi >> 2) & 0xFFFFFFu) * (1.0f / 16777216.0f);      // the leading 24 position bits
+  const float c = cosf_0_pi(0.196349541f * fmaf((float)vs_width16(bin), posf, (float)vs_edge16(bin)));
+  const float af = __builtin_amdgcn_exp2f(fmaf(kp, c - 1.0f, tab.lw[cls * kVsBins + bin]));   // acceptance probability
+  // error budget of log2(af): |x| to 24 bits (1e-7 kappa'), the cosine (1.5e-7 kappa'), kappa' itself (2e-7 kappa' from
+  // the fp32 cosine behind it), the fma (1e-6 at |log2 af| <= 16): < 4e-7 (1 + kappa') in all, i.e. < 3e-7 (1 + kappa')
+  // relative on af, plus v_exp_f32's own ~2e-7.  The band is 30 times that.
+  const float band = af * (1e-5f * (1.0f + kp));
+  const float lo_s = (float)((lo >> 1) & 0x7FFu) * (1.0f / 2048.0f), hi_s = lo_s + (1.0f / 2048.0f);   // u2 in [lo_s, hi_s)
+  return hi_s <= af - band ? 1 : (lo_s >= af + band ? 0 : -1);
+}
+
+// the exact test: u2 = (b + tail) / 2048 against exp(kappa (cos x - 1)) 2^lw, in logarithms
+__device__ __forceinline__ int vs_exact(uint32_t lo, uint32_t hi, uint32_t bin, double tail, double kappa, float lw) {
+  const double u2 = ((double)((lo >> 1) & 0x7FFu) + tail) * (1.0 / 2048.0);
+  const double la = fma(kappa, cospi_unit(vs_theta(lo, hi, bin) * (1.0 / kPi)) - 1.0, 0.69314718055994531 * (double)lw);
+  return (u2 <= 0.0 || log_unit(u2) <= la) ? 1 : 0;
+}
+
+// attempts 2 pair and 2 pair + 1 of `site`; kappa_exact() is evaluated only when a screening decision is open.
+// Returns true when one of them is accepted (or the attempt bound is hit); |x| and its sign come back either way.
+template <class KappaExact>
+__device__ __forceinline__ bool vs_attempt_pair(const RngKey &k, uint32_t site, uint32_t pair, float kp, uint32_t cls,
+                                                const VsTable &tab, KappaExact kappa_exact, double &theta, bool &negative,
+                                                uint32_t sub0 = 0) {
+  const uint32_t w3 = (P_VONMISES << 24) | sub0 | pair;
+  const U4 q = philox4x32_10(site, k.chain, k.step, w3, k.k0, k.k1);
+  uint32_t ba, bb;
+  int sa = vs_try(q.x, q.y, kp, cls, tab, ba), sb = vs_try(q.z, q.w, kp, cls, tab, bb);
+  if (sa < 0 || (sa == 0 && sb < 0)) {
+    const U4 e = philox4x32_10(site, k.chain, k.step, w3 | kVmRefine, k.k0, k.k1);
+    const double kap = kappa_exact();
+    if (sa < 0) sa = vs_exact(q.x, q.y, ba, u01(e.x, e.y), kap, tab.lw[cls * kVsBins + ba]);
+    if (sa == 0 && sb < 0) sb = vs_exact(q.z, q.w, bb, u01(e.z, e.w), kap, tab.lw[cls * kVsBins + bb]);
+  }
+  const bool first = sa == 1;
+  const uint32_t lo = first ? q.x : q.z, hi = first ? q.y : q.w;
+  theta = vs_theta(lo, hi, first ? ba : bb);
+  negative = (lo & 1u) != 0;
+  return sa == 1 || sb == 1 || pair + 1 >= kMaxVmPairs;
+}
+
+// Retry pool of the step-envelope phases.  After the first pair of attempts ~5 % of the cells are still open.  An entry
+// is just the cell's LDS offset and the index of its next pair -- everything else (stencil, centre, kappa) is recomputed
+// from the tile image, which the phase does not change under the cell.  Rounds: every thread takes entries of the
+// current buffer, gives each ONE pair of attempts and pushes what is still open into the other buffer; one barrier
+// per round; a round of at most one wave's worth of entries (nearly always the first) is finished by wave 0 in place.
+// Three counters in rotation (read in round r, filled for round r + 1, cleared for round r + 2) make one barrier per
+// round enough.
+template <class E>  // uint16_t: offset in 12 bits, next pair in 4 (compile-time 64 x 32 tiles); uint32_t: 16 + 16
+struct VsPool {
+  static constexpr uint32_t kOffBits = sizeof(E) == 2 ? 12 : 16;
+  static constexpr uint32_t kMaxPair = (1u << (8 * sizeof(E) - kOffBits)) - 1;
+  E *buf0;               // two buffers of `cap` entries, one behind the other (no pointer array: it would live in scratch)
+  uint32_t *count;       // [3]
+  uint32_t cap, round;   // capacity per buffer (0: no pool); rounds so far (uniform over the workgroup)
+  VsTable tab;
+  // LDS bytes: table | counters | buffers
+  static __host__ __device__ constexpr size_t bytes(uint32_t cap) { return kVsTableBytes + 16 + ((size_t)2 * cap * sizeof(E) + 7) / 8 * 8; }
+  __device__ E *buf(uint32_t round_) const { return buf0 + ((round_ & 1u) ? cap : 0u); }
+  __device__ static VsPool carve(double *lds, uint32_t cap, const uint32_t *d_table) {  // call from every thread
+    VsPool p;
+    p.tab = VsTable::stage(lds, d_table);
+    p.count = (uint32_t *)((uint8_t *)lds + kVsTableBytes);
+    p.buf0 = (E *)(p.count + 4);
+    p.cap = cap;
+    p.round = 0;
+    if (cap && threadIdx.x < 3) p.count[threadIdx.x] = 0;
+    return p;
+  }
+};
+
+// One colour phase.  off_of(idx) = LDS offset of cell idx of the phase; setup(off, cell) = centre, class, kappa', Philox
+// site from the tile image; kappa_exact(off) = the fp64 concentration (rare); commit(off, angle).
+// Round 0 walks the cells of the phase (thread t: cells t, t + NT, ...), later rounds the pool; both go through ONE copy
+// of the attempt code (the rare exact test would otherwise be inlined four times over and spill).
+template <int NT, int S, class E, class OffOf, class Setup, class KappaExact, class Commit>
+__device__ __forceinline__ void heatbath_cells_step(uint32_t total, const RngKey &key, VsPool<E> &pool, OffOf off_of, Setup setup,
+                                                    KappaExact kappa_exact, Commit commit) {
+  using P = VsPool<E>;
+  constexpr uint32_t kOffMask = (1u << P::kOffBits) - 1;
+  uint32_t r = pool.round, n = total;
+  bool first = true, tail = false;
+  for (;;) {
+    // counter of round r + 2: read in round r - 1, pushed to in round r + 1
+    if (pool.cap && threadIdx.x == 0) pool.count[(r + 2) % 3] = 0;
+    for (uint32_t i = threadIdx.x; i < n; i += NT) {
+      uint32_t off, pair = 0;
+      if (first) {
+        off = off_of(i);
+      } else {
+        const uint32_t e = pool.buf(r)[i];
+        off = e & kOffMask;
+        pair = e >> P::kOffBits;
+      }
+      VsCell c;
+      setup(off, c);
+      double th = 0.0;
+      bool neg = false, in_place = tail;
+      for (;;) {  // one pair of attempts; more of them only for a cell that cannot go (back) to the pool
+        const bool done = vs_attempt_pair(key, c.site, pair, c.kp, c.cls, pool.tab, [&] { return kappa_exact(off); }, th, neg);
+        if (done) {
+          commit(off, mod_2pi_fast(c.centre + (neg ? -th : th)));
+          break;
+        }
+        ++pair;
+        if (!in_place) {
+          in_place = true;
+          if (pool.cap && pair <= P::kMaxPair) {
+            const uint32_t slot = atomicAdd(pool.count + (r + 1) % 3, 1u);
+            if (slot < pool.cap) {
+              pool.buf(r + 1)[slot] = (E)(off | (pair << P::kOffBits));
+              break;
+            }
+          }
+        }
+      }
+    }
+    if (!pool.cap || tail) break;
+    __syncthreads();
+    ++r;
+    first = false;
+    n = min(pool.count[r % 3], pool.cap);
+    if (n <= kWave) {  // the tail: wave 0 finishes it in place, one entry per lane; nothing is pushed any more
+      tail = true;
+      if (threadIdx.x == 0) pool.count[r % 3] = 0;  // (a wave that reads the counter after this sees 0 entries and leaves as well)
+      if (n == 0 || threadIdx.x >= kWave) break;
+    }
+  }
+  pool.round = r;
+}
+
+// one draw x ~ exp(kappa cos(x - centre)) for the conditional between x_p and x_m (test hook; the sweeps go through
+// heatbath_cells_step): returns mod_2pi(centre + x)
+__device__ __forceinline__ double vs_draw(const RngKey &k, uint32_t site, double scale, double x_p, double x_m, const VsTable &tab) {
+  VsCell c;
+  vs_cell(scale, x_p, x_m, c);
+  double th = 0.0;
+  bool neg = false;
+  for (uint32_t pair = 0; !vs_attempt_pair(k, site, pair, c.kp, c.cls, tab, [&] { return vs_kappa_exact(scale, x_p, x_m); }, th, neg); ++pair) {
+  }
+  return mod_2pi_fast(c.centre + (neg ? -th : th));
+}
+
 // -log of ExpCosDistribution::evaluate(x, x_p, x_m) (distribution/expcosdistribution.cc:7-21)
 __device__ __forceinline__ double expcos_neg_log_pdf(double beta, double x, double x_p, double x_m) {
   double dx = x_p - x_m, z = x - x_m;

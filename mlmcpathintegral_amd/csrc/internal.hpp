@@ -51,6 +51,10 @@ struct Tuning {
 };
 Tuning tuning();  // a copy taken under the lock: callers snapshot it once per call
 
+// Table of the step-envelope heat-bath sampler for an action of the given scale (2 beta, 2 m0 / a), in the memory of the
+// current device: built and uploaded on first use (device_common.hpp, runtime.hip).
+int vs_table_device(double scale, const uint32_t **d_table);
+
 constexpr uint32_t kMaxFuse = 16;  // max sweeps fused in one launch (kinds travel in a bitmask)
 
 }  // namespace mlmcpi

@@ -10,6 +10,7 @@
 // one write of every entry -- instead of the 4-5 passes of one-kernel-per-colour -- and k fused
 // sweeps divide that by k.
 #include <algorithm>
+#include <type_traits>
 #include <mutex>
 
 #include <hipfft/hipfft.h>
@@ -107,6 +108,39 @@ __device__ __forceinline__ void heatbath_region(uint32_t nr, uint32_t nc, const 
                         commit);
 }
 
+// the same for the step-envelope sampler (device_common.hpp): cells are addressed by their LDS offset
+// r0 * bw + c0 + (row step) * bw * ri + (column step) * ci
+template <int NT, int S, bool DIRECT, class E, class Setup, class KappaExact, class Commit>
+__device__ __forceinline__ void heatbath_region_step(uint32_t nr, uint32_t nc, uint32_t origin, uint32_t row_stride,
+                                                     uint32_t col_stride, const RngKey &key, VsPool<E> &pool, Setup setup,
+                                                     KappaExact kappa_exact, Commit commit) {
+  if (DIRECT) {  // nc is a compile-time constant at the call site
+    heatbath_cells_step<NT, S, E>(nr * nc, key, pool,
+                                  [&](uint32_t idx) {
+                                    const uint32_t ri = idx / nc;
+                                    return origin + ri * row_stride + (idx - ri * nc) * col_stride;
+                                  },
+                                  setup, kappa_exact, commit);
+    return;
+  }
+  uint32_t cur = threadIdx.x, ri = cur / nc, ci = cur - ri * nc;
+  const uint32_t dr = NT / nc, dc = NT - dr * nc;
+  heatbath_cells_step<NT, S, E>(nr * nc, key, pool,
+                                [&](uint32_t idx) {  // a thread's cells come in increasing order, NT apart
+                                  while (cur < idx) {
+                                    cur += NT;
+                                    ri += dr;
+                                    ci += dc;
+                                    if (ci >= nc) {
+                                      ci -= nc;
+                                      ++ri;
+                                    }
+                                  }
+                                  return origin + ri * row_stride + ci * col_stride;
+                                },
+                                setup, kappa_exact, commit);
+}
+
 struct TileGeom {
   uint32_t TW, TH;      // owned tile extent (even)
   uint32_t tiles_x;     // tiles per row of tiles
@@ -128,11 +162,13 @@ __device__ __forceinline__ uint32_t wrap_add(uint32_t base, uint32_t off, uint32
 // (Mt >= TWC + 4, Mx >= THC + 4): tile and buffer extents are compile-time constants (index arithmetic folds, cell
 // coordinates come from divisions by constants) and a buffer coordinate wraps around the lattice at most once.  Same
 // updates in the same order as the generic instantiation (TWC = THC = 0): bit-identical results.
-template <bool HEAT, int NT, int TWC = 0, int THC = 0>
+// STEP: the heat-bath phases draw from the step envelope (2 beta <= kVsKappaMax; device_common.hpp) instead of the
+// wrapped-Cauchy one; pool_cap then counts entries of VsPool.
+template <bool HEAT, int NT, int TWC = 0, int THC = 0, bool STEP = false>
 __global__ void __launch_bounds__(NT, HEAT ? (NT == 256 ? 4 : NT == 512 ? 2 : 1) : 1)
     schwinger_sweep_kernel(uint32_t Mt, uint32_t Mx, double beta, const double2 *__restrict__ in,
                            double2 *__restrict__ out, TileGeom tg, uint32_t nsweeps_arg, uint32_t kinds, RngKey key0,
-                           uint32_t pool_cap, int qoi_op, double *__restrict__ qoi_partial) {
+                           uint32_t pool_cap, int qoi_op, double *__restrict__ qoi_partial, const uint32_t *__restrict__ vs_table) {
   extern __shared__ double lds[];
   __shared__ double qoi_red[NT / kWave];
   constexpr bool FIXED = TWC > 0;
@@ -153,7 +189,11 @@ __global__ void __launch_bounds__(NT, HEAT ? (NT == 256 ? 4 : NT == 512 ? 2 : 1)
   };
   double *th0 = lds, *th1 = lds + (size_t)bw * bh;
   // retry pool of the heat-bath phases, behind the tile image (the host sizes the allocation for tg.TW x tg.TH tiles)
-  HbPool pool = HbPool::carve(lds + (size_t)2 * ((FIXED ? TWC : tg.TW) + 2 * H) * ((FIXED ? THC : tg.TH) + 2 * H), HEAT ? pool_cap : 0u);
+  double *pool_lds = lds + (size_t)2 * ((FIXED ? TWC : tg.TW) + 2 * H) * ((FIXED ? THC : tg.TH) + 2 * H);
+  HbPool pool = HbPool::carve(pool_lds, HEAT && !STEP ? pool_cap : 0u);
+  using PoolEntry = typename std::conditional<FIXED, uint16_t, uint32_t>::type;   // 68 x 36 cells: 12 bits of offset
+  VsPool<PoolEntry> vpool = VsPool<PoolEntry>::carve(pool_lds, HEAT && STEP ? pool_cap : 0u, STEP ? vs_table : nullptr);
+  const double beta2 = 2. * beta;
   const uint32_t sc = (uint32_t)(((uint64_t)i0 + Mt - (H % Mt)) % Mt);  // lattice column of buffer column 0
   const uint32_t sr = (uint32_t)(((uint64_t)j0 + Mx - (H % Mx)) % Mx);
   const double2 *src = in + (size_t)b * Mt * Mx;
@@ -189,7 +229,19 @@ __global__ void __launch_bounds__(NT, HEAT ? (NT == 256 ? 4 : NT == 512 ? 2 : 1)
       const uint32_t r_first = last ? H + par : (par ? 1 : 2);
       const uint32_t nr = r_first <= r_hi0 ? (r_hi0 - r_first) / 2 + 1 : 0;
       const uint32_t ncol = c_hi0 - c_lo0 + 1;
-      if (heat) {
+      if (heat && STEP) {
+        heatbath_region_step<NT, 5, FIXED, PoolEntry>(
+            nr, ncol, r_first * bw + c_lo0, 2 * bw, 1, skey, vpool,
+            [&](uint32_t o, VsCell &cell) {
+              const uint32_t r = o / bw, c = o - r * bw;
+              vs_cell(beta2, th0[o + bw] + th1[o] - th1[o + 1], th0[o - bw] + th1[o - bw + 1] - th1[o - bw], cell);
+              cell.site = 2 * (wrap(sr, r, Mx) * Mt + wrap(sc, c, Mt));
+            },
+            [&](uint32_t o) {
+              return vs_kappa_exact(beta2, th0[o + bw] + th1[o] - th1[o + 1], th0[o - bw] + th1[o - bw + 1] - th1[o - bw]);
+            },
+            [&](uint32_t o, double v) { th0[o] = v; });
+      } else if (heat) {
         heatbath_region<NT, 5, FIXED>(
             nr, ncol, skey, pool,
             [&](uint32_t ri, uint32_t ci, double &tau, double &centre, uint32_t &site, uint32_t &o) {
@@ -218,7 +270,19 @@ __global__ void __launch_bounds__(NT, HEAT ? (NT == 256 ? 4 : NT == 512 ? 2 : 1)
       const uint32_t c_hi1 = last ? (par ? H + ow - 1 : H + ow) : bw - 2;
       const uint32_t nc = c_first <= c_hi1 ? (c_hi1 - c_first) / 2 + 1 : 0;
       const uint32_t nrow = r_hi1 - r_lo1 + 1;
-      if (heat) {
+      if (heat && STEP) {
+        heatbath_region_step<NT, 5, FIXED, PoolEntry>(
+            nrow, nc, r_lo1 * bw + c_first, bw, 2, skey, vpool,
+            [&](uint32_t o, VsCell &cell) {
+              const uint32_t r = o / bw, c = o - r * bw;
+              vs_cell(beta2, th0[o] + th1[o + 1] - th0[o + bw], th0[o + bw - 1] + th1[o - 1] - th0[o - 1], cell);
+              cell.site = 2 * (wrap(sr, r, Mx) * Mt + wrap(sc, c, Mt)) + 1;
+            },
+            [&](uint32_t o) {
+              return vs_kappa_exact(beta2, th0[o] + th1[o + 1] - th0[o + bw], th0[o + bw - 1] + th1[o - 1] - th0[o - 1]);
+            },
+            [&](uint32_t o, double v) { th1[o] = v; });
+      } else if (heat) {
         heatbath_region<NT, 5, FIXED>(
             nrow, nc, skey, pool,
             [&](uint32_t ri, uint32_t ci, double &tau, double &centre, uint32_t &site, uint32_t &o) {
@@ -1403,30 +1467,42 @@ static SweepGeom choose_geometry(const Tuning &tune, uint32_t Mt, uint32_t Mx, u
 }
 
 template <bool SCHW, bool HEAT, int NT>
-static void launch_sweep_nt(const SweepGeom &g, dim3 grid, hipStream_t st, uint32_t Mt, uint32_t Mx, double coupling,
+static int launch_sweep_nt(const SweepGeom &g, dim3 grid, hipStream_t st, uint32_t Mt, uint32_t Mx, double coupling,
                             const double *src, double *dst, uint32_t n, uint32_t kinds, RngKey key, int qoi_op = 0,
                             double *qoi_partial = nullptr) {
   if (SCHW) {
     // heat-bath launches: room for the retry pool behind the tile image, as many entries as still keep the workgroup's
     // LDS footprint within a quarter of the CU's 160 KiB (4 workgroups per CU), at least one wave's worth
+    const bool fixed = HEAT && NT == 256 && n == 1 && !g.overridden && g.tg.TW == 64 && g.tg.TH == 32 && Mt % 64 == 0 &&
+                       Mx % 32 == 0 && Mt >= 128 && Mx >= 64;  // compile-time tile geometry (bit-identical results)
+    const bool step = HEAT && 2. * coupling <= kVsKappaMax;      // which sampler: a property of the action, not a knob
     uint32_t cap = 0;
     size_t lds = g.lds_bytes;
+    const uint32_t *vs_table = nullptr;
+    if (step)
+      if (int rc = vs_table_device(2. * coupling, &vs_table)) return rc;
     if (HEAT) {
       const size_t quarter = 40 * 1024 - 64;  // (the kernel's static LDS: the QoI reduction scratch)
+      const size_t entry = step ? 2 * (fixed ? sizeof(uint16_t) : sizeof(uint32_t)) : 24, fixed_part = step ? kVsTableBytes + 16 : 8;
       cap = 64;
-      if (lds + HbPool::bytes(cap) <= quarter) cap = (uint32_t)((quarter - lds - 8) / 24);
-      if (cap > 1024) cap = 1024;
-      lds += HbPool::bytes(cap);
-      if (lds > 160 * 1024 - 256) { cap = 0; lds = g.lds_bytes; }
+      if (lds + fixed_part + entry * cap <= quarter) cap = (uint32_t)((quarter - lds - fixed_part) / entry) & ~7u;
+      if (cap > (step ? 256u : 1024u)) cap = step ? 256u : 1024u;
+      const size_t pool_bytes = step ? (fixed ? VsPool<uint16_t>::bytes(cap) : VsPool<uint32_t>::bytes(cap)) : HbPool::bytes(cap);
+      lds += pool_bytes;
+      if (lds > 160 * 1024 - 256) { cap = 0; lds = g.lds_bytes + (step ? VsPool<uint32_t>::bytes(0) : 0); }
     }
-    // single heat-bath sweep on a lattice the default tiles divide: compile-time geometry (bit-identical results)
-    if (HEAT && NT == 256 && n == 1 && !g.overridden && g.tg.TW == 64 && g.tg.TH == 32 && Mt % 64 == 0 && Mx % 32 == 0 &&
-        Mt >= 128 && Mx >= 64)
+    if (fixed && step)
+      hipLaunchKernelGGL((schwinger_sweep_kernel<HEAT, NT, 64, 32, HEAT>), grid, dim3(NT), lds, st, Mt, Mx, coupling,
+                         (const double2 *)src, (double2 *)dst, g.tg, n, kinds, key, cap, qoi_op, qoi_partial, vs_table);
+    else if (fixed)
       hipLaunchKernelGGL((schwinger_sweep_kernel<HEAT, NT, 64, 32>), grid, dim3(NT), lds, st, Mt, Mx, coupling,
-                         (const double2 *)src, (double2 *)dst, g.tg, n, kinds, key, cap, qoi_op, qoi_partial);
+                         (const double2 *)src, (double2 *)dst, g.tg, n, kinds, key, cap, qoi_op, qoi_partial, vs_table);
+    else if (step)
+      hipLaunchKernelGGL((schwinger_sweep_kernel<HEAT, NT, 0, 0, HEAT>), grid, dim3(NT), lds, st, Mt, Mx, coupling,
+                         (const double2 *)src, (double2 *)dst, g.tg, n, kinds, key, cap, qoi_op, qoi_partial, vs_table);
     else
       hipLaunchKernelGGL((schwinger_sweep_kernel<HEAT, NT>), grid, dim3(NT), lds, st, Mt, Mx, coupling,
-                         (const double2 *)src, (double2 *)dst, g.tg, n, kinds, key, cap, qoi_op, qoi_partial);
+                         (const double2 *)src, (double2 *)dst, g.tg, n, kinds, key, cap, qoi_op, qoi_partial, vs_table);
   }
   else
   if (HEAT && NT == 256 && n == 1 && (kinds & 1u) && !g.overridden && g.tg.TW == 64 && g.tg.TH == 32 && Mt % 64 == 0 &&
@@ -1436,17 +1512,20 @@ static void launch_sweep_nt(const SweepGeom &g, dim3 grid, hipStream_t st, uint3
   else
     hipLaunchKernelGGL((gff_sweep_kernel<HEAT, NT>), grid, dim3(NT), g.lds_bytes, st, Mt, Mx, coupling, src, dst, g.tg, n,
                        kinds, key, qoi_op, qoi_partial);
+  return MLMCPI_OK;
 }
 
 template <bool SCHW, bool HEAT>
 static int launch_sweep(const SweepGeom &g, dim3 grid, hipStream_t st, uint32_t Mt, uint32_t Mx, double coupling,
                         const double *src, double *dst, uint32_t n, uint32_t kinds, RngKey key, int qoi_op = 0,
                         double *qoi_partial = nullptr) {
+  int rc;
   switch (g.NT) {
-    case 1024: launch_sweep_nt<SCHW, HEAT, 1024>(g, grid, st, Mt, Mx, coupling, src, dst, n, kinds, key, qoi_op, qoi_partial); break;
-    case 512: launch_sweep_nt<SCHW, HEAT, 512>(g, grid, st, Mt, Mx, coupling, src, dst, n, kinds, key, qoi_op, qoi_partial); break;
-    default: launch_sweep_nt<SCHW, HEAT, 256>(g, grid, st, Mt, Mx, coupling, src, dst, n, kinds, key, qoi_op, qoi_partial);
+    case 1024: rc = launch_sweep_nt<SCHW, HEAT, 1024>(g, grid, st, Mt, Mx, coupling, src, dst, n, kinds, key, qoi_op, qoi_partial); break;
+    case 512: rc = launch_sweep_nt<SCHW, HEAT, 512>(g, grid, st, Mt, Mx, coupling, src, dst, n, kinds, key, qoi_op, qoi_partial); break;
+    default: rc = launch_sweep_nt<SCHW, HEAT, 256>(g, grid, st, Mt, Mx, coupling, src, dst, n, kinds, key, qoi_op, qoi_partial);
   }
+  if (rc) return rc;
   MLMCPI_LAUNCH_CHECK("lattice sweep kernel");
   return MLMCPI_OK;
 }
@@ -1456,6 +1535,8 @@ static int allow_full_lds() {
   // tiles with deep halos may use the whole 160 KiB of LDS
   // (the kernels also hold NT / 64 doubles of static LDS for the fused QoI reduction)
   MLMCPI_HIP_TRY(hipFuncSetAttribute((const void *)schwinger_sweep_kernel<HEAT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+  if (HEAT)
+    MLMCPI_HIP_TRY(hipFuncSetAttribute((const void *)schwinger_sweep_kernel<HEAT, NT, 0, 0, HEAT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
   MLMCPI_HIP_TRY(hipFuncSetAttribute((const void *)gff_sweep_kernel<HEAT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
   return MLMCPI_OK;
 }

@@ -481,13 +481,16 @@ __global__ void __launch_bounds__(256) path_transfer_kernel(uint32_t Mc, double 
 // by at most two sites per sweep and never reach the owned range.  in != out (halo reads race with
 // the neighbours' writes otherwise).  kinds bit s = 1 -> sweep s is a heat-bath sweep.
 // rotoraction.cc:20-56, rotoraction.hh:195-213.
-template <bool HEAT>  // HEAT = false: overrelaxation-only instantiation (no sampler code, few registers)
+// HEAT = false: overrelaxation-only instantiation (no sampler code, few registers).  STEP: heat-bath draws from the step
+// envelope (2 m0 / a <= kVsKappaMax, device_common.hpp) instead of the wrapped-Cauchy one; pool_cap then counts VsPool entries.
+template <bool HEAT, bool STEP = false>
 __global__ void __launch_bounds__(256)
     rotor_sweep_kernel(PathP P, const double *__restrict__ in, double *__restrict__ out, uint32_t owned_len,
-                       uint32_t nsweeps, uint32_t kinds, RngKey key0, uint32_t pool_cap) {
+                       uint32_t nsweeps, uint32_t kinds, RngKey key0, uint32_t pool_cap, const uint32_t *__restrict__ vs_table) {
   extern __shared__ double buf[];
   const uint32_t b = blockIdx.y, seg = blockIdx.x, M = P.M, halo = 2 * nsweeps;
-  HbPool pool = HbPool::carve(buf + owned_len + 2 * halo, HEAT ? pool_cap : 0u);  // behind the segment image
+  HbPool pool = HbPool::carve(buf + owned_len + 2 * halo, HEAT && !STEP ? pool_cap : 0u);  // behind the segment image
+  VsPool<uint32_t> vpool = VsPool<uint32_t>::carve(buf + owned_len + 2 * halo, HEAT && STEP ? pool_cap : 0u, STEP ? vs_table : nullptr);
   const uint32_t o0 = seg * owned_len, olen = min(owned_len, M - o0);
   const uint32_t L = olen + 2 * halo;
   const uint32_t g0 = (uint32_t)(((uint64_t)o0 + M - (halo % M)) % M);
@@ -518,6 +521,20 @@ __global__ void __launch_bounds__(256)
           const uint32_t k = k0 + 2 * idx;
           buf[k] = mod_2pi_fast(buf[k - 1] + buf[k + 1] - buf[k]);
         }
+      } else if (HEAT && STEP) {
+        auto global_site = [&](uint32_t k) {
+          uint32_t g = g0 + k;
+          while (g >= M) g -= M;
+          return g;
+        };
+        heatbath_cells_step<256, 4, uint32_t>(
+            count, skey, vpool, [&](uint32_t idx) { return k0 + 2 * idx; },
+            [&](uint32_t k, VsCell &cell) {
+              vs_cell(sig_scale, buf[k + 1], buf[k - 1], cell);
+              cell.site = global_site(k);
+            },
+            [&](uint32_t k) { return vs_kappa_exact(sig_scale, buf[k + 1], buf[k - 1]); },
+            [&](uint32_t k, double angle) { buf[k] = angle; });
       } else if (HEAT) {
         heatbath_cells<256, 4>(
             count, skey, pool,
@@ -901,13 +918,21 @@ static int path_sweep_impl(const mlmcpi_path_action *act, double *d_x, double *d
     owned += owned & 1;  // keep segment starts even
     const uint32_t nseg2 = (P.M + owned - 1) / owned;
     const size_t lds = (size_t)(owned + 2 * halo) * sizeof(double);
-    const uint32_t pool_cap = 256;  // retry pool of the heat-bath phases (device_common.hpp, heatbath_cells)
-    if (kinds)
+    // retry pool of the heat-bath phases (device_common.hpp); which sampler: a property of the action (2 m0 / a), not a knob
+    const bool step = 2.0 * P.m0 / P.a <= kVsKappaMax;
+    const uint32_t pool_cap = 256;
+    const uint32_t *vs_table = nullptr;
+    if (kinds && step)
+      if (int rc = vs_table_device(2.0 * P.m0 / P.a, &vs_table)) return rc;
+    if (kinds && step)
+      hipLaunchKernelGGL((rotor_sweep_kernel<true, true>), dim3(nseg2, B), dim3(256), lds + VsPool<uint32_t>::bytes(pool_cap), st, P,
+                         (const double *)src, dst, owned, n, kinds, make_key(seed, chain0, sweep0 + s), pool_cap, vs_table);
+    else if (kinds)
       hipLaunchKernelGGL(rotor_sweep_kernel<true>, dim3(nseg2, B), dim3(256), lds + HbPool::bytes(pool_cap), st, P,
-                         (const double *)src, dst, owned, n, kinds, make_key(seed, chain0, sweep0 + s), pool_cap);
+                         (const double *)src, dst, owned, n, kinds, make_key(seed, chain0, sweep0 + s), pool_cap, vs_table);
     else
       hipLaunchKernelGGL(rotor_sweep_kernel<false>, dim3(nseg2, B), dim3(256), lds, st, P, (const double *)src, dst, owned, n,
-                         kinds, make_key(seed, chain0, sweep0 + s), 0u);
+                         kinds, make_key(seed, chain0, sweep0 + s), 0u, vs_table);
     MLMCPI_LAUNCH_CHECK("rotor_sweep_kernel");
     src = dst;
     dst = (dst == d_w0) ? d_w1 : d_w0;

@@ -114,6 +114,78 @@ Tuning tuning() {
   return g_tuning;
 }
 
+// ---- tables of the step-envelope sampler (device_common.hpp, "tabulated step envelope") -----------------------------------
+// For the action's scale (kappa = scale |cos(.)| <= scale <= kVsKappaMax) and each of the kVsClasses ranges of kappa: the
+// proposal probabilities q_k / 64 of the eight bins, as a 64-entry selector, and log2 of the acceptance factors.
+void vs_build_tables(double scale, uint8_t *sel, float *lw) {
+  static const int edges16[kVsBins + 1] = {0, 1, 2, 3, 4, 6, 8, 12, 16};
+  for (int c = 0; c < kVsClasses; ++c) {
+    const double kmin = scale * sin(2.0 * kPi * c / 32.0);  // the smallest concentration of the class
+    double hw[kVsBins], w[kVsBins], total = 0.0;
+    for (int k = 0; k < kVsBins; ++k) {
+      w[k] = (edges16[k + 1] - edges16[k]) * (kPi / 16.0);
+      hw[k] = exp(kmin * (cos(edges16[k] * (kPi / 16.0)) - 1.0)) * w[k];  // target at the bin's left edge (its maximum) x width
+      total += hw[k];
+    }
+    int q[kVsBins], sum = 0;
+    for (int k = 0; k < kVsBins; ++k) {
+      q[k] = (int)floor(hw[k] / total * kVsSel);
+      if (q[k] < 1) q[k] = 1;
+      sum += q[k];
+    }
+    while (sum < kVsSel) {  // the bin that binds the envelope constant gets the next selector value
+      int j = 0;
+      for (int k = 1; k < kVsBins; ++k)
+        if (hw[k] / q[k] > hw[j] / q[j]) j = k;
+      ++q[j];
+      ++sum;
+    }
+    while (sum > kVsSel) {  // (many bins at the minimum of one value): take from the bin that stays lowest
+      int j = -1;
+      for (int k = 0; k < kVsBins; ++k)
+        if (q[k] > 1 && (j < 0 || hw[k] / (q[k] - 1) < hw[j] / (q[j] - 1))) j = k;
+      --q[j];
+      --sum;
+    }
+    double M = 0.0;
+    for (int k = 0; k < kVsBins; ++k) M = fmax(M, hw[k] / q[k]);
+    int pos = 0;
+    for (int k = 0; k < kVsBins; ++k) {
+      for (int i = 0; i < q[k]; ++i) sel[c * kVsSel + pos++] = (uint8_t)k;
+      // acceptance factor (w_k / q_k) / M <= 1 / H_k, lowered by 4e-6 in log2 so that float rounding never lifts it above
+      const double x = log2(w[k] / q[k] / M) - 4e-6;
+      float f = (float)x;
+      if ((double)f > x) f = nextafterf(f, -INFINITY);
+      lw[c * kVsBins + k] = f;
+    }
+  }
+}
+
+namespace {
+struct VsTableEntry { int device; double scale; uint32_t *d_table; };
+std::mutex g_vs_mutex;
+std::vector<VsTableEntry> g_vs_tables;
+}  // namespace
+
+int vs_table_device(double scale, const uint32_t **d_table) {
+  int dev = 0;
+  MLMCPI_HIP_TRY(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(g_vs_mutex);
+  for (const VsTableEntry &e : g_vs_tables)
+    if (e.device == dev && e.scale == scale) {
+      *d_table = e.d_table;
+      return MLMCPI_OK;
+    }
+  uint32_t host[kVsTableBytes / 4];
+  vs_build_tables(scale, (uint8_t *)host, (float *)((uint8_t *)host + kVsClasses * kVsSel));
+  uint32_t *d = nullptr;
+  MLMCPI_HIP_TRY(hipMalloc((void **)&d, kVsTableBytes));
+  MLMCPI_HIP_TRY(hipMemcpy(d, host, kVsTableBytes, hipMemcpyHostToDevice));  // first use of this scale on this device only
+  g_vs_tables.push_back(VsTableEntry{dev, scale, d});
+  *d_table = d;
+  return MLMCPI_OK;
+}
+
 // ---- test kernels ------------------------------------------------------------------------------
 __global__ void test_random_kernel(RngKey key, uint32_t purpose, uint32_t sub, uint32_t n, double *out) {
   uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -136,6 +208,15 @@ __global__ void test_expcos_kernel(RngKey key, double beta, const double *xp, co
                                    double *out) {
   uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k < n) out[k] = expcos_draw(key, k, beta, xp[k], xm[k]);
+}
+
+__global__ void __launch_bounds__(256)
+    test_vs_draw_kernel(RngKey key, double scale, const double *xp, const double *xm, uint32_t n, const uint32_t *d_table, double *out) {
+  __shared__ uint32_t tab_lds[kVsTableBytes / 4];
+  const VsTable tab = VsTable::stage(tab_lds, d_table);
+  __syncthreads();
+  uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) out[k] = vs_draw(key, k, scale, xp[k], xm[k], tab);
 }
 
 __global__ void test_expsin2_kernel(RngKey key, const double *sigma, uint32_t n, double *out) {
@@ -311,6 +392,23 @@ int mlmcpi_test_expcos(uint64_t seed, uint32_t chain, uint32_t step, double beta
   hipLaunchKernelGGL(test_expcos_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream),
                      make_key(seed, chain, step), beta, d_xp, d_xm, n, d_out);
   MLMCPI_LAUNCH_CHECK("test_expcos_kernel");
+  return MLMCPI_OK;
+}
+
+int mlmcpi_test_vs_draw(uint64_t seed, uint32_t chain, uint32_t step, double scale, const double *d_xp, const double *d_xm,
+                        uint32_t n, double *d_out, void *stream) {
+  MLMCPI_REQUIRE(d_xp && d_xm && d_out && n > 0 && scale >= 0.0 && scale <= kVsKappaMax, "bad arguments");
+  const uint32_t *d_table = nullptr;
+  if (int rc = vs_table_device(scale, &d_table)) return rc;
+  hipLaunchKernelGGL(test_vs_draw_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream), make_key(seed, chain, step),
+                     scale, d_xp, d_xm, n, d_table, d_out);
+  MLMCPI_LAUNCH_CHECK("test_vs_draw_kernel");
+  return MLMCPI_OK;
+}
+
+int mlmcpi_vs_table(double scale, uint8_t *sel, float *lw) {
+  MLMCPI_REQUIRE(sel && lw && scale >= 0.0 && scale <= kVsKappaMax, "bad arguments (0 <= scale <= %g)", kVsKappaMax);
+  vs_build_tables(scale, sel, lw);
   return MLMCPI_OK;
 }
 

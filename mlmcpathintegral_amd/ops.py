@@ -344,6 +344,12 @@ def test_expcos(seed, chain, step, beta, xp, xm):
     return out
 
 
+def test_vs_draw(seed, chain, step, scale, xp, xm):
+    out = torch.empty_like(xp)
+    abi.call("mlmcpi_test_vs_draw", seed, chain, step, float(scale), _p(xp), _p(xm), xp.numel(), _p(out), _stream())
+    return out
+
+
 def test_expsin2(seed, chain, step, sigma):
     out = torch.empty_like(sigma)
     abi.call("mlmcpi_test_expsin2", seed, chain, step, _p(sigma), sigma.numel(), _p(out), _stream())

@@ -55,6 +55,8 @@ _SIGS = {
     "orc_expsin2_draws": (None, [_u64, _d, _u32, _dp]),
     "orc_dev_expcos_draw": (_d, [_u64, _u32, _u32, _u32, _d, _d, _d]),
     "orc_dev_expsin2_draw": (_d, [_u64, _u32, _u32, _u32, _d]),
+    "orc_dev_vs_draw": (_d, [_u64, _u32, _u32, _u32, _d, _d, _d]),
+    "orc_vs_tables": (None, [_d, _vp, _vp]),
     "orc_qoi_xsquared": (_d, [_dp, _u32]),
     "orc_qoi_susceptibility": (_d, [_dp, _u32, _d]),
     "orc_qoi_2d_susceptibility": (_d, [_dp, _i, _i]),

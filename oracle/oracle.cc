@@ -201,6 +201,107 @@ inline double dev_vonmises(const DevRng &rng, uint32_t site, double kappa, uint3
   return negative ? -theta : theta;
 }
 
+// Device-order angle sampler for moderate concentrations (sweeps of actions with kappa_max = scale <= kVsKappaMax;
+// device: device_common.hpp, "tabulated step envelope").  Same von Mises law p(x) ~ exp(kappa cos x), piecewise-constant
+// envelope: |x| falls into one of eight bins with edges (0, 1, 2, 3, 4, 6, 8, 12, 16) pi/16, bin k proposed with
+// probability q_k / 64, |x| uniform inside the bin, accepted with probability
+//     exp(kappa (cos x - 1)) (w_k / q_k) / max_j (H_j w_j / q_j),      H_j = exp(kappa_min (cos(edge_j) - 1)),
+// = target / (proposal density x envelope constant) for every kappa >= kappa_min.  The q_k depend on the range the
+// concentration lies in: with t = |(x_m - x_p) / (4 pi)| reduced to [0, 1/2], kappa = scale sin(2 pi v), v = |t - 1/4|,
+// class c = floor(32 v) (at most 7), kappa_min(c) = scale sin(2 pi c / 32).  The integers q_k are chosen by a
+// deterministic rule (below); tests compare them, and the acceptance factors, with the product's table
+// (mlmcpi_vs_table).  Bits of an attempt v = hi:lo as for dev_vonmises (bit 0 sign, bits 1..11 leading bits of u2, tail
+// of u2 from the refine call); of the 52 bits above them the top six select the bin (selector value s belongs to bin k
+// when q_0 + ... + q_{k-1} <= s < q_0 + ... + q_k) and the other 46 are the position inside it.  The test is taken in
+// logarithms, exactly as the device's exact path does.
+constexpr double kVsKappaMax = 4.0;
+constexpr int kVsClasses = 8, kVsBins = 8, kVsSel = 64;
+struct VsTables {
+  int q[kVsClasses][kVsBins];
+  float lw[kVsClasses][kVsBins];  // log2 of the acceptance factor, as the float the device holds
+  double scale = -1.0;
+  static const int *edges16() {
+    static const int e[kVsBins + 1] = {0, 1, 2, 3, 4, 6, 8, 12, 16};
+    return e;
+  }
+  void build(double scale_) {
+    scale = scale_;
+    const int *e16 = edges16();
+    for (int c = 0; c < kVsClasses; ++c) {
+      const double kmin = scale * std::sin(2.0 * kPi * c / 32.0);
+      double hw[kVsBins], w[kVsBins], total = 0.0;
+      for (int k = 0; k < kVsBins; ++k) {
+        w[k] = (e16[k + 1] - e16[k]) * (kPi / 16.0);
+        hw[k] = std::exp(kmin * (std::cos(e16[k] * (kPi / 16.0)) - 1.0)) * w[k];
+        total += hw[k];
+      }
+      // every bin at least one selector value; then the remaining values one at a time to the bin that currently
+      // binds the envelope constant (largest H w / q); should the minimum of one have overshot, values are taken back
+      // from the bin that stays lowest
+      int sum = 0;
+      for (int k = 0; k < kVsBins; ++k) {
+        q[c][k] = std::max(1, (int)std::floor(hw[k] / total * kVsSel));
+        sum += q[c][k];
+      }
+      for (; sum < kVsSel; ++sum) {
+        int j = 0;
+        for (int k = 1; k < kVsBins; ++k)
+          if (hw[k] / q[c][k] > hw[j] / q[c][j]) j = k;
+        ++q[c][j];
+      }
+      for (; sum > kVsSel; --sum) {
+        int j = -1;
+        for (int k = 0; k < kVsBins; ++k)
+          if (q[c][k] > 1 && (j < 0 || hw[k] / (q[c][k] - 1) < hw[j] / (q[c][j] - 1))) j = k;
+        --q[c][j];
+      }
+      double M = 0.0;
+      for (int k = 0; k < kVsBins; ++k) M = std::fmax(M, hw[k] / q[c][k]);
+      for (int k = 0; k < kVsBins; ++k) {
+        const double x = std::log2(w[k] / q[c][k] / M) - 4e-6;  // a hair below: float rounding must not lift it above 1 / H_k
+        float f = (float)x;
+        if ((double)f > x) f = std::nextafterf(f, -INFINITY);
+        lw[c][k] = f;
+      }
+    }
+  }
+};
+inline const VsTables &vs_tables(double scale) {
+  static thread_local VsTables t;
+  if (t.scale != scale) t.build(scale);
+  return t;
+}
+
+// one draw between the staple sums / neighbours x_p, x_m; returns the angle relative to the centre
+inline double dev_vonmises_table(const DevRng &rng, uint32_t site, double scale, double x_p, double x_m, uint32_t sub0 = 0) {
+  const VsTables &T = vs_tables(scale);
+  const double v = (x_m - x_p) * (0.25 / kPi);
+  const double t = std::fabs(v - std::rint(v));
+  const int cls = std::min(kVsClasses - 1, (int)(32.0 * std::fabs(t - 0.25)));
+  const double kappa = std::fmax(scale * std::fabs(std::cos(0.5 * (x_m - x_p))), 1e-12);
+  const int *e16 = VsTables::edges16();
+  double theta = 0.0;
+  bool negative = false;
+  for (uint32_t pair = 0; pair < kMaxVmPairs; ++pair) {
+    const Philox4 w = rng.raw(site, P_VONMISES, sub0 | pair);
+    const Philox4 e = rng.raw(site, P_VONMISES, sub0 | kVmRefine | pair);
+    bool accepted = false;
+    for (int h = 0; h < 2 && !accepted; ++h) {
+      const uint32_t lo = w.v[2 * h], hi = w.v[2 * h + 1];
+      const uint64_t bits = ((uint64_t)hi << 32) | lo;
+      int sel = (int)(hi >> 26), k = 0;
+      while (sel >= T.q[cls][k]) sel -= T.q[cls][k++];
+      const double pos = (double)((bits >> 12) & ((1ull << 46) - 1)) * (1.0 / 70368744177664.0);  // 46 bits
+      theta = (kPi / 16.0) * ((double)e16[k] + (double)(e16[k + 1] - e16[k]) * pos);
+      negative = (lo & 1u) != 0;
+      const double u2 = ((double)((lo >> 1) & 0x7FFu) + u01(e.v[2 * h], e.v[2 * h + 1])) * (1.0 / 2048.0);
+      accepted = u2 <= 0.0 || std::log(u2) <= kappa * (std::cos(theta) - 1.0) + 0.69314718055994531 * (double)T.lw[cls][k];
+    }
+    if (accepted) break;
+  }
+  return negative ? -theta : theta;
+}
+
 struct RefAngles {  // reference algorithms, reference engine
   RefRng &r;
   double expcos(uint32_t, double beta, double x_p, double x_m) {
@@ -213,12 +314,17 @@ struct RefAngles {  // reference algorithms, reference engine
   }
 };
 
-struct DevAngles {  // device order: Philox + Best-Fisher
+struct DevAngles {  // device order: Philox + Best-Fisher, or the tabulated step envelope for actions of moderate concentration
   const DevRng &rng;
+  double scale = 1e300;  // the largest concentration the action can produce (2 beta; 2 m0 / a): picks the sampler
+  // angle relative to the centre of the conditional between x_p and x_m, concentration kappa = scale |cos((x_m - x_p)/2)|
+  double between(uint32_t site, double x_p, double x_m, double kappa) const {
+    return scale <= kVsKappaMax ? dev_vonmises_table(rng, site, scale, x_p, x_m) : dev_vonmises(rng, site, kappa);
+  }
   double expcos(uint32_t site, double beta, double x_p, double x_m) {
     const double dx = x_m - x_p;
     const double tau = 2. * beta * std::fabs(std::cos(0.5 * dx));
-    const double x = dev_vonmises(rng, site, tau);
+    const double x = scale <= kVsKappaMax ? between(site, x_p, x_m, tau) : dev_vonmises(rng, site, tau);
     return wrap_2pi(x + 0.5 * (x_p + x_m) + (std::fabs(dx) > kPi ? kPi : 0.0));  // expcosdistribution.hh:64
   }
   double expsin2(uint32_t site, double sigma) { return dev_vonmises(rng, site, 0.5 * sigma); }
@@ -561,7 +667,8 @@ void rotor_dev_update(const ActionO &A, double *x, unsigned l, bool heat, const 
   const double c = std::cos(0.5 * (xp - xm));
   const double kappa = 2.0 * A.m0 / A.a * std::fabs(c);
   const double centre = 0.5 * (xp + xm) + (c < 0.0 ? kPi : 0.0);
-  x[l] = wrap_2pi(centre + dev_vonmises(rng, l, kappa));
+  const DevAngles src{rng, 2.0 * A.m0 / A.a};
+  x[l] = wrap_2pi(centre + src.between(l, xp, xm, kappa));
 }
 
 void dev_sweep(const ActionO &A, double *x, bool heat, const DevRng &rng) {
@@ -576,7 +683,7 @@ void dev_sweep(const ActionO &A, double *x, bool heat, const DevRng &rng) {
       if (!heat) {
         A.overrelax(x, l);
       } else {
-        DevAngles src{rng};
+        DevAngles src{rng, A.kind == SCHWINGER ? 2.0 * A.beta : 1e300};
         double gn = 0.0;
         if (A.kind == GFF) {
           double n0, n1;
@@ -1738,6 +1845,22 @@ double orc_dev_expcos_draw(uint64_t seed, uint32_t chain, uint32_t step, uint32_
   DevRng r{(uint32_t)seed, (uint32_t)(seed >> 32), chain, step};
   DevAngles s{r};
   return s.expcos(site, beta, x_p, x_m);
+}
+// the tabulated step-envelope sampler: heat-bath draw between x_p and x_m for an action of the given scale (<= 4),
+// returned as the device's test hook returns it: wrap_2pi(centre + x)
+double orc_dev_vs_draw(uint64_t seed, uint32_t chain, uint32_t step, uint32_t site, double scale, double x_p, double x_m) {
+  DevRng r{(uint32_t)seed, (uint32_t)(seed >> 32), chain, step};
+  const double c = std::cos(0.5 * (x_m - x_p));
+  return wrap_2pi(0.5 * (x_p + x_m) + (c < 0.0 ? kPi : 0.0) + dev_vonmises_table(r, site, scale, x_p, x_m));
+}
+// the oracle's own construction of the sampler's tables: q[8][8] selector counts, lw[8][8] log2 acceptance factors
+void orc_vs_tables(double scale, int *q, float *lw) {
+  const VsTables &T = vs_tables(scale);
+  for (int c = 0; c < kVsClasses; ++c)
+    for (int k = 0; k < kVsBins; ++k) {
+      q[c * kVsBins + k] = T.q[c][k];
+      lw[c * kVsBins + k] = T.lw[c][k];
+    }
 }
 double orc_dev_expsin2_draw(uint64_t seed, uint32_t chain, uint32_t step, uint32_t site, double sigma) {
   DevRng r{(uint32_t)seed, (uint32_t)(seed >> 32), chain, step};

@@ -51,6 +51,85 @@ def test_expsin2_device_order_equals_reference_distribution(orc, sigma):
     assert stats.ks_2samp(dev, ref).pvalue > 1e-3
 
 
+@pytest.mark.parametrize("scale,d", [(2.0, 0.0), (2.0, 0.5), (2.0, 1.2), (2.0, 2.0), (2.0, 2.6), (2.0, 3.0), (2.0, 3.14159265),
+                                     (4.0, 0.3), (4.0, 4.5), (0.6, 1.0), (0.0, 1.0), (3.0, -7.0)])
+def test_step_envelope_sampler_draws_the_von_mises_law(orc, scale, d):
+    """The sweeps' sampler for actions of moderate concentration (oracle dev_vonmises_table = the device's tabulated step
+    envelope), over all concentration classes: KS against the analytic CDF and against the reference's own ExpSin2
+    algorithm (sigma = 2 kappa), and the mean of cos(x - centre) against I1/I0."""
+    from scipy.special import i0e, i1e
+    L = orc.lib()
+    n = 60000
+    x_p, x_m = 0.4, 0.4 + d
+    kappa = scale * abs(np.cos(0.5 * d))
+    centre = 0.5 * (x_p + x_m) + (np.pi if np.cos(0.5 * d) < 0 else 0.0)
+    dev = np.array([L.orc_dev_vs_draw(5, 0, 0, k, scale, x_p, x_m) for k in range(n)])
+    rel = dev - centre
+    rel -= 2 * np.pi * np.round(rel / (2 * np.pi))
+    assert (np.abs(dev) <= np.pi + 1e-12).all()
+    assert stats.kstest(rel, vonmises_cdf(kappa)).pvalue > 1e-3
+    if kappa > 1e-6:
+        ref = np.zeros(n)
+        L.orc_expsin2_draws(8765, 2.0 * kappa, n, ref)
+        assert stats.ks_2samp(rel, ref).pvalue > 1e-3
+    m, se = np.cos(rel).mean(), np.cos(rel).std() / np.sqrt(n)
+    assert abs(m - i1e(kappa) / i0e(kappa)) < 4.5 * se, (m, i1e(kappa) / i0e(kappa), se)
+
+
+@pytest.mark.parametrize("scale", [0.0, 0.5, 2.0, 2.5, 4.0])
+def test_step_envelope_tables(orc, scale):
+    """The product's table (mlmcpi_vs_table, host code of libmlmcpi_hip.so) against the oracle's own construction: same
+    selector counts, same acceptance factors; and the properties that make it a sampler at all -- 64 selector values per
+    class, every bin reachable, and a valid envelope (acceptance probability <= 1 at every bin's left edge for the
+    smallest concentration of the class, hence everywhere for every concentration of the class)."""
+    import ctypes as C
+    from mlmcpathintegral_amd import abi
+    sel = np.zeros(8 * 64, dtype=np.uint8)
+    lw = np.zeros(64, dtype=np.float32)
+    abi.call("mlmcpi_vs_table", float(scale), sel.ctypes.data_as(C.c_void_p), lw.ctypes.data_as(C.c_void_p))
+    q_o = np.zeros(64, dtype=np.int32)
+    lw_o = np.zeros(64, dtype=np.float32)
+    orc.lib().orc_vs_tables(float(scale), q_o.ctypes.data_as(C.c_void_p), lw_o.ctypes.data_as(C.c_void_p))
+    sel, lw, q_o, lw_o = sel.reshape(8, 64), lw.reshape(8, 8), q_o.reshape(8, 8), lw_o.reshape(8, 8)
+    edges = np.array([0, 1, 2, 3, 4, 6, 8, 12, 16]) * np.pi / 16
+    for c in range(8):
+        q = np.bincount(sel[c], minlength=8)
+        assert q.sum() == 64 and (q >= 1).all() and (np.diff(sel[c].astype(int)) >= 0).all()
+        assert (q == q_o[c]).all(), (c, q, q_o[c])
+        assert (lw[c] == lw_o[c]).all(), (c, lw[c], lw_o[c])
+        kmin = scale * np.sin(2 * np.pi * c / 32)
+        worst = np.exp(kmin * (np.cos(edges[:-1]) - 1.0)) * 2.0 ** lw[c].astype(np.float64)
+        assert worst.max() <= 1.0 and worst.max() > 0.99999, worst       # valid, and tight in the binding bin
+        # overall acceptance = integral of the target / envelope mass
+        grid = np.linspace(0, np.pi, 20001)
+        for kappa in (kmin, scale * np.sin(2 * np.pi * (c + 1) / 32)):
+            k = np.searchsorted(edges, grid, side="right") - 1
+            k = np.clip(k, 0, 7)
+            acc = np.exp(kappa * (np.cos(grid) - 1.0)) * 2.0 ** lw[c][k].astype(np.float64)      # acceptance probability at x
+            dens = (q[k] / 64.0) / np.diff(edges)[k]                                               # proposal density on |x|
+            rate = np.trapezoid(acc * dens, grid)
+            # 0.67 ... 0.89 at scale 2 (beta = 1); the classes of scale 4 are twice as wide in kappa: 0.53 at worst
+            assert acc.max() <= 1.0 + 1e-12 and rate > (0.65 if scale <= 2.0 else 0.5), (c, kappa, rate)
+
+
+def test_sweep_sampler_rule_follows_the_largest_concentration(orc):
+    """dev_sweep picks the sampler from the action (2 beta, 2 m0 / a <= 4: step envelope): a Schwinger heat-bath update
+    at beta <= 2 must be the tabulated sampler's draw between the staples, at beta = 2.5 the wrapped-Cauchy one."""
+    import ctypes as C
+    L = orc.lib()
+    for beta, step in ((1.0, True), (2.0, True), (2.5, False)):
+        A = orc.Action(orc.SCHWINGER, Mt=4, Mx=4, beta=beta)
+        x = np.sin(np.arange(32) + 1.0)
+        y = x.copy()
+        A.dev_sweep(y, True, 77, 3, 5)
+        # link 0 is updated first (colour 0): rebuild its draw from the initial staples
+        tp, tm = C.c_double(), C.c_double()
+        L.orc_action_staples(A.h, x, 0, C.byref(tp), C.byref(tm))
+        d = L.orc_dev_vs_draw(77, 3, 5, 0, min(2 * beta, 4.0), tp.value, tm.value) - y[0]
+        d -= 2 * np.pi * np.round(d / (2 * np.pi))
+        assert (abs(d) < 1e-13) == step, (beta, d)
+
+
 def test_vonmises_extreme_concentrations_terminate(orc):
     L = orc.lib()
     for sigma in (0.0, 1e-300, 1e-9, 1e9, float("nan")):

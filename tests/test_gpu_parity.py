@@ -89,6 +89,21 @@ def test_expcos_draws_match_oracle(gpu_ops, orc):
         assert ((got >= -np.pi) & (got < np.pi + 1e-15)).all()
 
 
+def test_step_envelope_draws_match_oracle(gpu_ops, orc):
+    """The sampler of the heat-bath sweeps at moderate concentrations (device_common.hpp, "tabulated step envelope";
+    oracle dev_vonmises_table): the accepted angle is a linear function of random bits, so device and oracle agree to
+    rounding wherever they take the same accept / reject decisions -- i.e. everywhere."""
+    rng = np.random.default_rng(3)
+    n = 8192
+    for scale in (2.0, 4.0, 0.7, 0.0):
+        xp, xm = rng.uniform(-3 * np.pi, 3 * np.pi, n), rng.uniform(-3 * np.pi, 3 * np.pi, n)
+        xm[:4] = xp[:4] + np.array([0.0, np.pi, 2 * np.pi, np.pi - 1e-9])   # kappa = scale, 0, scale, ~0
+        got = gpu_ops.test_vs_draw(SEED, 2, 9, scale, dev(xp), dev(xm)).cpu().numpy()
+        want = np.array([orc.lib().orc_dev_vs_draw(SEED, 2, 9, k, scale, xp[k], xm[k]) for k in range(n)])
+        assert_angles_close(got, want, tol=1e-13, what=f"tabulated step envelope, scale {scale}")
+        assert ((got >= -np.pi - 1e-15) & (got < np.pi + 1e-15)).all()
+
+
 def test_expsin2_draws_match_oracle(gpu_ops, orc):
     rng = np.random.default_rng(2)
     n = 4096

@@ -230,7 +230,8 @@ def test_rotor_closed_form_equals_reference_formula(orc):
                 xm, xp = ref[(l - 1) % M], ref[(l + 1) % M]
                 x_min = math.atan2(math.sin(xp) + math.sin(xm), math.cos(xp) + math.cos(xm))
                 sigma = 2.0 * (2.0 * m0 / a) * abs(math.cos(0.5 * (xp - xm)))
-                ref[l] = wrap(x_min + L.orc_dev_expsin2_draw(5, 0, trial, l, sigma))
+                # 2 m0 / a = 4 <= kVsKappaMax: the sweeps of this action draw from the step envelope (kappa = sigma / 2)
+                ref[l] = L.orc_dev_vs_draw(5, 0, trial, l, 2.0 * m0 / a, xp, xm)
         dev = x.copy()
         A.dev_sweep(dev, True, 5, 0, trial)
         assert np.max(np.abs(wrap(dev - ref))) < 1e-9
