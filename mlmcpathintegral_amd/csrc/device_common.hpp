@@ -536,7 +536,7 @@ __device__ __forceinline__ void heatbath_cells(uint32_t total, const RngKey &key
 // is built for kappa_min = scale sin(2 pi c / 32) and is a valid envelope for every larger kappa (the normalised target
 // only gets narrower).  Acceptance 0.70 ... 0.89 (0.79 on average; wrapped Cauchy: 0.82).  The tables are built by the
 // host for the action's scale (runtime.hip, vs_build_tables; exported as mlmcpi_vs_table so that the oracle's own
-// construction can be compared with it) and copied to LDS by the kernels: 512 selector bytes + 64 floats.
+// construction can be compared with it) and copied to LDS by the kernels: 512 selector bytes + 8 x 16 floats.
 // The test is screened in fp32 (24 bits of |x|, one polynomial cosine, v_exp_f32) against the 11 leading bits of u2 with a
 // guard band that covers every fp32 rounding on the way; when the band does not decide (one attempt in ~10^3), the exact
 // fp64 test with the full u2 takes over, as for the wrapped-Cauchy sampler, so the decision is always the one of the
@@ -545,20 +545,23 @@ __device__ __forceinline__ void heatbath_cells(uint32_t total, const RngKey &key
 // selector bits on top of 46 position bits).
 constexpr double kVsKappaMax = 4.0;  // host rule (lattice2d.hip / path1d.hip; the oracle applies the same): kappa_max <= 4
 constexpr int kVsClasses = 8, kVsBins = 8, kVsSel = 64;
-constexpr uint32_t kVsTableBytes = kVsClasses * kVsSel + kVsClasses * kVsBins * 4;  // selector bytes | lw floats
+// In LDS (and in the device copy the host uploads): code[class][64], one byte per selector value = left edge of its bin
+// (low nibble) and the bin's width (high nibble), both in units of pi/16 -- an attempt needs no other decoding --, then
+// lw[class][16] floats indexed by that left edge (8 of the 16 slots are used).
+constexpr uint32_t kVsTableBytes = kVsClasses * kVsSel + kVsClasses * 16 * 4;
 
 struct VsTable {  // in LDS
-  const uint8_t *sel;  // [class][64]: bin of a selector value
-  const float *lw;     // [class][8]: log2 of the acceptance factor of a bin
-  // threads 0 .. 191 copy the action's table from global memory (visible after the caller's next barrier)
+  const uint8_t *code;  // [class][64]
+  const float *lw;      // [class][16]: log2 of the acceptance factor of the bin whose left edge is the index
+  // threads 0 .. 255 copy the action's table from global memory (visible after the caller's next barrier)
   __device__ static VsTable stage(void *lds, const uint32_t *__restrict__ d_table) {
     if (d_table && threadIdx.x < kVsTableBytes / 4) ((uint32_t *)lds)[threadIdx.x] = d_table[threadIdx.x];
     return VsTable{(const uint8_t *)lds, (const float *)((const uint8_t *)lds + kVsClasses * kVsSel)};
   }
 };
-// left edge and width of bin k in units of pi/16: edges 0 1 2 3 4 6 8 12, widths 1 1 1 1 2 2 4 4
-__device__ __forceinline__ uint32_t vs_edge16(uint32_t k) { return (0xC8643210u >> (4u * k)) & 15u; }
-__device__ __forceinline__ uint32_t vs_width16(uint32_t k) { return 1u << ((k >> 1) > 1u ? (k >> 1) - 1u : 0u); }
+// host side of the same encoding: left edge and width of bin k in units of pi/16 (edges 0 1 2 3 4 6 8 12, widths 1 1 1 1 2 2 4 4)
+__host__ __device__ constexpr uint32_t vs_edge16(uint32_t k) { return (0xC8643210u >> (4u * k)) & 15u; }
+__host__ __device__ constexpr uint32_t vs_width16(uint32_t k) { return (0x44221111u >> (4u * k)) & 15u; }
 
 // cos(x), x in [0, pi], fp32: sin(pi/2 - x) by its Taylor polynomial to x^11 (truncation 6e-8, rounding ~1e-7)
 __device__ __forceinline__ float cosf_0_pi(float x) {
@@ -577,6 +580,8 @@ struct VsCell {
   uint32_t cls;    // which table
   uint32_t site;   // Philox counter word 0
 };
+// guard band of the screening test, relative to the acceptance probability (see vs_try)
+__device__ __forceinline__ float vs_band(float kp) { return 1e-5f * (1.0f + kp); }
 
 // Cell set-up shared by the Schwinger links (x_p, x_m = the two staple sums, scale = 2 beta) and the rotor sites
 // (x_p, x_m = the neighbours, scale = 2 m0 / a): conditional exp(scale/2 [cos(x - x_p) + cos(x - x_m)])
@@ -594,33 +599,46 @@ __device__ __forceinline__ double vs_kappa_exact(double scale, double x_p, doubl
   return vm_clamp(scale * fabs(cos_half(x_m - x_p)));
 }
 
-// |x| of the attempt (lo, hi), fp64: (pi/16) (edge + width pos), pos = the 46 bits below the selector
-__device__ __forceinline__ double vs_theta(uint32_t lo, uint32_t hi, uint32_t bin) {
+// |x| of the attempt (lo, hi), fp64: (pi/16) (edge + width pos), pos = the 46 bits below the selector; code = the bin's byte
+__device__ __forceinline__ double vs_theta(uint32_t lo, uint32_t hi, uint32_t code) {
   // mantissa = 000000 | 46 position bits: m = 1 + pos / 64
   const double m = __hiloint2double((int)(((hi >> 12) & 0x3FFFu) | 0x3FF00000u), (int)__builtin_amdgcn_alignbit(hi, lo, 12));
-  const double w64 = (double)(64u * vs_width16(bin)), e = (double)vs_edge16(bin);
+  const double w64 = (double)((code >> 4) << 6), e = (double)(code & 15u);
   return (kPi / 16.0) * fma(w64, m, e - w64);   // one rounding of edge + width pos, as in the oracle
 }
 
-// screening decision of one attempt: 1 accepted, 0 rejected, -1 open; `bin` comes back for the caller
-__device__ __forceinline__ int vs_try(uint32_t lo, uint32_t hi, float kp, uint32_t cls, const VsTable &tab, uint32_t &bin) {
-  bin = tab.sel[cls * kVsSel + (hi >> 26)];
+// screening decision of one attempt: 1 accepted, 0 rejected, -1 open; the bin's code byte comes back for the caller
+__device__ __forceinline__ int vs_try(uint32_t lo, uint32_t hi, float kp, uint32_t cls, const VsTable &tab, uint32_t &code) {
+  code = tab.code[cls * kVsSel + (hi >> 26)];
+  const uint32_t e16 = code & 15u;
   const float posf = (float)((hi >> 2) & 0xFFFFFFu) * (1.0f / 16777216.0f);      // the leading 24 position bits
-  const float c = cosf_0_pi(0.196349541f * fmaf((float)vs_width16(bin), posf, (float)vs_edge16(bin)));
-  const float af = __builtin_amdgcn_exp2f(fmaf(kp, c - 1.0f, tab.lw[cls * kVsBins + bin]));   // acceptance probability
-  // error budget of log2(af): |x| to 24 bits (1e-7 kappa'), the cosine (1.5e-7 kappa'), kappa' itself (2e-7 kappa' from
-  // the fp32 cosine behind it), the fma (1e-6 at |log2 af| <= 16): < 4e-7 (1 + kappa') in all, i.e. < 3e-7 (1 + kappa')
-  // relative on af, plus v_exp_f32's own ~2e-7.  The band is 30 times that.
-  const float band = af * (1e-5f * (1.0f + kp));
-  const float lo_s = (float)((lo >> 1) & 0x7FFu) * (1.0f / 2048.0f), hi_s = lo_s + (1.0f / 2048.0f);   // u2 in [lo_s, hi_s)
-  return hi_s <= af - band ? 1 : (lo_s >= af + band ? 0 : -1);
+  const float c = cosf_0_pi(0.196349541f * fmaf((float)(code >> 4), posf, (float)e16));
+  // acceptance probability x 2048 (the scale of the 11 leading bits b of u2: u2 in [b, b + 1) / 2048)
+  const float a2048 = __builtin_amdgcn_exp2f(fmaf(kp, c - 1.0f, tab.lw[cls * 16 + e16] + 11.0f));
+  // error budget of log2(a): |x| to 24 bits (1e-7 kappa'), the cosine (1.5e-7 kappa'), kappa' itself (2e-7 kappa' from
+  // the fp32 cosine behind it), the fma (1e-6 at |log2 a| <= 16): < 4e-7 (1 + kappa') in all, i.e. < 3e-7 (1 + kappa')
+  // relative on a, plus v_exp_f32's own ~2e-7.  The band is 30 times that.
+  const float band = vs_band(kp), b = (float)((lo >> 1) & 0x7FFu);
+  return b + 1.0f <= a2048 * (1.0f - band) ? 1 : (b >= a2048 * (1.0f + band) ? 0 : -1);
 }
 
 // the exact test: u2 = (b + tail) / 2048 against exp(kappa (cos x - 1)) 2^lw, in logarithms
-__device__ __forceinline__ int vs_exact(uint32_t lo, uint32_t hi, uint32_t bin, double tail, double kappa, float lw) {
+__device__ __forceinline__ int vs_exact(uint32_t lo, uint32_t hi, uint32_t code, double tail, double kappa, float lw) {
   const double u2 = ((double)((lo >> 1) & 0x7FFu) + tail) * (1.0 / 2048.0);
-  const double la = fma(kappa, cospi_unit(vs_theta(lo, hi, bin) * (1.0 / kPi)) - 1.0, 0.69314718055994531 * (double)lw);
+  const double la = fma(kappa, cospi_unit(vs_theta(lo, hi, code) * (1.0 / kPi)) - 1.0, 0.69314718055994531 * (double)lw);
   return (u2 <= 0.0 || log_unit(u2) <= la) ? 1 : 0;
+}
+
+// The open decisions of a pair of attempts, taken exactly (one attempt in ~10^3 gets here).  Not inlined: the fp64
+// polynomial coefficients of this path would otherwise be hoisted into scalar registers for the whole kernel and push
+// the hot loop's own constants out (the hot loop then reloads them with v_readlane every iteration).
+__device__ __attribute__((noinline)) uint32_t vs_exact_pair(uint32_t k0, uint32_t k1, uint32_t chain, uint32_t step, uint32_t site,
+                                                            uint32_t w3, U4 q, uint32_t codes, float lwa, float lwb, double kappa,
+                                                            int sa, int sb) {
+  const U4 e = philox4x32_10(site, chain, step, w3 | kVmRefine, k0, k1);
+  if (sa < 0) sa = vs_exact(q.x, q.y, codes & 0xFFu, u01(e.x, e.y), kappa, lwa);
+  if (sa == 0 && sb < 0) sb = vs_exact(q.z, q.w, codes >> 8, u01(e.z, e.w), kappa, lwb);
+  return (uint32_t)(sa & 3) | ((uint32_t)(sb & 3) << 2);   // two's complement in two bits each: 3 = open (cannot remain), 1, 0
 }
 
 // attempts 2 pair and 2 pair + 1 of `site`; kappa_exact() is evaluated only when a screening decision is open.
@@ -634,10 +652,10 @@ __device__ __forceinline__ bool vs_attempt_pair(const RngKey &k, uint32_t site, 
   uint32_t ba, bb;
   int sa = vs_try(q.x, q.y, kp, cls, tab, ba), sb = vs_try(q.z, q.w, kp, cls, tab, bb);
   if (sa < 0 || (sa == 0 && sb < 0)) {
-    const U4 e = philox4x32_10(site, k.chain, k.step, w3 | kVmRefine, k.k0, k.k1);
-    const double kap = kappa_exact();
-    if (sa < 0) sa = vs_exact(q.x, q.y, ba, u01(e.x, e.y), kap, tab.lw[cls * kVsBins + ba]);
-    if (sa == 0 && sb < 0) sb = vs_exact(q.z, q.w, bb, u01(e.z, e.w), kap, tab.lw[cls * kVsBins + bb]);
+    const uint32_t r = vs_exact_pair(k.k0, k.k1, k.chain, k.step, site, w3, q, ba | (bb << 8), tab.lw[cls * 16 + (ba & 15u)],
+                                     tab.lw[cls * 16 + (bb & 15u)], kappa_exact(), sa, sb);
+    sa = (int)(r & 3u) == 3 ? -1 : (int)(r & 3u);
+    sb = (int)(r >> 2) == 3 ? -1 : (int)(r >> 2);
   }
   const bool first = sa == 1;
   const uint32_t lo = first ? q.x : q.z, hi = first ? q.y : q.w;

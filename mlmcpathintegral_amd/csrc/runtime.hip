@@ -117,17 +117,17 @@ Tuning tuning() {
 // ---- tables of the step-envelope sampler (device_common.hpp, "tabulated step envelope") -----------------------------------
 // For the action's scale (kappa = scale |cos(.)| <= scale <= kVsKappaMax) and each of the kVsClasses ranges of kappa: the
 // proposal probabilities q_k / 64 of the eight bins, as a 64-entry selector, and log2 of the acceptance factors.
-void vs_build_tables(double scale, uint8_t *sel, float *lw) {
-  static const int edges16[kVsBins + 1] = {0, 1, 2, 3, 4, 6, 8, 12, 16};
+// q[c][k] selector values for bin k of class c, lw[c][k] = log2 of its acceptance factor
+void vs_build_tables(double scale, int *q_out, float *lw) {
   for (int c = 0; c < kVsClasses; ++c) {
     const double kmin = scale * sin(2.0 * kPi * c / 32.0);  // the smallest concentration of the class
     double hw[kVsBins], w[kVsBins], total = 0.0;
     for (int k = 0; k < kVsBins; ++k) {
-      w[k] = (edges16[k + 1] - edges16[k]) * (kPi / 16.0);
-      hw[k] = exp(kmin * (cos(edges16[k] * (kPi / 16.0)) - 1.0)) * w[k];  // target at the bin's left edge (its maximum) x width
+      w[k] = vs_width16(k) * (kPi / 16.0);
+      hw[k] = exp(kmin * (cos(vs_edge16(k) * (kPi / 16.0)) - 1.0)) * w[k];  // target at the bin's left edge (its maximum) x width
       total += hw[k];
     }
-    int q[kVsBins], sum = 0;
+    int *q = q_out + c * kVsBins, sum = 0;
     for (int k = 0; k < kVsBins; ++k) {
       q[k] = (int)floor(hw[k] / total * kVsSel);
       if (q[k] < 1) q[k] = 1;
@@ -149,14 +149,29 @@ void vs_build_tables(double scale, uint8_t *sel, float *lw) {
     }
     double M = 0.0;
     for (int k = 0; k < kVsBins; ++k) M = fmax(M, hw[k] / q[k]);
-    int pos = 0;
     for (int k = 0; k < kVsBins; ++k) {
-      for (int i = 0; i < q[k]; ++i) sel[c * kVsSel + pos++] = (uint8_t)k;
       // acceptance factor (w_k / q_k) / M <= 1 / H_k, lowered by 4e-6 in log2 so that float rounding never lifts it above
       const double x = log2(w[k] / q[k] / M) - 4e-6;
       float f = (float)x;
       if ((double)f > x) f = nextafterf(f, -INFINITY);
       lw[c * kVsBins + k] = f;
+    }
+  }
+}
+
+// the device image (device_common.hpp, VsTable): code[class][64] | lw[class][16]
+static void vs_device_image(double scale, uint32_t *image) {
+  int q[kVsClasses * kVsBins];
+  float lw[kVsClasses * kVsBins];
+  vs_build_tables(scale, q, lw);
+  memset(image, 0, kVsTableBytes);
+  uint8_t *code = (uint8_t *)image;
+  float *lw16 = (float *)(code + kVsClasses * kVsSel);
+  for (int c = 0; c < kVsClasses; ++c) {
+    int pos = 0;
+    for (int k = 0; k < kVsBins; ++k) {
+      for (int i = 0; i < q[c * kVsBins + k]; ++i) code[c * kVsSel + pos++] = (uint8_t)(vs_edge16(k) | (vs_width16(k) << 4));
+      lw16[c * 16 + vs_edge16(k)] = lw[c * kVsBins + k];
     }
   }
 }
@@ -177,7 +192,7 @@ int vs_table_device(double scale, const uint32_t **d_table) {
       return MLMCPI_OK;
     }
   uint32_t host[kVsTableBytes / 4];
-  vs_build_tables(scale, (uint8_t *)host, (float *)((uint8_t *)host + kVsClasses * kVsSel));
+  vs_device_image(scale, host);
   uint32_t *d = nullptr;
   MLMCPI_HIP_TRY(hipMalloc((void **)&d, kVsTableBytes));
   MLMCPI_HIP_TRY(hipMemcpy(d, host, kVsTableBytes, hipMemcpyHostToDevice));  // first use of this scale on this device only
@@ -408,7 +423,13 @@ int mlmcpi_test_vs_draw(uint64_t seed, uint32_t chain, uint32_t step, double sca
 
 int mlmcpi_vs_table(double scale, uint8_t *sel, float *lw) {
   MLMCPI_REQUIRE(sel && lw && scale >= 0.0 && scale <= kVsKappaMax, "bad arguments (0 <= scale <= %g)", kVsKappaMax);
-  vs_build_tables(scale, sel, lw);
+  int q[kVsClasses * kVsBins];
+  vs_build_tables(scale, q, lw);
+  for (int c = 0; c < kVsClasses; ++c) {
+    int pos = 0;
+    for (int k = 0; k < kVsBins; ++k)
+      for (int i = 0; i < q[c * kVsBins + k]; ++i) sel[c * kVsSel + pos++] = (uint8_t)k;
+  }
   return MLMCPI_OK;
 }
 
