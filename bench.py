@@ -123,6 +123,30 @@ def cpu_baseline(a, size):
                     "(12 M link-updates/s/core for 10 OR + 1 HB), so gpu_over_cpu understates the gap to the reference"}
 
 
+def cxx_path(a, size):
+    """The same sampling loop through the C++ host layer (include/mlmcpi/*.hh: OverrelaxedHeatBathSampler::draw_with_qoi +
+    mlmcpi_stats_accumulate, the loop of montecarlosinglelevel.cc:59-77), run by host/driver BEFORE this process touches the
+    GPU: north_star's host is the C++ one, so its rate is recorded next to the Python-driven one of the same session."""
+    exe = os.path.join(ROOT, "host", "driver")
+    if not os.path.exists(exe):
+        return {"error": "host/driver not built"}
+    out = {}
+    for name, batch, samples in (("chains_32", 32, 40), ("single_chain", 1, 200)):
+        cmd = [exe, "--method", "throughput", "--action", "schwinger", "--Mt_lat", str(size), "--sampler", "heatbath",
+               "--batch", str(batch), "--n_samples", str(samples), "--n_burnin", "30", "--seed", str(a.seed),
+               "--n_sweep_overrelax", str(a.n_overrelax), "--n_sweep_heatbath", str(a.n_heatbath)]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not lines:
+            out[name] = {"error": (r.stderr or r.stdout)[-300:]}
+            continue
+        d = json.loads(lines[-1])
+        out[name] = {"chains_per_gpu": batch, "samples": samples, "ms_per_sample": d["ms_per_sample"],
+                     "value_per_gpu": d["updates_per_s"], "unit": "updates/s", "qoi_mean": d["qoi_mean"]}
+    out["command"] = "host/driver --method throughput --action schwinger --Mt_lat %d --sampler heatbath --batch B" % size
+    return out
+
+
 class SweepWorkload:
     """OverrelaxedHeatBathSampler::draw + QoI + record_sample on a 2-D lattice action, B chains."""
 
@@ -258,6 +282,9 @@ def main():
     cpu = None
     if world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(a, size)
+    cxx = None
+    if world == 1 and a.workload == "schwinger" and not a.no_extra_points and a.chains == 0:
+        cxx = cxx_path(a, size)  # child processes; this one has not touched the GPU yet
 
     import torch
     import torch.distributed as dist
@@ -494,6 +521,10 @@ def main():
                 "state and momenta stay in registers for the whole trajectory")
         result["qoi_mean"] = qoi_mean
         result.update(extra)
+        if cxx is not None:
+            result["cxx_path"] = cxx
+            if "value_per_gpu" in cxx.get("chains_32", {}) and B == 32:
+                result["cxx_path"]["over_python_driven"] = cxx["chains_32"]["value_per_gpu"] / (result["value"] / world)
         if cpu is not None:
             result["cpu_baseline"] = cpu
             if cpu.get("value"):

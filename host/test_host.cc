@@ -49,9 +49,9 @@ int main(int argc, char **argv) {
       auto lat = std::make_shared<Lattice1D>(16, 4.0);
       auto act = std::make_shared<QuarticOscillatorAction>(lat, RenormalisationNone, 1.0, 1.0, 1.0, 1.0);
       OverrelaxedHeatBathSampler s(act, OverrelaxedHeatBathParameters());
-    } else if (what == "per_site_update") {
+    } else if (what == "per_site_update") {  // action/action.hh:73-79: an action without local updates
       auto lat = std::make_shared<Lattice1D>(16, 4.0);
-      auto act = std::make_shared<RotorAction>(lat, RenormalisationNone, 0.25);
+      auto act = std::make_shared<QuarticOscillatorAction>(lat, RenormalisationNone, 1.0, 1.0, 1.0, 1.0);
       auto st = std::make_shared<SampleState>(16);
       act->heatbath_update(st, 3);
     } else if (what == "qoi_wrong_size") {
@@ -496,6 +496,56 @@ int main(int argc, char **argv) {
     EXPECT(avg[0] == avg[1] && err[0] == err[1] && total[0] == total[1] && passes[0] == passes[1], "ranks disagree on the reduced statistics");
     EXPECT(total[0] == local[0] + local[1] && local[0] >= local[1] && local[0] - local[1] <= 1 + total[0] / 2, "sample split");
     EXPECT(std::fabs(avg[0] - exact) < 4 * err[0] && err[0] < 2.5e-3, "2-rank plaquette %.6f +- %.6f", avg[0], err[0]);
+  }
+  // ---- site-at-a-time updates (action/action.hh:73-96) and the random_order loop of overrelaxedheatbathsampler.cc:8-31 ------
+  {
+    auto lat = std::make_shared<Lattice2D>(8, 8, CoarsenBoth);
+    auto act = std::make_shared<QuenchedSchwingerAction>(lat, nullptr, RenormalisationNone, 1.0);
+    auto a = std::make_shared<SampleState>(act->sample_size(), 3), b = std::make_shared<SampleState>(act->sample_size(), 3),
+         scratch = std::make_shared<SampleState>(act->sample_size(), 3);
+    act->initialise_state(a);
+    b->data = a->data;
+    // one heat-bath sweep (Philox step 7) = the four colour classes visited link by link with the same step
+    act->sweep(a, scratch, 0, 1, 7);
+    for (int colour = 0; colour < 4; ++colour)
+      for (unsigned l = 0; l < act->sample_size(); ++l) {
+        const unsigned mu = l & 1, v = l >> 1, j = v / 8, i = v % 8;
+        if ((int)(mu == 0 ? (j & 1) : 2 + (i & 1)) != colour) continue;
+        act->set_site_step(7);
+        act->heatbath_update(b, l);
+      }
+    double worst = 0.0;
+    for (unsigned k = 0; k < 3 * act->sample_size(); ++k) worst = std::fmax(worst, std::fabs(std::remainder(a->data[k] - b->data[k], 2 * M_PI)));
+    std::printf(" site-at-a-time heat bath over the four colour classes vs one device sweep: max difference %.2e\n", worst);
+    EXPECT(worst < 1e-12, "per-site updates do not reproduce the sweep: %.3e", worst);
+    // overrelaxation of a single link conserves the action and is an involution
+    const double S0 = act->evaluate(b);
+    const double before = b->data[37];
+    act->overrelaxation_update(b, 37);
+    EXPECT(std::fabs(act->evaluate(b) - S0) < 1e-10 && std::fabs(b->data[37] - before) > 1e-6, "overrelaxation_update(37)");
+    act->overrelaxation_update(b, 37);
+    EXPECT(std::fabs(std::remainder(b->data[37] - before, 2 * M_PI)) < 1e-12, "overrelaxation_update twice is the identity");
+    // random_order = true: the reference's loop (shuffled index set, one local update per index); plaquette of 16 x 16, beta = 1
+    auto lat16 = std::make_shared<Lattice2D>(16, 16, CoarsenBoth);
+    auto act16 = std::make_shared<QuenchedSchwingerAction>(lat16, nullptr, RenormalisationNone, 1.0);
+    OverrelaxedHeatBathParameters hb;
+    hb.n_sweep_heatbath = 1; hb.n_sweep_overrelax = 1; hb.n_burnin = 30; hb.random_order = true; hb.batch = 64;
+    OverrelaxedHeatBathSampler sampler(act16, hb);
+    QoIAvgPlaquette qoi(lat16);
+    auto st = std::make_shared<SampleState>(act16->sample_size(), 64);
+    double sum = 0.0, sum2 = 0.0;
+    const int n_draws = 60;
+    std::vector<double> chain_mean(64, 0.0);
+    for (int d = 0; d < n_draws; ++d) {
+      sampler.draw(st);
+      const std::vector<double> q = qoi.evaluate_batch(st);
+      for (int c = 0; c < 64; ++c) chain_mean[c] += q[c] / n_draws;
+    }
+    for (double m : chain_mean) { sum += m; sum2 += m * m; }
+    const double mean = sum / 64, err = std::sqrt((sum2 / 64 - mean * mean) / 63);
+    std::printf(" random_order sampler (shuffled site-at-a-time sweeps, 64 chains x %d draws): plaquette %.5f +- %.5f (I1/I0 = 0.44639)\n",
+                n_draws, mean, err);
+    EXPECT(std::fabs(mean - 0.446390) < 4 * err + 1e-3 && err < 3e-3, "random_order plaquette %.5f +- %.5f", mean, err);
   }
   // ---- RcclExchange (one rank here: communicator set-up, the all-reduce itself and the tear-down on real RCCL) ------------
   {

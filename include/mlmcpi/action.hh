@@ -34,15 +34,26 @@ public:
   /** action.hh:122-123; chains of a batch get the Philox streams chain0, chain0+1, ... */
   virtual void initialise_state(std::shared_ptr<SampleState> phi_state) const = 0;
 
-  /** action.hh:73-96.  Site-at-a-time updates are the reference's CPU inner loop; on the device
-   *  the unit of work is a whole multicolour sweep (OverrelaxedHeatBathSampler::draw).  Calling the
-   *  per-site form is an error, exactly like calling it on an action that does not implement it. */
-  virtual void heatbath_update(std::shared_ptr<SampleState>, const unsigned int) {
-    fatal("heat bath update not implemented for this action (use OverrelaxedHeatBathSampler::draw, which runs device sweeps)");
+  /** action.hh:73-96: the update of site / link `ell`, on every chain of the state.  Site-at-a-time updates are the
+   *  reference's CPU inner loop; the device's unit of work is a whole multicolour sweep (OverrelaxedHeatBathSampler::draw),
+   *  but a caller that walks an index set itself is served: actions with local updates forward to
+   *  mlmcpi_{path,lattice}_site_updates (one thread per chain, sequential within a chain as in the reference).  Every call
+   *  draws from fresh Philox numbers, like an engine: (site, chain, site_step) with site_step advancing per call. */
+  virtual void heatbath_update(std::shared_ptr<SampleState> phi_state, const unsigned int ell) {
+    site_updates(phi_state, nullptr, 1, ell, true);
   }
-  virtual void overrelaxation_update(std::shared_ptr<SampleState>, const unsigned int) {
-    fatal("overrelaxation update not implemented for this action (use OverrelaxedHeatBathSampler::draw, which runs device sweeps)");
+  virtual void overrelaxation_update(std::shared_ptr<SampleState> phi_state, const unsigned int ell) {
+    site_updates(phi_state, nullptr, 1, ell, false);
   }
+  /** The same for a whole index list in ONE call: d_sites = n site indices in device memory, visited in list order (the
+   *  loops of overrelaxedheatbathsampler.cc:8-31 over a lexicographic or shuffled index set); the sites of a list should
+   *  be distinct -- they share one Philox step, which advances per call. */
+  virtual void site_updates(std::shared_ptr<SampleState>, const uint32_t *, unsigned int, unsigned int, bool heat) {
+    fatal(std::string(heat ? "heat bath" : "overrelaxation") + " update not implemented for this action ");
+  }
+  /** the Philox step the next site-at-a-time call draws from */
+  void set_site_step(uint32_t s) { site_step = s; }
+  uint32_t get_site_step() const { return site_step; }
   /** Does OverrelaxedHeatBathSampler work with this action? */
   virtual bool has_local_updates() const { return false; }
   /** Device sweeps: n_overrelax overrelaxation then n_heatbath heat-bath sweeps. */
@@ -74,6 +85,7 @@ protected:
   std::vector<unsigned int> heatbath_indexset;
   uint64_t seed = 2481317;  // the reference's Schwinger / GFF engine seed, reused as the Philox key
   uint32_t chain0 = 0;
+  uint32_t site_step = 0x40000000u;  // site-at-a-time calls: far from the sweep counters of the samplers
 };
 
 // ---- quantum mechanics: 1-D paths (action/qm/qmaction.hh:79-215) ---------------------------------
@@ -222,6 +234,12 @@ public:
     return 1. / (4. * M_PI * M_PI * m0) * (1. - xi * Sigma_hat(xi, 2));
   }
   bool has_local_updates() const override { return true; }
+  /** rotoraction.cc:20-56 */
+  void site_updates(std::shared_ptr<SampleState> x, const uint32_t *d_sites, unsigned int n, unsigned int ell, bool heat) override {
+    if (x->size() != M_lat) fatal("site update on a path of wrong size.");
+    check(mlmcpi_path_site_updates(&abi, x->device_mutable(), x->batch(), d_sites, n, ell, heat ? 1 : 0, seed, chain0, site_step++,
+                                   nullptr), "path_site_updates");
+  }
   void sweep(std::shared_ptr<SampleState> x, std::shared_ptr<SampleState> scratch, unsigned n_or, unsigned n_hb,
              uint32_t sweep0) override {
     check(mlmcpi_path_sweep_draw(&abi, x->device_mutable(), scratch->device_mutable(), x->batch(), n_or, n_hb, seed,
@@ -264,6 +282,12 @@ public:
   }
   void initialise_state(std::shared_ptr<SampleState> phi) const override {
     check(mlmcpi_lattice_initialise(&abi, phi->device_mutable(), phi->batch(), seed, chain0, nullptr), "lattice_initialise");
+  }
+  /** gffaction.cc:33-42,68-77; quenchedschwingeraction.cc:46-65 */
+  void site_updates(std::shared_ptr<SampleState> phi, const uint32_t *d_sites, unsigned int n, unsigned int ell, bool heat) override {
+    if (phi->size() != sample_size()) fatal("site update on a state of wrong size.");
+    check(mlmcpi_lattice_site_updates(&abi, phi->device_mutable(), phi->batch(), d_sites, n, ell, heat ? 1 : 0, seed, chain0,
+                                      site_step++, nullptr), "lattice_site_updates");
   }
   void sweep(std::shared_ptr<SampleState> phi, std::shared_ptr<SampleState> scratch, unsigned n_or, unsigned n_hb,
              uint32_t sweep0) override {

@@ -6,7 +6,9 @@
 #include <cmath>
 #include <iomanip>
 #include <iostream>
+#include <algorithm>
 #include <memory>
+#include <random>
 #include <typeinfo>
 #include <vector>
 
@@ -169,8 +171,11 @@ struct OverrelaxedHeatBathParameters {
   unsigned int n_sweep_heatbath = 1;
   unsigned int n_sweep_overrelax = 10;
   unsigned int n_burnin = 100;
-  bool random_order = true;  // accepted for compatibility: device sweeps are multicolour, which
-                             // needs no shuffling to be a valid sweep order
+  // overrelaxedheatbathsampler.hh:60-63.  false (the default here; the reference's template says true): the fixed sweep
+  // order -- on the device the multicolour order instead of the reference's lexicographic one (a different, equally
+  // valid fixed order; said once on stderr).  true: the reference's own loop, every sweep over a freshly shuffled index
+  // set, through the site-at-a-time updates (sequential within a chain, chains in parallel): exact semantics, slow.
+  bool random_order = false;
   unsigned int batch = 1;
 };
 
@@ -188,6 +193,18 @@ public:
       : Sampler(), action(action_), n_sweep_heatbath(p.n_sweep_heatbath), n_sweep_overrelax(p.n_sweep_overrelax),
         n_burnin(p.n_burnin), random_order(p.random_order) {
     if (!action->has_local_updates()) fatal("heat bath update not implemented for this action ");
+    if (random_order) {  // overrelaxedheatbathsampler.hh:110-116: the action's index set, or every entry
+      index_map = action->get_heatbath_indexset();
+      if (index_map.empty()) {
+        index_map.resize(action->sample_size());
+        for (unsigned int l = 0; l < index_map.size(); ++l) index_map[l] = l;
+      }
+      d_index = std::make_shared<DeviceVector>((index_map.size() + 1) / 2);  // uint32 entries in 8-byte units
+    } else {
+      static bool said = false;
+      if (!said) std::cerr << "NOTE: random_order = false: device sweeps run in multicolour order, not lexicographically" << std::endl;
+      said = true;
+    }
     phi_state_cur = std::make_shared<SampleState>(action->sample_size(), p.batch);
     action->initialise_state(phi_state_cur);
     std::shared_ptr<SampleState> tmp = std::make_shared<SampleState>(action->sample_size(), p.batch);
@@ -207,7 +224,16 @@ public:
   }
   /** the draw without handing the sample out (callers that read current_state()) */
   bool advance(int qoi_kind = 0, double *d_q = nullptr) {
-    if (qoi_kind && n_sweep_heatbath == 0) return false;
+    if (qoi_kind && (n_sweep_heatbath == 0 || random_order)) return false;
+    if (random_order) {  // overrelaxedheatbathsampler.cc:8-31 as written: shuffle, then one local update per index
+      // (site_updates works in place; a sample handed out earlier keeps its values: SampleState::device_mutable detaches)
+      for (unsigned int s = 0; s < n_sweep_overrelax + n_sweep_heatbath; ++s) {
+        std::shuffle(index_map.begin(), index_map.end(), engine);
+        check(mlmcpi_copy_h2d(d_index->ptr(), index_map.data(), index_map.size() * sizeof(uint32_t), nullptr), "copy_h2d");
+        action->set_site_step(sweep_counter + s);
+        action->site_updates(phi_state_cur, (const uint32_t *)d_index->ptr(), (unsigned int)index_map.size(), 0, s >= n_sweep_overrelax);
+      }
+    } else
     if (n_sweep_overrelax + n_sweep_heatbath > 0) {
       std::shared_ptr<DeviceBuffer> src = phi_state_cur->buffer();
       // `src` is held by phi_state_cur, by this local variable and by the pool if it came from there: one holder more
@@ -245,6 +271,9 @@ protected:
   const std::shared_ptr<Action> action;
   const unsigned int n_sweep_heatbath, n_sweep_overrelax, n_burnin;
   bool random_order;
+  std::vector<unsigned int> index_map;      // random_order: the index set, reshuffled per sweep
+  std::shared_ptr<DeviceVector> d_index;    // ... and its device copy
+  std::mt19937_64 engine{871417};           // overrelaxedheatbathsampler.hh:111
   mutable std::shared_ptr<SampleState> phi_state_cur;
   std::vector<std::shared_ptr<DeviceBuffer>> pool;  // buffers that have carried a sample (some may still be lent out)
   uint32_t sweep_counter = 0;

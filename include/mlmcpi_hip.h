@@ -151,6 +151,16 @@ int mlmcpi_path_sweep_draw_from(const mlmcpi_path_action *act, const double *d_s
                                 uint32_t n_overrelax, uint32_t n_heatbath, uint64_t seed, uint32_t chain0, uint32_t sweep0,
                                 int32_t *result_in, void *stream);
 
+/* Action::heatbath_update / overrelaxation_update(state, l) (action/action.hh:73-96; rotoraction.cc:20-56): the update of
+ * site l for every chain of the batch -- of the n sites d_sites[0 .. n) (device memory) in list order when d_sites is not
+ * NULL, of the single site `site` otherwise.  One thread per chain walks the list, so the updates are sequential within
+ * a chain exactly as in the reference's loops (overrelaxedheatbathsampler.cc:8-31: lexicographic or shuffled index
+ * sets); chains run in parallel.  heat != 0: heat bath, else overrelaxation.  Random numbers: Philox (site, chain,
+ * step), the sweeps' contract, so the sites of one colour visited with a sweep's step reproduce that phase of the sweep.
+ * This is the reference's CPU inner loop kept for callers that walk index sets themselves; the fast path is a sweep. */
+int mlmcpi_path_site_updates(const mlmcpi_path_action *act, double *d_x, uint32_t B, const uint32_t *d_sites, uint32_t n,
+                             uint32_t site, int32_t heat, uint64_t seed, uint32_t chain0, uint32_t step, void *stream);
+
 /* TwoLevelMetropolisStep::draw (montecarlo/twolevelmetropolisstep.cc:35-89) with QMAction::copy_from_{coarse,fine}
  * (action/qm/qmaction.cc:7-24) and the action's conditioned fine action: Gaussian for the harmonic / quartic
  * oscillator (action/qm/gaussianconditionedfineaction.cc:7-43), ExpSin2 for the rotor
@@ -205,6 +215,11 @@ int mlmcpi_lattice_initialise(const mlmcpi_lattice_action *act, double *d_phi, u
 int mlmcpi_lattice_sweep_draw(const mlmcpi_lattice_action *act, double *d_phi, double *d_scratch, uint32_t B,
                               uint32_t n_overrelax, uint32_t n_heatbath, uint64_t seed, uint32_t chain0,
                               uint32_t sweep0, uint32_t fuse, void *stream);
+/* Action::heatbath_update / overrelaxation_update(state, l) on a 2-D action (gffaction.cc:33-42,68-77;
+ * quenchedschwingeraction.cc:46-65): as mlmcpi_path_site_updates; l is a vertex (GFF) or link (Schwinger) index. */
+int mlmcpi_lattice_site_updates(const mlmcpi_lattice_action *act, double *d_state, uint32_t B, const uint32_t *d_sites,
+                                uint32_t n, uint32_t site, int32_t heat, uint64_t seed, uint32_t chain0, uint32_t step,
+                                void *stream);
 /* Same, without the final device-to-device copy: the sweeps ping-pong between d_a (input) and d_b;
  * *result_in_b tells the caller which buffer holds the result (swap your pointers when it is 1). */
 int mlmcpi_lattice_sweep_draw_pingpong(const mlmcpi_lattice_action *act, double *d_a, double *d_b, uint32_t B,

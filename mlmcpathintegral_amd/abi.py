@@ -109,6 +109,8 @@ SIGNATURES = {
     "mlmcpi_test_random": (_i, [_u64, _u32, _u32, _u32, _u32, _u32, _vp, _vp]),
     "mlmcpi_test_expcos": (_i, [_u64, _u32, _u32, _d, _vp, _vp, _u32, _vp, _vp]),
     "mlmcpi_test_expsin2": (_i, [_u64, _u32, _u32, _vp, _u32, _vp, _vp]),
+    "mlmcpi_path_site_updates": (_i, [_vp, _vp, _u32, _vp, _u32, _u32, C.c_int32, _u64, _u32, _u32, _vp]),
+    "mlmcpi_lattice_site_updates": (_i, [_vp, _vp, _u32, _vp, _u32, _u32, C.c_int32, _u64, _u32, _u32, _vp]),
     "mlmcpi_test_vs_draw": (_i, [_u64, _u32, _u32, _d, _vp, _vp, _u32, _vp, _vp]),
     "mlmcpi_vs_table": (_i, [_d, _vp, _vp]),
 }

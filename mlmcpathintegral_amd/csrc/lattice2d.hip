@@ -1365,6 +1365,71 @@ __global__ void stats_accumulate_kernel(double *__restrict__ acc, const double *
   a[4] += v * v * v * v;
 }
 
+// ---- site-at-a-time updates: Action::heatbath_update / overrelaxation_update(state, l), action/action.hh:73-96 -----------
+// gffaction.cc:33-42,68-77; quenchedschwingeraction.cc:25-65.  One thread per chain walks the site list in order (the
+// reference's own sequential semantics: every update sees the ones before it), straight on the state in global memory.
+// Same arithmetic and the same random numbers -- Philox (site, chain, step) -- as the sweep kernels, so the sites of a
+// colour class visited in any order with the sweep's step reproduce that colour phase of the sweep.
+template <bool SCHW>
+__global__ void __launch_bounds__(64)
+    lattice_site_update_kernel(uint32_t Mt, uint32_t Mx, double coupling, double *__restrict__ state, uint32_t B,
+                               const uint32_t *__restrict__ sites, uint32_t n, uint32_t single, int heat, RngKey key0,
+                               const uint32_t *__restrict__ vs_table) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  RngKey key = key0;
+  key.chain += b;
+  if (SCHW) {
+    double *th = state + (size_t)b * 2 * Mt * Mx;
+    auto link = [&](uint32_t i, uint32_t j, uint32_t mu) -> double & { return th[2 * (Mt * j + i) + mu]; };
+    const bool step = 2. * coupling <= kVsKappaMax;
+    const VsTable tab{(const uint8_t *)vs_table, (const float *)((const uint8_t *)vs_table + kVsClasses * kVsSel)};
+    for (uint32_t q = 0; q < n; ++q) {
+      const uint32_t l = sites ? sites[q] : single;
+      const uint32_t mu = l & 1u, v = l >> 1, j = v / Mt, i = v - j * Mt;
+      const uint32_t ip = i + 1 == Mt ? 0 : i + 1, im = i == 0 ? Mt - 1 : i - 1, jp = j + 1 == Mx ? 0 : j + 1, jm = j == 0 ? Mx - 1 : j - 1;
+      double tp, tm;  // staple sums, unwrapped (quenchedschwingeraction.cc:25-43; same sums as schwinger_sweep_kernel)
+      if (mu == 0) {
+        tp = link(i, jp, 0) + link(i, j, 1) - link(ip, j, 1);
+        tm = link(i, jm, 0) + link(ip, jm, 1) - link(i, jm, 1);
+      } else {
+        tp = link(i, j, 0) + link(ip, j, 1) - link(i, jp, 0);
+        tm = link(im, jp, 0) + link(im, j, 1) - link(im, j, 0);
+      }
+      double &x = th[l];
+      if (!heat) {
+        x = mod_2pi_fast((tp + tm) - x);
+      } else if (step) {
+        x = vs_draw(key, l, 2. * coupling, tp, tm, tab);
+      } else {
+        double tau, centre;
+        expcos_params(coupling, tp, tm, tau, centre);
+        x = mod_2pi_fast(vonmises_draw(key, l, tau) + centre);
+      }
+    }
+  } else {
+    double *phi = state + (size_t)b * Mt * Mx;
+    const double inv_kappa = 1. / (4. + coupling), two_over_kappa = 2. / (4. + coupling), sigma = 1. / sqrt(4. + coupling);
+    for (uint32_t q = 0; q < n; ++q) {
+      const uint32_t l = sites ? sites[q] : single;
+      const uint32_t j = l / Mt, i = l - j * Mt;
+      const uint32_t ip = i + 1 == Mt ? 0 : i + 1, im = i == 0 ? Mt - 1 : i - 1, jp = j + 1 == Mx ? 0 : j + 1, jm = j == 0 ? Mx - 1 : j - 1;
+      double Delta = 0.0;  // the order of the reference's neighbour table: +i, -i, +j, -j
+      Delta += phi[Mt * j + ip];
+      Delta += phi[Mt * j + im];
+      Delta += phi[Mt * jp + i];
+      Delta += phi[Mt * jm + i];
+      if (!heat) {
+        phi[l] = fma(two_over_kappa, Delta, -phi[l]);
+      } else {
+        double n0, n1;
+        rng_normals(key, l >> 1, P_GFF_NORMAL, 0, n0, n1);
+        phi[l] = fma(Delta, inv_kappa, sigma * ((l & 1u) ? n1 : n0));
+      }
+    }
+  }
+}
+
 // ---- host dispatch ----------------------------------------------------------------------------------------
 static int check_lattice_dims(const mlmcpi_lattice_action *act) {
   if (!act) return fail(MLMCPI_ERR_INVALID, "action is NULL");
@@ -1869,6 +1934,34 @@ int mlmcpi_qoi_2d_susceptibility(const double *d_theta, uint32_t Mt, uint32_t Mx
                                  void *stream) {
   MLMCPI_REQUIRE(d_theta && d_out && B > 0 && Mt > 1 && Mx > 1, "bad arguments");
   return launch_lattice_reduce<L_CHARGE>(Mt, Mx, 0.0, d_theta, B, 1.0, d_out, as_stream(stream));
+}
+
+int mlmcpi_lattice_site_updates(const mlmcpi_lattice_action *act, double *d_state, uint32_t B, const uint32_t *d_sites,
+                                uint32_t n, uint32_t site, int32_t heat, uint64_t seed, uint32_t chain0, uint32_t step,
+                                void *stream) {
+  if (int rc = check_lattice(act)) return rc;
+  MLMCPI_REQUIRE(d_state && B > 0, "bad arguments");
+  uint32_t size = 0;
+  mlmcpi_lattice_state_size(act, &size);
+  if (!d_sites) {
+    MLMCPI_REQUIRE(site < size, "site %u out of range (%u entries)", site, size);
+    n = 1;
+  }
+  if (n == 0) return MLMCPI_OK;
+  const bool schw = act->kind == MLMCPI_SCHWINGER;
+  const uint32_t *vs_table = nullptr;
+  if (schw && heat && 2. * act->beta <= kVsKappaMax)
+    if (int rc = vs_table_device(2. * act->beta, &vs_table)) return rc;
+  const dim3 grid((B + 63) / 64), block(64);
+  const RngKey key = make_key(seed, chain0, step);
+  if (schw)
+    hipLaunchKernelGGL((lattice_site_update_kernel<true>), grid, block, 0, as_stream(stream), act->Mt, act->Mx, act->beta, d_state, B,
+                       d_sites, n, site, (int)heat, key, vs_table);
+  else
+    hipLaunchKernelGGL((lattice_site_update_kernel<false>), grid, block, 0, as_stream(stream), act->Mt, act->Mx, gff_mu2(*act), d_state,
+                       B, d_sites, n, site, (int)heat, key, vs_table);
+  MLMCPI_LAUNCH_CHECK("lattice_site_update_kernel");
+  return MLMCPI_OK;
 }
 
 int mlmcpi_stats_accumulate(double *d_acc, const double *d_q, uint32_t B, void *stream) {

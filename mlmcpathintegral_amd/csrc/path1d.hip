@@ -559,6 +559,35 @@ __global__ void __launch_bounds__(256)
   for (uint32_t k = threadIdx.x; k < olen; k += blockDim.x) xout[o0 + k] = buf[halo + k];
 }
 
+// Site-at-a-time rotor updates (rotoraction.cc:20-56 through Action::heatbath_update / overrelaxation_update,
+// action/action.hh:73-96): one thread per chain walks the site list in order, on the state in global memory; arithmetic
+// and random numbers of rotor_sweep_kernel.
+__global__ void __launch_bounds__(64)
+    rotor_site_update_kernel(PathP P, double *__restrict__ x_all, uint32_t B, const uint32_t *__restrict__ sites, uint32_t n,
+                             uint32_t single, int heat, RngKey key0, const uint32_t *__restrict__ vs_table) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  RngKey key = key0;
+  key.chain += b;
+  double *x = x_all + (size_t)b * P.M;
+  const double sig_scale = 2.0 * P.m0 / P.a;
+  const bool step = sig_scale <= kVsKappaMax;
+  const VsTable tab{(const uint8_t *)vs_table, (const float *)((const uint8_t *)vs_table + kVsClasses * kVsSel)};
+  for (uint32_t q = 0; q < n; ++q) {
+    const uint32_t l = sites ? sites[q] : single;
+    const double xm = x[l == 0 ? P.M - 1 : l - 1], xp = x[l + 1 == P.M ? 0 : l + 1];
+    if (!heat) {
+      x[l] = mod_2pi_fast(xm + xp - x[l]);
+    } else if (step) {
+      x[l] = vs_draw(key, l, sig_scale, xp, xm, tab);
+    } else {
+      const double c = cospi_unit(fmin(fabs(xp - xm) * (0.5 / kPi), 1.0));
+      const double centre = 0.5 * (xp + xm) + (c < 0.0 ? kPi : 0.0);
+      x[l] = mod_2pi_fast(vonmises_draw(key, l, sig_scale * fabs(c)) + centre);
+    }
+  }
+}
+
 // ---- two-level Metropolis step (montecarlo/twolevelmetropolisstep.cc:35-89) ----------------------------------
 // Conditioned-action quantities of the Gaussian fill-in (action/qm/gaussianconditionedfineaction.cc:7-43):
 // HO  harmonicoscillatoraction.hh:163-189: W'' = 2 m0/a + a m0 mu2, x0 = (x- + x+) / (2 + a^2 mu2)
@@ -942,6 +971,27 @@ static int path_sweep_impl(const mlmcpi_path_action *act, double *d_x, double *d
     *result_in = total == 0 ? -1 : (src == d_w0 ? 0 : 1);
   else if (src != d_x)
     MLMCPI_HIP_TRY(hipMemcpyAsync(d_x, src, (size_t)B * P.M * 8, hipMemcpyDeviceToDevice, st));
+  return MLMCPI_OK;
+}
+
+int mlmcpi_path_site_updates(const mlmcpi_path_action *act, double *d_x, uint32_t B, const uint32_t *d_sites, uint32_t n,
+                             uint32_t site, int32_t heat, uint64_t seed, uint32_t chain0, uint32_t step, void *stream) {
+  if (int rc = check_action(act)) return rc;
+  if (act->kind != MLMCPI_ROTOR)
+    return fail(MLMCPI_ERR_UNSUPPORTED, "heat bath / overrelaxation update not implemented for this action");
+  MLMCPI_REQUIRE(d_x && B > 0, "bad arguments");
+  if (!d_sites) {
+    MLMCPI_REQUIRE(site < act->M, "site %u out of range (%u sites)", site, act->M);
+    n = 1;
+  }
+  if (n == 0) return MLMCPI_OK;
+  const PathP P = make_params(*act);
+  const uint32_t *vs_table = nullptr;
+  if (heat && 2.0 * P.m0 / P.a <= kVsKappaMax)
+    if (int rc = vs_table_device(2.0 * P.m0 / P.a, &vs_table)) return rc;
+  hipLaunchKernelGGL(rotor_site_update_kernel, dim3((B + 63) / 64), dim3(64), 0, as_stream(stream), P, d_x, B, d_sites, n, site,
+                     (int)heat, make_key(seed, chain0, step), vs_table);
+  MLMCPI_LAUNCH_CHECK("rotor_site_update_kernel");
   return MLMCPI_OK;
 }
 

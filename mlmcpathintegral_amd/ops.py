@@ -217,6 +217,27 @@ def path_sweep_draw(act, x, scratch, n_overrelax, n_heatbath, seed, chain0, swee
              chain0, sweep0, _stream())
 
 
+def _site_args(x, sites):
+    """(d_sites, n, single) for the site-update entry points: an int, or a uint32 / int32 device tensor of site indices"""
+    if isinstance(sites, int):
+        return None, 1, sites
+    assert sites.is_cuda and sites.dtype in (torch.int32, torch.uint32) and sites.is_contiguous()
+    return C.c_void_p(sites.data_ptr()), sites.numel(), 0
+
+
+def path_site_updates(act, x, sites, heat, seed, chain0, step):
+    """Action::heatbath_update / overrelaxation_update(state, l) (rotor): the sites in order, all chains of x in place"""
+    _check_state(x, act.M)
+    d, n, single = _site_args(x, sites)
+    abi.call("mlmcpi_path_site_updates", C.byref(act), _p(x), x.shape[0], d, n, single, int(bool(heat)), seed, chain0, step, _stream())
+
+
+def lattice_site_updates(act, x, sites, heat, seed, chain0, step):
+    _check_state(x, lattice_size(act))
+    d, n, single = _site_args(x, sites)
+    abi.call("mlmcpi_lattice_site_updates", C.byref(act), _p(x), x.shape[0], d, n, single, int(bool(heat)), seed, chain0, step, _stream())
+
+
 # ---- 2-D lattices ---------------------------------------------------------------------------------
 def lattice_size(act):
     n = C.c_uint32(0)

@@ -76,6 +76,7 @@ _SIGS = {
     "orc_heatbath_draw": (None, [_vp, _dp]),
     "orc_heatbath_set_state": (None, [_vp, _dp]),
     "orc_dev_sweep": (None, [_vp, _dp, _i, _u64, _u32, _u32]),
+    "orc_dev_site_update": (None, [_vp, _dp, _u32, _i, _u64, _u32, _u32]),
     "orc_dev_hmc_trajectory": (_i, [_vp, _dp, _u32, _d, _u64, _u32, _u32, _dp, _dp]),
     "orc_dev_initialise": (None, [_vp, _dp, _u64, _u32]),
     "orc_dev_twolevel_draw": (_i, [_vp, _vp, _dp, _dp, _u64, _u32, _u32, _dp]),
@@ -173,6 +174,9 @@ class Action:
 
     def dev_sweep(self, x, heatbath, seed, chain, step):
         lib().orc_dev_sweep(self.h, x, int(heatbath), seed, chain, step)
+
+    def dev_site_update(self, x, site, heatbath, seed, chain, step):
+        lib().orc_dev_site_update(self.h, x, int(site), int(heatbath), seed, chain, step)
 
     def dev_hmc_trajectory(self, x, nt, dt, seed, chain, step):
         en = np.zeros(4)

@@ -671,28 +671,32 @@ void rotor_dev_update(const ActionO &A, double *x, unsigned l, bool heat, const 
   x[l] = wrap_2pi(centre + src.between(l, xp, xm, kappa));
 }
 
+// Action::heatbath_update / overrelaxation_update(state, l) in device order (Philox stream of site l): the unit the
+// sweeps are made of, and what the device's site-at-a-time entry points compute
+void dev_site_update(const ActionO &A, double *x, unsigned l, bool heat, const DevRng &rng) {
+  if (A.kind == ROTOR) {
+    rotor_dev_update(A, x, l, heat, rng);
+    return;
+  }
+  if (!heat) {
+    A.overrelax(x, l);
+    return;
+  }
+  DevAngles src{rng, A.kind == SCHWINGER ? 2.0 * A.beta : 1e300};
+  double gn = 0.0;
+  if (A.kind == GFF) {
+    double n0, n1;
+    rng.normals(l >> 1, P_GFF_NORMAL, 0, n0, n1);
+    gn = (l & 1) ? n1 : n0;
+  }
+  A.heatbath(x, l, src, gn);
+}
+
 void dev_sweep(const ActionO &A, double *x, bool heat, const DevRng &rng) {
   unsigned n = A.size();
   for (int c = 0; c < A.n_colours(); ++c)
-    for (unsigned l = 0; l < n; ++l) {
-      if (A.colour_of(l) != c) continue;
-      if (A.kind == ROTOR) {
-        rotor_dev_update(A, x, l, heat, rng);
-        continue;
-      }
-      if (!heat) {
-        A.overrelax(x, l);
-      } else {
-        DevAngles src{rng, A.kind == SCHWINGER ? 2.0 * A.beta : 1e300};
-        double gn = 0.0;
-        if (A.kind == GFF) {
-          double n0, n1;
-          rng.normals(l >> 1, P_GFF_NORMAL, 0, n0, n1);
-          gn = (l & 1) ? n1 : n0;
-        }
-        A.heatbath(x, l, src, gn);
-      }
-    }
+    for (unsigned l = 0; l < n; ++l)
+      if (A.colour_of(l) == c) dev_site_update(A, x, l, heat, rng);
 }
 
 // energies[0..3] = S(x_cur), T(p_0), S(x_trial), T(p_end); returns accept flag and leaves the
@@ -1927,6 +1931,10 @@ void orc_heatbath_set_state(void *h, const double *x) { HeatBathO *s = (HeatBath
 void orc_dev_sweep(void *action, double *x, int heatbath, uint64_t seed, uint32_t chain, uint32_t step) {
   DevRng r{(uint32_t)seed, (uint32_t)(seed >> 32), chain, step};
   dev_sweep(*(ActionO *)action, x, heatbath != 0, r);
+}
+void orc_dev_site_update(void *action, double *x, unsigned l, int heatbath, uint64_t seed, uint32_t chain, uint32_t step) {
+  DevRng r{(uint32_t)seed, (uint32_t)(seed >> 32), chain, step};
+  dev_site_update(*(ActionO *)action, x, l, heatbath != 0, r);
 }
 int orc_dev_hmc_trajectory(void *action, double *x, unsigned nt, double dt, uint64_t seed, uint32_t chain,
                            uint32_t step, double *energies, double *dH) {

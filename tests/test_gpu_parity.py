@@ -544,6 +544,63 @@ def test_heatbath_retry_pool_with_several_passes_per_phase(gpu_ops, tile):
         assert torch.equal(want, got), f"tile {tile}, beta {beta}: heat-bath result depends on the tile geometry"
 
 
+@pytest.mark.parametrize("kind,Mt,Mx,kw", [("schwinger", 8, 6, dict(beta=1.0)), ("schwinger", 6, 6, dict(beta=3.0)),
+                                           ("gff", 8, 8, dict(mass=3.0)), ("rotor", 32, 0, dict(T_final=4.0, m0=0.25)),
+                                           ("rotor", 16, 0, dict(T_final=1.0, m0=1.0))])
+def test_site_at_a_time_updates_match_oracle(gpu_ops, orc, kind, Mt, Mx, kw):
+    """Action::heatbath_update / overrelaxation_update(state, l) (action/action.hh:73-96) through
+    mlmcpi_{path,lattice}_site_updates: a shuffled index list walked sequentially per chain -- the loop of
+    overrelaxedheatbathsampler.cc:8-31 with random_order -- against the oracle's single-site updates applied in the
+    same order; both samplers (beta = 1: tabulated step envelope, beta = 3 / m0/a = 16: wrapped Cauchy)."""
+    from mlmcpathintegral_amd import abi
+    B = 3
+    if kind == "rotor":
+        act = abi.path_action(abi.ROTOR, Mt, kw["T_final"], kw["m0"])
+        A = orc.Action(orc.ROTOR, M=Mt, T_final=kw["T_final"], m0=kw["m0"])
+        update = gpu_ops.path_site_updates
+    else:
+        act, A = make_lattice(orc, kind, Mt, Mx, **kw)
+        update = gpu_ops.lattice_site_updates
+    n = A.size
+    rng = np.random.default_rng(n)
+    x0 = rng.uniform(-np.pi, np.pi, (B, n))
+    for heat in (False, True):
+        sites = rng.permutation(n).astype(np.uint32)
+        xd = dev(x0)
+        update(act, xd, torch.from_numpy(sites.view(np.int32)).cuda(), heat, SEED, 5, 21)
+        update(act, xd, int(sites[3]), heat, SEED, 5, 22)   # the single-site form
+        want = x0.copy()
+        for b in range(B):
+            for l in sites:
+                A.dev_site_update(want[b], l, heat, SEED, 5 + b, 21)
+            A.dev_site_update(want[b], sites[3], heat, SEED, 5 + b, 22)
+        got = xd.cpu().numpy()
+        if kind == "gff":
+            assert_close(got, want, tol=1e-11, what=f"site updates heat={heat}")
+        else:
+            assert_angles_close(got, want, tol=HB_TOL[2] if heat else 1e-12, what=f"site updates heat={heat}")
+
+
+def test_site_updates_over_the_colour_classes_equal_a_sweep(gpu_ops):
+    """The random-number contract of the site-at-a-time entry points: Philox (site, chain, step), as in the sweeps -- the
+    links of the four colour classes visited one class after the other, with the sweep's step, ARE the sweep."""
+    from mlmcpathintegral_amd import abi
+    Mt = 64
+    act = abi.lattice_action(4, Mt, Mt, beta=1.0)
+    x = gpu_ops.lattice_initialise(act, 2, SEED, 0)
+    for heat in (False, True):
+        a, b = x.clone(), x.clone()
+        gpu_ops.lattice_sweep_draw(act, a, torch.empty_like(a), 0 if heat else 1, 1 if heat else 0, SEED, 0, 9, fuse=1)
+        l = np.arange(2 * Mt * Mt)
+        mu, v = l & 1, l >> 1
+        colour = np.where(mu == 0, (v // Mt) & 1, 2 + ((v % Mt) & 1))
+        order = np.concatenate([l[colour == c] for c in range(4)]).astype(np.int32)
+        gpu_ops.lattice_site_updates(act, b, torch.from_numpy(order).cuda(), heat, SEED, 0, 9)
+        d = (a - b).abs()
+        d = torch.minimum(d, (d - 2 * np.pi).abs())
+        assert float(d.max()) < 1e-12, f"heat={heat}: {float(d.max())}"
+
+
 @pytest.mark.parametrize("rt,rx", [(2, 2), (2, 1), (1, 2)])
 def test_level_transfers_match_oracle(gpu_ops, orc, golden, rt, rx):
     """Action::copy_from_fine / copy_from_coarse (Schwinger, GFF, 1-D paths) against the oracle, plus the

@@ -85,6 +85,45 @@ def test_driver_throughput_mode_on_gpu():
 
 
 @pytest.mark.gpu
+def test_driver_throughput_at_the_headline_shape_matches_the_python_driven_loop():
+    """the C++ path's rate is a record, not a claim.  host/driver at 1024^2 x 32 chains against the
+    same loop driven through ctypes in this session (one ABI call for draw + QoI, one for record_sample): within 7 %
+    (the two run minutes apart on a chip whose clock moves by a few per cent), and both see a thermalised plaquette."""
+    import json
+    import time
+    import torch
+    from mlmcpathintegral_amd import abi, ops
+    if not os.path.exists(EXE):
+        build()
+    r = subprocess.run([os.path.join(ROOT, "host", "driver"), "--method", "throughput", "--action", "schwinger", "--Mt_lat", "1024",
+                        "--sampler", "heatbath", "--batch", "32", "--n_samples", "40", "--n_burnin", "30"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    act = abi.lattice_action(abi.SCHWINGER, 1024, 1024, beta=1.0)
+    x = ops.lattice_initialise(act, 32, 2481317, 0)
+    w = torch.empty_like(x)
+    acc = torch.zeros((32, 5), dtype=torch.float64, device="cuda")
+    sweep = 0
+    def step():
+        nonlocal x, w, sweep
+        x, w, q = ops.lattice_sweep_draw_qoi(act, x, w, x, 10, 1, 2481317, 0, sweep, 1, 0)
+        ops.stats_accumulate(acc, q)
+        sweep += 11
+    for _ in range(35):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(40):
+        step()
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / 40
+    print("C++ driver %.4f ms per sample, ctypes-driven %.4f ms" % (line["ms_per_sample"], ms))
+    assert abs(line["ms_per_sample"] / ms - 1.0) < 0.07, (line, ms)
+    assert 0.44 < line["qoi_mean"] < 0.452
+
+
+@pytest.mark.gpu
 def test_comm_single_rank_on_gpu():
     """libmlmcpi_rccl.so through ctypes with the RCCL runtime of this PyTorch process: communicator of one rank, device
     and host all-reduce (the N > 1 path of bench.py uses the same calls; one GPU per rank is all RCCL allows)."""
