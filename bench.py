@@ -29,11 +29,11 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0    # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy ceiling 6290 GB/s
 VALU_PEAK_WAVE_INSTS = 256 * 4 * 2.4e9 / 4   # 256 CUs x 4 SIMDs, one fp64-class wave64 instruction per 4 cycles, 2.4 GHz
 
-WORKLOADS = ["schwinger", "gff", "rotor_hmc", "quartic_hmc", "ho_hmc", "quartic_mlmc", "rotor_sweep"]
+WORKLOADS = ["schwinger", "gff", "rotor_hmc", "quartic_hmc", "ho_hmc", "quartic_mlmc", "quartic_mlmc_hier", "rotor_sweep"]
 DEFAULT_SIZE = {"schwinger": 1024, "gff": 512, "rotor_hmc": 65536, "quartic_hmc": 32768, "ho_hmc": 128,
-                "quartic_mlmc": 32768, "rotor_sweep": 65536}
+                "quartic_mlmc": 32768, "quartic_mlmc_hier": 32768, "rotor_sweep": 65536}
 DEFAULT_CHAINS = {"schwinger": 32, "gff": 1024, "rotor_hmc": 1024, "quartic_hmc": 2048, "ho_hmc": 8192,
-                  "quartic_mlmc": 512, "rotor_sweep": 1024}
+                  "quartic_mlmc": 512, "quartic_mlmc_hier": 512, "rotor_sweep": 1024}
 
 
 def parse():
@@ -59,6 +59,8 @@ def parse():
     ap.add_argument("--no-extra-points", action="store_true",
                     help="skip the single-chain and 128-chain side measurements of the default workload")
     ap.add_argument("--cpu-draws", type=int, default=0)
+    ap.add_argument("--epsilon", type=float, default=2e-3, help="quartic_mlmc_hier: tolerance of the untimed run to convergence")
+    ap.add_argument("--t-final", type=float, default=0.0, help="quartic_mlmc_hier: T_final (default size / 8, i.e. a = 0.125 on the finest level)")
     return ap.parse_args()
 
 
@@ -106,7 +108,7 @@ def pmc_entry(section, **match):
 def cpu_baseline(a, size):
     """Reference-order oracle on the host cores; run BEFORE this process touches the GPU."""
     wl = {"schwinger": "schwinger", "gff": "gff", "rotor_hmc": "rotor", "quartic_hmc": "quartic", "ho_hmc": "harmonic",
-          "quartic_mlmc": "quartic", "rotor_sweep": "rotor_sweep"}[a.workload]
+          "quartic_mlmc": "quartic", "quartic_mlmc_hier": "quartic", "rotor_sweep": "rotor_sweep"}[a.workload]
     draws = a.cpu_draws or {"schwinger": 5, "gff": 40, "rotor": 30, "quartic": 200, "harmonic": 100000, "rotor_sweep": 150}[wl]
     dt = a.dt or {"rotor": 0.05, "harmonic": 0.0558}.get(wl, 0.02)
     cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--workload", wl, "--size", str(size),
@@ -373,7 +375,8 @@ def main():
         est = mlmc.PathMLMC(abi.QUARTIC, size, size / 8.0, n_level, B, nt=a.nt, dt0=a.dt or 0.02, seed=a.seed, rank=rank,
                             world=world, n_sub=2, params=dict(lam=1.0, x0=1.0))
         est.exchange = exchange  # the level-table all-reduce goes through the same communicator
-        est.thermalise(64)
+        est.thermalise(400)      # (r02 ran 64 trajectories here: the chains were still relaxing and the estimate read 0.4575
+                                 # where the thermalised value is 0.598 -- see quartic_mlmc_hier's single-level reference)
         units_per_step = 0  # site-steps per step over all ranks: HMC of the feeding level + two-level pass
         for l in range(n_level):
             src = l if l == n_level - 1 else l + 1
@@ -385,6 +388,35 @@ def main():
                 e0, e1 = ev(), ev()
                 e0.record()
             est.pass_(1)  # sampler draws, two-level steps, QoIs and record_sample of every owned instance
+            if record:
+                e1.record()
+                events.append((e0, e1))
+        acc_of = lambda: est.packed_finest()
+    elif a.workload == "quartic_mlmc_hier":
+        # BASELINE configs[4] AS THE REFERENCE RUNS IT: sampler = 'hierarchical' -- HMC only on the
+        # coarsest level (M_lat = 2048, nt = 100, dt = 0.095), two-level steps up (sampler/hierarchicalsampler.cc:55-81),
+        # the coarse sampler of every level sub-sampled ceil(2 tau_int) draws apart (montecarlomultilevel.cc:170-190).
+        # A step = one Y sample per chain of every level instance of this rank.
+        from mlmcpathintegral_amd import mlmc
+        n_level = 5
+        T_hier = a.t_final or size / 8.0
+        est = mlmc.PathMLMC(abi.QUARTIC, size, T_hier, n_level, B, nt=a.nt, seed=a.seed, rank=rank, world=world,
+                            params=dict(lam=1.0, x0=1.0), hierarchical=True, dt_coarse=a.dt or 0.095)
+        est.exchange = exchange
+        est.thermalise(400)   # untimed: every chain starts from an equilibrium sample of its level (direct HMC, once)
+        sub = {l: lv.n_sub for l, lv in est.levels.items()}
+        # site-steps per step of THIS rank's instances (HMC force evaluations on the coarsest level + two-level passes)
+        units_rank = sum((lv.n_sub * lv.sampler.cost + (0 if lv.coarsest else lv.step.fine.M)) * lv.B for lv in est.levels.values())
+        units_per_step = units_rank
+        if world > 1:
+            units_per_step = sum(exchange.allreduce_sum_host([float(units_rank)]))
+        fuse = 1
+
+        def step(record):
+            if record:
+                e0, e1 = ev(), ev()
+                e0.record()
+            est.pass_(1)
             if record:
                 e1.record()
                 events.append((e0, e1))
@@ -453,12 +485,38 @@ def main():
         elapsed = max(red[packed.numel():])
         collective = (f"mlmcpi_comm_allreduce_sum_host_f64 (libmlmcpi_rccl.so: ncclAllReduce, {rccl['ranks']} ranks)"
                       if backend == "nccl" else f"torch.distributed all_reduce ({backend} rehearsal, {rccl['ranks']} ranks)")
+    hier_run = None
+    if a.workload == "quartic_mlmc_hier":
+        # untimed continuation to the tolerance (or to a bound on the work): wall time to epsilon as the reference reports it
+        t_eps, extra_passes = time.perf_counter(), 0
+        mlmc_q, mlmc_e, mlmc_t = est.estimate()
+        while mlmc_e > a.epsilon and extra_passes < 40:
+            est.pass_(4)
+            extra_passes += 4
+            mlmc_q, mlmc_e, mlmc_t = est.estimate()
+        torch.cuda.synchronize()
+        hier_run = {"epsilon": a.epsilon, "reached": bool(mlmc_e <= a.epsilon), "extra_passes": extra_passes,
+                    "seconds_after_timed_steps": time.perf_counter() - t_eps,
+                    "samples_per_chain_and_level": a.warmup + a.steps + extra_passes}
+        if rank == 0:  # single-level HMC on the finest lattice (untimed): what the telescoping sum must reproduce
+            fine_act = abi.path_action(abi.QUARTIC, size, T_hier, 1.0, 1.0, 1.0, 1.0)
+            xf = ops.path_initialise(fine_act, B, a.seed + 99, 0)
+            hf = ops.PathHMC(fine_act, B, a.nt, 0.02, seed=a.seed + 99)
+            ops.hmc_thermalise(hf, xf, 400)
+            vals = []
+            for _ in range(60):
+                hf.draw(xf)
+                vals.append(ops.qoi_xsquared(xf))
+            cm = torch.stack(vals).mean(dim=0)
+            ref_m, ref_e = float(cm.mean()), float(cm.std(unbiased=True)) / (B ** 0.5)
+            hier_run["single_level_fine_hmc"] = {"mean": ref_m, "error": ref_e, "chains": B, "draws": 60,
+                                                 "z": (mlmc_q - ref_m) / max(1e-300, (mlmc_e ** 2 + ref_e ** 2) ** 0.5)}
     if a.workload == "quartic_mlmc":
         mlmc_q, mlmc_e, mlmc_t = est.estimate()  # the level-table exchange, through est.exchange when world > 1
     qoi_mean = float(packed[1] / packed[0]) if float(packed[0]) > 0 else None
 
     if rank == 0:
-        total_units = units_per_step * a.steps * (1 if a.workload == "quartic_mlmc" else world)
+        total_units = units_per_step * a.steps * (1 if a.workload.startswith("quartic_mlmc") else world)
         ms = lambda pairs: sum(p[0].elapsed_time(p[1]) for p in pairs)
         step_ms = 1e3 * elapsed / a.steps
         result = {
@@ -506,6 +564,27 @@ def main():
             floor = 16.0 * est.state_entries() * 2  # every owned state read and written once per trajectory, 2 per step
             result["roofline"] = register_resident_roofline(
                 "hmc_trajectory_kernel (the level samplers; > 99 % of the site-steps)", launch_ms, floor,
+                32.0 * units_per_step / world, pmc_entry("kernels_valu_busy", workload=a.workload, size=size, chains=B),
+                "one step of all level instances of rank 0")
+        elif a.workload == "quartic_mlmc_hier":
+            result["scaling"] = "strong"
+            result["config"] = {"workload": f"quartic MLMC as the reference runs it: 5 levels, finest M_lat={size}, a={T_hier / size:g}, "
+                                            f"sampler='hierarchical' (HMC nt={a.nt}, dt={a.dt or 0.095} on the coarsest level "
+                                            f"M_lat={size >> 4} only, two-level steps up), coarse samplers sub-sampled "
+                                            "ceil(2 tau_int) draws apart; one Y sample per chain and level per step",
+                                "chains_per_level": B, "instances_on_rank0": est.describe(), "sub_sampling_rank0": {str(k): v for k, v in sub.items()},
+                                "parallelism": f"(level, chain) instances cut into {world} equal-cost shares; per pass one "
+                                               "all-reduce of the [5, 7] level table"}
+            result["mlmc"] = {"estimate": mlmc_q, "error": mlmc_e, "level_means": mlmc_t[:, 1].tolist(),
+                              "level_variances": mlmc_t[:, 2].tolist(), "level_tau_int": mlmc_t[:, 3].tolist(),
+                              "acceptance_rank0": {str(k): v for k, v in est.p_accept().items()},
+                              "hierarchical_acceptance_rank0": {str(l): {str(k): round(v, 4) for k, v in lv.sampler.p_accept().items()}
+                                                                for l, lv in est.levels.items()},
+                              "run_to_epsilon": hier_run}
+            launch_ms = ms(events) / a.steps
+            floor = 16.0 * sum(lv.n_sub * lv.B * lv.sampler.acts[-1].M for lv in est.levels.values())  # coarsest states, once per trajectory
+            result["roofline"] = register_resident_roofline(
+                "hmc_chain_kernel (coarsest-level HMC of every hierarchical draw; > 95 % of the site-steps)", launch_ms, floor,
                 32.0 * units_per_step / world, pmc_entry("kernels_valu_busy", workload=a.workload, size=size, chains=B),
                 "one step of all level instances of rank 0")
         else:

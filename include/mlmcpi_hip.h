@@ -177,6 +177,14 @@ int mlmcpi_path_twolevel_draw(const mlmcpi_path_action *fine, const mlmcpi_path_
                               double *d_theta, uint32_t B, uint64_t seed, uint32_t chain0, uint32_t step, void *d_work,
                               int32_t *d_accept, double *d_terms, void *stream);
 
+/* The same with a per-chain mask (d_mask may be NULL = all ones; d_mask may be the d_accept of the level below): chains
+ * with d_mask[b] == 0 are left alone -- d_accept[b] = 0, d_theta[b] untouched, no random numbers of the step consumed for
+ * them.  This is the `if (not accept) break` of HierarchicalSampler::draw (sampler/hierarchicalsampler.cc:62-76) for a
+ * batch of chains: a chain whose move was rejected on a coarser level does not move on the finer ones. */
+int mlmcpi_path_twolevel_draw_masked(const mlmcpi_path_action *fine, const mlmcpi_path_action *coarse, const double *d_x_coarse,
+                                     double *d_theta, uint32_t B, uint64_t seed, uint32_t chain0, uint32_t step, void *d_work,
+                                     const int32_t *d_mask, int32_t *d_accept, double *d_terms, void *stream);
+
 /* QMAction::copy_from_fine / copy_from_coarse (action/qm/qmaction.cc:7-24): coarse[j] <-> fine[2j]; the odd
  * fine sites are left untouched.  d_fine [B*2*M_coarse], d_coarse [B*M_coarse]. */
 int mlmcpi_path_copy_from_fine(const double *d_fine, double *d_coarse, uint32_t M_coarse, uint32_t B, void *stream);

@@ -66,6 +66,7 @@ SIGNATURES = {
     "mlmcpi_path_sweep_draw_from": (_i, [_PA, _vp, _vp, _vp, _u32, _u32, _u32, _u64, _u32, _u32, _vp, _vp]),
     "mlmcpi_path_twolevel_workspace_bytes": (_i, [_PA, _u32, C.POINTER(_sz)]),
     "mlmcpi_path_twolevel_draw": (_i, [_PA, _PA, _vp, _vp, _u32, _u64, _u32, _u32, _vp, _vp, _vp, _vp]),
+    "mlmcpi_path_twolevel_draw_masked": (_i, [_PA, _PA, _vp, _vp, _u32, _u64, _u32, _u32, _vp, _vp, _vp, _vp, _vp]),
     "mlmcpi_path_copy_from_fine": (_i, [_vp, _vp, _u32, _u32, _vp]),
     "mlmcpi_path_copy_from_coarse": (_i, [_vp, _vp, _u32, _u32, _vp]),
     "mlmcpi_ho_cholesky_factor": (_i, [_PA, _vp]),

@@ -617,96 +617,93 @@ __device__ __forceinline__ void w_conditioned(const PathP &P, double x_m, double
   }
 }
 
-// Builds the trial state theta' (even sites = coarse proposal, odd sites = Gaussian fill-in with Philox
-// normals, site = fine index) and accumulates the conditioned fine action of theta' and of the current
-// fine state theta.  Grid (nblk, B); partial[(b*nblk + blk)*2 + {0,1}] = {S_cfa(theta'), S_cfa(theta)}.
+// TwoLevelMetropolisStep::draw (montecarlo/twolevelmetropolisstep.cc:35-89) for one chain per workgroup, in ONE launch (r02:
+// a propose kernel, four reductions of two launches each and an accept kernel -- ten launches for an O(M) streaming job,
+// 27 % of the multilevel kernel time).  The thread of coarse site j builds theta'[2j] = x_c[j] and the fill-in
+// theta'[2j+1] (Gaussian around Wminimum with Wcurvature, gaussianconditionedfineaction.cc:7-43; ExpSin2 for the rotor,
+// rotorconditionedfineaction.cc:7-43; Philox normals / von Mises draws of site 2j+1) and adds up, for the sites 2j+1 and
+// 2j+2 of the fine paths and for coarse site j+1, the six sums of the step:
+//     S_f(theta'), S_f(theta), S_c(theta_C), S_c(x_c), S_cfa(theta'), S_cfa(theta).
+// The workgroup reduces them in a fixed order, takes the decision (exp(-dS) against the chain's P_ACCEPT2 uniform) and,
+// if accepted, copies theta' over theta -- every thread the entries it wrote itself.
 template <int KIND>
-__global__ void __launch_bounds__(256)
-    twolevel_propose_kernel(PathP Pf, const double *__restrict__ x_coarse, const double *__restrict__ theta,
-                            double *__restrict__ theta_prime, double *__restrict__ partial, RngKey key0) {
-  __shared__ double red[8];
-  const uint32_t b = blockIdx.y, M = Pf.M, Mc = M / 2;
-  const double *xc = x_coarse + (size_t)b * Mc, *th = theta + (size_t)b * M;
-  double *tp = theta_prime + (size_t)b * M;
+__global__ void __launch_bounds__(KIND == MLMCPI_ROTOR ? 512 : 1024)  // the rotor's libm calls want more than 128 registers
+    twolevel_fused_kernel(PathP Pf, PathP Pc, const double *__restrict__ x_coarse, double *__restrict__ theta,
+                          double *__restrict__ theta_prime, int32_t *__restrict__ accept, double *__restrict__ terms, RngKey key0,
+                          const int32_t *__restrict__ mask) {
+  __shared__ double red[6 * 16];
+  __shared__ int decision;
+  const uint32_t b = blockIdx.x, M = Pf.M, Mc = M / 2;
+  if (mask && mask[b] == 0) {  // hierarchicalsampler.cc:62-76: a chain rejected further down does not move on this level
+    if (threadIdx.x == 0) {
+      accept[b] = 0;
+      if (terms) terms[3 * b + 0] = terms[3 * b + 1] = terms[3 * b + 2] = 0.0;
+    }
+    return;
+  }
+  const double *xc = x_coarse + (size_t)b * Mc;
+  double *th = theta + (size_t)b * M, *tp = theta_prime + (size_t)b * M;
   RngKey key = key0;
   key.chain += b;
-  const uint32_t per = (Mc + gridDim.x - 1) / gridDim.x;
-  const uint32_t lo = blockIdx.x * per, hi = min(Mc, lo + per);
-  double acc[2] = {0.0, 0.0};
-  for (uint32_t j = lo + threadIdx.x; j < hi; j += blockDim.x) {
+  double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  for (uint32_t j = threadIdx.x; j < Mc; j += blockDim.x) {
     const uint32_t jn = (j + 1 == Mc) ? 0 : j + 1;
     const double x_m = xc[j], x_p = xc[jn];
     double w_min, w_curv;
     w_conditioned<KIND>(Pf, x_m, x_p, w_min, w_curv);
     double fill;
     if (KIND == MLMCPI_ROTOR) {
-      // RotorConditionedFineAction (action/qm/rotorconditionedfineaction.cc:7-43): fill-in from the
-      // ExpSin2 law with sigma = 2 W'' (a von Mises law, see device_common.hpp), -log of its density
       const double sigma = 2. * w_curv;
       fill = mod_2pi(w_min + vonmises_draw(key, 2 * j + 1, 0.5 * sigma, kVmFillin));
       const double sh = sin(0.5 * (fill - w_min));
-      acc[0] += sigma * sh * sh + log(two_pi_i0_scaled(0.5 * sigma));
+      acc[4] += sigma * sh * sh + log(two_pi_i0_scaled(0.5 * sigma));
     } else {
       const double sigma = 1. / sqrt(w_curv);
       fill = w_min + rng_normal0(key, 2 * j + 1, P_FILLIN, 0) * sigma;
       const double dxp = fill - w_min;
-      acc[0] += 0.5 * w_curv * dxp * dxp - 0.5 * log(w_curv);
+      acc[4] += 0.5 * w_curv * dxp * dxp - 0.5 * log(w_curv);
     }
     tp[2 * j] = x_m;
     tp[2 * j + 1] = fill;
-    const double t_m = th[2 * j], t_p = th[2 * jn];
+    const double t_m = th[2 * j], t_o = th[2 * j + 1], t_p = th[2 * jn];
     w_conditioned<KIND>(Pf, t_m, t_p, w_min, w_curv);
-    const double dx = th[2 * j + 1] - w_min;
+    const double dx = t_o - w_min;
     if (KIND == MLMCPI_ROTOR) {
       const double sigma = 2. * w_curv, sh = sin(0.5 * dx);
-      acc[1] += sigma * sh * sh + log(two_pi_i0_scaled(0.5 * sigma));
+      acc[5] += sigma * sh * sh + log(two_pi_i0_scaled(0.5 * sigma));
     } else {
-      acc[1] += 0.5 * w_curv * dx * dx - 0.5 * log(w_curv);
+      acc[5] += 0.5 * w_curv * dx * dx - 0.5 * log(w_curv);
     }
+    // actions: sites 2j+1 and 2j+2 of the fine paths, site j+1 of the coarse ones (each site once over all j)
+    acc[0] += site_energy<KIND>(Pf, fill, x_m) + site_energy<KIND>(Pf, x_p, fill);
+    acc[1] += site_energy<KIND>(Pf, t_o, t_m) + site_energy<KIND>(Pf, t_p, t_o);
+    acc[2] += site_energy<KIND>(Pc, t_p, t_m);
+    acc[3] += site_energy<KIND>(Pc, x_p, x_m);
   }
-  block_sum<2>(acc, red);
+  block_sum<6>(acc, red);
   if (threadIdx.x == 0) {
-    partial[((size_t)b * gridDim.x + blockIdx.x) * 2 + 0] = acc[0];
-    partial[((size_t)b * gridDim.x + blockIdx.x) * 2 + 1] = acc[1];
-  }
-}
-
-// en6 = [6][B]: S_f(theta'), S_f(theta), S_c(theta_C), S_c(x_c), then the CFA partials are summed here.
-// deltaS = (S_f' - S_f) + (S_c(theta_C) - S_c(x_c)) + (S_cfa(theta) - S_cfa(theta'))   (twolevelmetropolisstep.cc:46-68)
-__global__ void __launch_bounds__(256)
-    twolevel_accept_kernel(uint32_t M, double *__restrict__ theta, const double *__restrict__ theta_prime,
-                           const double *__restrict__ en4, const double *__restrict__ cfa_partial, uint32_t nblk,
-                           uint32_t B, int32_t *__restrict__ accept, double *__restrict__ terms, RngKey key0) {
-  const uint32_t b = blockIdx.y;
-  double cfa_p = 0.0, cfa_c = 0.0;
-  for (uint32_t k = 0; k < nblk; ++k) {
-    cfa_p += cfa_partial[((size_t)b * nblk + k) * 2 + 0];
-    cfa_c += cfa_partial[((size_t)b * nblk + k) * 2 + 1];
-  }
-  const double dS_fine = en4[b] - en4[B + b];
-  const double dS_coarse = en4[2 * B + b] - en4[3 * B + b];
-  const double dS_trial = cfa_c - cfa_p;
-  const double dS = dS_fine + dS_coarse + dS_trial;
-  bool acc;
-  if (dS < 0.0) {
-    acc = true;
-  } else {
-    RngKey key = key0;
-    key.chain += b;
-    double u, v;
-    rng_uniforms(key, 0, P_ACCEPT2, 0, u, v);
-    acc = u < exp(-dS);
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    accept[b] = acc ? 1 : 0;
+    const double dS_fine = energy_scale(Pf) * acc[0] - energy_scale(Pf) * acc[1];
+    const double dS_coarse = energy_scale(Pc) * acc[2] - energy_scale(Pc) * acc[3];
+    const double dS_trial = acc[5] - acc[4];
+    const double dS = dS_fine + dS_coarse + dS_trial;
+    bool ok = dS < 0.0;
+    if (!ok) {
+      double u, v;
+      rng_uniforms(key, 0, P_ACCEPT2, 0, u, v);
+      ok = u < exp(-dS);
+    }
+    decision = ok ? 1 : 0;
+    accept[b] = decision;
     if (terms) {
       terms[3 * b + 0] = dS_fine; terms[3 * b + 1] = dS_coarse; terms[3 * b + 2] = dS_trial;
     }
   }
-  if (!acc) return;
-  double *dst = theta + (size_t)b * M;
-  const double *src = theta_prime + (size_t)b * M;
-  for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < M; j += gridDim.x * blockDim.x) dst[j] = src[j];
+  __syncthreads();
+  if (!decision) return;
+  for (uint32_t j = threadIdx.x; j < Mc; j += blockDim.x) {  // the entries this thread wrote above
+    th[2 * j] = tp[2 * j];
+    th[2 * j + 1] = tp[2 * j + 1];
+  }
 }
 
 // ---- host dispatch ---------------------------------------------------------------------------------------
@@ -1010,7 +1007,7 @@ int mlmcpi_path_sweep_draw_from(const mlmcpi_path_action *act, const double *d_s
                          result_in, stream);
 }
 
-// workspace: theta' [B*M] | energies [4][B] | CFA partials [B*nblk*2]
+// workspace: theta' [B*M] (the trial state; kept at the r02 size, which also held reduction partials)
 static uint32_t twolevel_blocks(uint32_t M, uint32_t B) { return choose_split(M / 2, B); }
 
 int mlmcpi_path_twolevel_workspace_bytes(const mlmcpi_path_action *fine, uint32_t B, size_t *bytes) {
@@ -1024,6 +1021,13 @@ int mlmcpi_path_twolevel_workspace_bytes(const mlmcpi_path_action *fine, uint32_
 int mlmcpi_path_twolevel_draw(const mlmcpi_path_action *fine, const mlmcpi_path_action *coarse, const double *d_x_coarse,
                               double *d_theta, uint32_t B, uint64_t seed, uint32_t chain0, uint32_t step, void *d_work,
                               int32_t *d_accept, double *d_terms, void *stream) {
+  return mlmcpi_path_twolevel_draw_masked(fine, coarse, d_x_coarse, d_theta, B, seed, chain0, step, d_work, nullptr, d_accept, d_terms,
+                                          stream);
+}
+
+int mlmcpi_path_twolevel_draw_masked(const mlmcpi_path_action *fine, const mlmcpi_path_action *coarse, const double *d_x_coarse,
+                                     double *d_theta, uint32_t B, uint64_t seed, uint32_t chain0, uint32_t step, void *d_work,
+                                     const int32_t *d_mask, int32_t *d_accept, double *d_terms, void *stream) {
   if (int rc = check_action(fine)) return rc;
   if (int rc = check_action(coarse)) return rc;
   MLMCPI_REQUIRE(d_x_coarse && d_theta && d_work && d_accept && B > 0, "bad arguments");
@@ -1031,29 +1035,19 @@ int mlmcpi_path_twolevel_draw(const mlmcpi_path_action *fine, const mlmcpi_path_
                  "coarse action must live on the lattice with half the sites (M %u vs %u)", coarse->M, fine->M);
   hipStream_t st = as_stream(stream);
   const PathP Pf = make_params(*fine), Pc = make_params(*coarse);
-  const uint32_t nblk = twolevel_blocks(Pf.M, B);
-  char *w = (char *)d_work;
-  double *theta_prime = (double *)w;
-  w += align256((size_t)B * Pf.M * 8);
-  double *en4 = (double *)w;
-  w += align256((size_t)4 * B * 8);
-  double *cfa = (double *)w;
+  double *theta_prime = (double *)d_work;
   const RngKey key = make_key(seed, chain0, step);
-  dim3 grid(nblk, B), block(256);
+  // one workgroup per chain; as many threads as there are coarse sites, up to 1024 (then several sites per thread)
+  uint32_t nt = 64;
+  while (nt < (Pf.kind == MLMCPI_ROTOR ? 512u : 1024u) && nt < Pf.M / 2) nt *= 2;
+  const dim3 grid(B), block(nt);
   if (Pf.kind == MLMCPI_HARMONIC)
-    hipLaunchKernelGGL(twolevel_propose_kernel<MLMCPI_HARMONIC>, grid, block, 0, st, Pf, d_x_coarse, (const double *)d_theta, theta_prime, cfa, key);
+    hipLaunchKernelGGL(twolevel_fused_kernel<MLMCPI_HARMONIC>, grid, block, 0, st, Pf, Pc, d_x_coarse, d_theta, theta_prime, d_accept, d_terms, key, d_mask);
   else if (Pf.kind == MLMCPI_QUARTIC)
-    hipLaunchKernelGGL(twolevel_propose_kernel<MLMCPI_QUARTIC>, grid, block, 0, st, Pf, d_x_coarse, (const double *)d_theta, theta_prime, cfa, key);
+    hipLaunchKernelGGL(twolevel_fused_kernel<MLMCPI_QUARTIC>, grid, block, 0, st, Pf, Pc, d_x_coarse, d_theta, theta_prime, d_accept, d_terms, key, d_mask);
   else
-    hipLaunchKernelGGL(twolevel_propose_kernel<MLMCPI_ROTOR>, grid, block, 0, st, Pf, d_x_coarse, (const double *)d_theta, theta_prime, cfa, key);
-  MLMCPI_LAUNCH_CHECK("twolevel_propose_kernel");
-  if (int rc = launch_reduce<R_ENERGY>(Pf, theta_prime, B, energy_scale(Pf), en4, st)) return rc;
-  if (int rc = launch_reduce<R_ENERGY>(Pf, d_theta, B, energy_scale(Pf), en4 + B, st)) return rc;
-  if (int rc = launch_reduce<R_ENERGY>(Pc, d_theta, B, energy_scale(Pc), en4 + 2 * (size_t)B, st, 2)) return rc;
-  if (int rc = launch_reduce<R_ENERGY>(Pc, d_x_coarse, B, energy_scale(Pc), en4 + 3 * (size_t)B, st)) return rc;
-  hipLaunchKernelGGL(twolevel_accept_kernel, dim3(choose_split(Pf.M, B), B), block, 0, st, Pf.M, d_theta,
-                     (const double *)theta_prime, (const double *)en4, (const double *)cfa, nblk, B, d_accept, d_terms, key);
-  MLMCPI_LAUNCH_CHECK("twolevel_accept_kernel");
+    hipLaunchKernelGGL(twolevel_fused_kernel<MLMCPI_ROTOR>, grid, block, 0, st, Pf, Pc, d_x_coarse, d_theta, theta_prime, d_accept, d_terms, key, d_mask);
+  MLMCPI_LAUNCH_CHECK("twolevel_fused_kernel");
   return MLMCPI_OK;
 }
 

@@ -67,6 +67,127 @@ class PathLevel:
                 float(self.site_steps)]
 
 
+class HierChain:
+    """HierarchicalSampler (sampler/hierarchicalsampler.cc:55-81) for the action on level `top`, B chains: restrict the
+    current sample down the levels (copy_from_fine), one HMC draw on the coarsest level, then one TwoLevelMetropolisStep
+    per level up to `top`; a chain rejected on some level does not move on the finer ones (the reference's break)."""
+
+    def __init__(self, acts, top, B, nt, dt, seed, chain0=0):
+        L = len(acts)
+        self.acts, self.top, self.L, self.B = acts, top, L, B
+        self.state = {k: torch.zeros((B, acts[k].M), dtype=torch.float64, device="cuda") for k in range(top, L)}
+        self.state[L - 1] = ops.path_initialise(acts[L - 1], B, seed, chain0)
+        self.hmc = ops.PathHMC(acts[L - 1], B, nt, dt, seed=seed, chain0=chain0)
+        self.steps = {k: ops.PathTwoLevelStep(acts[k], acts[k + 1], B, seed=seed + 31 * (k + 1), chain0=chain0)
+                      for k in range(top, L - 1)}
+        for k, st in self.steps.items():
+            st.theta = self.state[k]  # the step's current state IS the sampler's state of that level (set_state without a copy)
+        self.n_draws = 0
+        self.n_accepted = torch.zeros(B, dtype=torch.int64, device="cuda")
+        self.level_accepted = {k: torch.zeros(B, dtype=torch.int64, device="cuda") for k in range(top, L)}
+        # site-steps per draw: HMC trajectory on the coarsest level + one pass per two-level step
+        self.cost = (nt + 1) * acts[L - 1].M + sum(acts[k].M for k in range(top, L - 1))
+
+    def thermalise(self, n_hmc, n_draws, dt_top=None):
+        """The sampler's own level `top` by a direct HMC run from the reference's start (ops.hmc_thermalise; untimed, once),
+        the coarser levels by restriction -- an equilibrium sample of the fine action, which is the state the hierarchical
+        chain is supposed to be in --, then hierarchical draws."""
+        if self.top == self.L - 1:
+            ops.hmc_thermalise(self.hmc, self.state[self.top], n_hmc)
+        else:
+            self.state[self.top] = ops.path_initialise(self.acts[self.top], self.B, self.hmc.seed + 1, self.hmc.chain0)
+            if self.top in self.steps:
+                self.steps[self.top].theta = self.state[self.top]
+            direct = ops.PathHMC(self.acts[self.top], self.B, self.hmc.nt, dt_top or 0.02, seed=self.hmc.seed + 1, chain0=self.hmc.chain0)
+            ops.hmc_thermalise(direct, self.state[self.top], n_hmc)
+            for k in range(self.top + 1, self.L):
+                self.state[k].copy_(self.state[k - 1][:, ::2])
+        for _ in range(n_draws):
+            self.draw(count=False)
+
+    def draw(self, count=True):
+        for k in range(self.top + 1, self.L):  # hierarchicalsampler.cc:57-60
+            self.state[k].copy_(self.state[k - 1][:, ::2])
+        mask = self.hmc.draw(self.state[self.L - 1], count_stats=count)
+        if count:
+            self.level_accepted[self.L - 1] += mask
+        for k in range(self.L - 2, self.top - 1, -1):
+            mask = self.steps[k].draw(self.state[k + 1], mask=mask)
+            if count:
+                self.level_accepted[k] += mask
+        if count:
+            self.n_draws += 1
+            self.n_accepted += mask
+        return self.state[self.top]
+
+    def p_accept(self):
+        n = max(1, self.n_draws)
+        return {k: float(v.double().mean()) / n for k, v in self.level_accepted.items()}
+
+
+class HierPathLevel(PathLevel):
+    """Level instance of MonteCarloMultiLevel with sampler = 'hierarchical' (montecarlomultilevel.cc:27-45,118-146,170-190):
+    the coarse sampler of level l is a HierarchicalSampler on level l + 1 (HMC only on the coarsest level of the whole
+    hierarchy), sub-sampled ceil(2 tau_int) draws apart, followed by the two-level step l + 1 -> l."""
+
+    def __init__(self, acts, level, B, nt, dt_coarse, seed, chain0=0, window=20, qoi=None):
+        self.level, self.B, self.chain0 = level, B, chain0
+        L = len(acts)
+        self.coarsest = level == L - 1
+        self.qoi = qoi or ops.qoi_xsquared
+        src = level if self.coarsest else level + 1
+        self.act_src = acts[src]
+        self.sampler = HierChain(acts, src, B, nt, dt_coarse, seed + 7919 * (level + 1), chain0)
+        self.hmc = self.sampler.hmc
+        self.step = None if self.coarsest else ops.PathTwoLevelStep(acts[level], acts[level + 1], B,
+                                                                     seed=seed + 104729 * (level + 1), chain0=chain0)
+        self.acc = torch.zeros((B, chains.N_MOMENTS), dtype=torch.float64, device="cuda")
+        self.site_steps = 0
+        self.n_draws = 0
+        self.step_accepted = torch.zeros(B, dtype=torch.int64, device="cuda")
+        self.window, self.n_sub = window, 1
+        self.tau_coarse = 1.0
+
+    def thermalise(self, n, dts=None):
+        self.sampler.thermalise(n, 24, dt_top=None if dts is None else dts[self.sampler.top])
+        # tau_int of the coarse sampler's QoI: the reference's windowed estimator (common/statistics.cc:38-61:
+        # 1 + 2 sum_{k < window} (1 - k/n) C_k / C_0), with the autocovariances C_k averaged over all chains of the batch
+        n = 8 * self.window
+        q = torch.stack([self.qoi(self.sampler.draw(count=False)).clone() for _ in range(n)])   # [n, B]
+        d = q - q.mean()
+        c0 = float((d * d).mean())
+        tau = 1.0
+        if c0 > 0.0:
+            for k in range(1, self.window):
+                tau += 2.0 * (1.0 - k / n) * float((d[:-k] * d[k:]).mean()) / c0
+        self.tau_coarse = max(1.0, tau)
+        # ceil(2 tau_int), montecarlomultilevel.cc:173 (a stationary series cannot exceed 1 + 2 (window - 1))
+        self.n_sub = min(max(1, int(-(-2.0 * self.tau_coarse // 1))), 2 * (1 + 2 * self.window))
+        if self.step is not None:
+            # the level's own state: an equilibrium sample of its action by a direct HMC run (untimed, once)
+            fine = self.step.fine
+            self.step.theta = ops.path_initialise(fine, self.B, self.sampler.hmc.seed + 2, self.chain0)
+            direct = ops.PathHMC(fine, self.B, self.hmc.nt, (dts or {}).get(self.level, 0.02) if isinstance(dts, dict) else
+                                 (dts[self.level] if dts else 0.02), seed=self.sampler.hmc.seed + 2, chain0=self.chain0)
+            ops.hmc_thermalise(direct, self.step.theta, n)
+            for _ in range(16):
+                self.step.draw(self.sampler.draw(count=False))
+
+    def sample(self):
+        for _ in range(self.n_sub):
+            x = self.sampler.draw()
+        self.site_steps += self.n_sub * self.sampler.cost * self.B
+        if self.coarsest:
+            y = self.qoi(x)
+        else:
+            self.step_accepted += self.step.draw(x)
+            self.site_steps += self.step.fine.M * self.B
+            y = self.qoi(self.step.theta) - self.qoi(x)
+        ops.stats_accumulate(self.acc, y)
+        self.n_draws += 1
+        return y
+
+
 def level_costs(acts, nt, n_sub):
     """site-steps per Y sample of one chain of each level: sampler trajectories of the feeding level + two-level pass"""
     L = len(acts)
@@ -74,7 +195,10 @@ def level_costs(acts, nt, n_sub):
 
 
 class PathMLMC:
-    def __init__(self, kind, M0, T_final, n_level, B, nt=20, dt0=0.05, seed=1, rank=0, world=1, n_sub=2, params=None):
+    def __init__(self, kind, M0, T_final, n_level, B, nt=20, dt0=0.05, seed=1, rank=0, world=1, n_sub=2, params=None,
+                 hierarchical=False, dt_coarse=0.095):
+        """hierarchical = True: sampler = 'hierarchical' of the reference (HierPathLevel); dt_coarse = the HMC step size on
+        the coarsest level (0.095 is what the reference's auto-tuner finds at M_lat = 2048)"""
         p = dict(m0=1.0, mu2=1.0, lam=0.0, x0=0.0)
         p.update(params or {})
         self.acts = [abi.path_action(kind, M0 >> l, T_final, p["m0"], p["mu2"], p["lam"], p["x0"]) for l in range(n_level)]
@@ -83,9 +207,16 @@ class PathMLMC:
         self.n_level, self.rank, self.world, self.B = n_level, rank, world, B
         self.concurrent_levels, self._streams = True, {}
         self.exchange = None  # object with allreduce_sum_host(list) -> list (comm.Comm); None: torch.distributed if initialised
-        self.shares = chains.partition_instances(level_costs(self.acts, nt, n_sub), B, world)
-        self.levels = {l: PathLevel(self.acts, l, nb, nt, self.dts, seed, chain0=c0, n_sub=n_sub)
-                       for l, (c0, nb) in self.shares[rank].items()}
+        self.hierarchical = hierarchical
+        if hierarchical:  # cost of a Y sample is dominated by the coarsest-level HMC on every level: about equal shares
+            costs = [(nt + 1) * self.acts[-1].M + sum(a.M for a in self.acts[l:-1]) for l in range(n_level)]
+            self.shares = chains.partition_instances(costs, B, world)
+            self.levels = {l: HierPathLevel(self.acts, l, nb, nt, dt_coarse, seed, chain0=c0)
+                           for l, (c0, nb) in self.shares[rank].items()}
+        else:
+            self.shares = chains.partition_instances(level_costs(self.acts, nt, n_sub), B, world)
+            self.levels = {l: PathLevel(self.acts, l, nb, nt, self.dts, seed, chain0=c0, n_sub=n_sub)
+                           for l, (c0, nb) in self.shares[rank].items()}
 
     def describe(self):
         return {str(l): {"chain0": lv.chain0, "chains": lv.B, "M_lat": lv.act_src.M} for l, lv in sorted(self.levels.items())}
@@ -95,7 +226,10 @@ class PathMLMC:
 
     def thermalise(self, n):
         for lv in self.levels.values():
-            lv.thermalise(n)
+            if self.hierarchical:
+                lv.thermalise(n, self.dts)
+            else:
+                lv.thermalise(n)
 
     def pass_(self, n_samples):
         """n_samples Y samples of every level instance this rank owns.  The instances are independent, and the coarse ones

@@ -133,10 +133,13 @@ class PathTwoLevelStep:
     def set_state(self, x):
         self.theta.copy_(x)
 
-    def draw(self, x_coarse):
+    def draw(self, x_coarse, mask=None):
+        """mask (int32 [B], optional): chains with mask == 0 are left alone and come back rejected
+        (HierarchicalSampler::draw's `if (not accept) break`, sampler/hierarchicalsampler.cc:62-76)"""
         _check_state(x_coarse, self.coarse.M)
-        abi.call("mlmcpi_path_twolevel_draw", C.byref(self.fine), C.byref(self.coarse), _p(x_coarse), _p(self.theta),
-                 self.B, self.seed, self.chain0, self.step, _p(self.work), _p(self.accept), _p(self.terms), _stream())
+        abi.call("mlmcpi_path_twolevel_draw_masked", C.byref(self.fine), C.byref(self.coarse), _p(x_coarse), _p(self.theta),
+                 self.B, self.seed, self.chain0, self.step, _p(self.work), _p(mask) if mask is not None else None,
+                 _p(self.accept), _p(self.terms), _stream())
         self.step += 1
         return self.accept
 

@@ -291,6 +291,39 @@ def test_batched_mlmc_quartic_five_levels_matches_single_level(gpu_ops):
     zcheck(_where() + ": q vs m", q, e, m, em)
 
 
+def test_hierarchical_mlmc_matches_single_level(gpu_ops):
+    """MonteCarloMultiLevel with sampler = 'hierarchical', as the reference composes it (montecarlomultilevel.cc:118-146,
+    170-190; sampler/hierarchicalsampler.cc:55-81): HMC only on the coarsest level, masked two-level steps up (a chain
+    rejected on a coarse level does not move on the finer ones), coarse samplers sub-sampled ceil(2 tau_int) draws
+    apart.  Quartic double well, 3 levels 512 / 256 / 128 sites at a = 1/32 ... 1/8; telescoping sum against a
+    single-level HMC estimate on the finest lattice."""
+    from mlmcpathintegral_amd import abi, mlmc
+    par = dict(lam=1.0, x0=1.0)
+    M0, T, B = 512, 16.0, 256
+    est = mlmc.PathMLMC(abi.QUARTIC, M0, T, 3, B=B, nt=40, seed=SEED, params=par, hierarchical=True, dt_coarse=0.12)
+    est.thermalise(200)
+    est.pass_(60)
+    q, e, table = est.estimate()
+    hier = {l: lv.sampler.p_accept() for l, lv in est.levels.items()}
+    fine = abi.path_action(abi.QUARTIC, M0, T, 1.0, 1.0, 1.0, 1.0)
+    x = gpu_ops.path_initialise(fine, B, SEED + 5)
+    hmc = gpu_ops.PathHMC(fine, B, 100, 0.03, seed=SEED + 5)
+    gpu_ops.hmc_thermalise(hmc, x, 300)
+    vals = []
+    for k in range(200):
+        hmc.draw(x)
+        vals.append(gpu_ops.qoi_xsquared(x))
+    m, em = chain_mean_and_error(torch.stack(vals))
+    print(f"hierarchical 3-level MLMC <x^2> = {q:.6f} +- {e:.6f}; single-level fine HMC {m:.6f} +- {em:.6f}; level means "
+          f"{table[:, 1].tolist()}; sub-sampling {[lv.n_sub for lv in est.levels.values()]}; acceptance of the hierarchical samplers {hier}; "
+          f"two-level steps {est.p_accept()}")
+    # every level of every hierarchical sampler moves, and the break is honoured: acceptance can only drop towards the fine levels
+    for l, acc in hier.items():
+        ks = sorted(acc, reverse=True)
+        assert all(acc[k] > 0.05 for k in ks) and all(acc[ks[i]] >= acc[ks[i + 1]] for i in range(len(ks) - 1)), (l, acc)
+    zcheck(_where() + ": q vs m", q, e, m, em)
+
+
 def test_ho_exact_sampler_covariance(gpu_ops):
     """The exact sampler draws independent paths from N(0, Q^-1): <x^2> against the closed form and the two-point
     function <x_0 x_k> against the first column of L L^T, from 8192 chains x 8 draws."""
