@@ -651,6 +651,12 @@ def register_resident_roofline(kernel, launch_ms, floor_bytes, streaming_bytes, 
                      "peak": VALU_PEAK_WAVE_INSTS / 1e9, "unit": "G wave-insts/s", "dominant_kernel": valu.get("dominant_kernel"),
                      "source": valu.get("source")}
         r["valu_frac"] = valu["valu_frac"]
+        if valu.get("issue_frac") is not None:
+            # cost-weighted vector-issue utilisation (profile, build-hash tied): class counts (SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F32/64,
+            # CVT, INT32, INT64) x the measured issue cycles of each class / (1024 SIMDs x 2.4 GHz x kernel time)
+            r["issue_frac"] = valu["issue_frac"]
+            r["valu"]["issue_frac"] = valu["issue_frac"]
+        r["valu"]["from"] = "profile (PMC passes of tools/profile_all.sh on this kernel build), not measured in this run"
     return r
 
 
@@ -705,7 +711,15 @@ def report_sweeps(result, a, W, size, B, world, step_ms, ms):
             insts = valu["SQ_INSTS_VALU_per_launch"] * B / valu["chains"]
             k["valu_wave_insts_per_launch"] = insts
             k["valu_insts_per_update"] = insts * 64 / (sites * B * sweeps)
-            k["valu_frac"] = insts / (launch_ms * 1e-3) / VALU_PEAK_WAVE_INSTS
+            k["valu_frac"] = insts / (launch_ms * 1e-3) / VALU_PEAK_WAVE_INSTS   # every instruction charged 4 cycles
+            k["valu_from"] = "profile (SQ counters of this kernel build, profiles/traffic.json), launch time of this run"
+            if valu.get("issue"):
+                # cost-weighted issue bound: the launch's instruction mix by class x the measured issue cycles of each class
+                # (profiles/r02_valu_issue_cost.txt) / (1024 SIMDs x 2.4 GHz x launch time of THIS run)
+                cyc = valu["issue"]["issue_cycles"] * B / valu["chains"]
+                k["issue_frac"] = cyc / (launch_ms * 1e-3) / (1024 * 2.4e9)
+                k["issue_cycles_per_inst"] = valu["issue"]["mean_cycles_per_inst"]
+                k["valu_mix"] = {c: v * B / valu["chains"] for c, v in valu["issue"]["mix"].items()}
         kernels.append(k)
         return k
 
@@ -739,11 +753,15 @@ def report_sweeps(result, a, W, size, B, world, step_ms, ms):
     if "valu_frac" in dom:
         roof["valu_frac"] = dom["valu_frac"]
         roof["valu_insts_per_update"] = dom["valu_insts_per_update"]
+        roof["valu_from"] = dom["valu_from"]
+    if "issue_frac" in dom:
+        roof["issue_frac"] = dom["issue_frac"]
+        roof["issue_cycles_per_inst"] = dom["issue_cycles_per_inst"]
     if dom["role"].startswith("heat-bath sweep") and a.workload == "schwinger":
         roof["limited_by"] = "valu"
-        roof["note"] = ("fp64 vector-issue bound (Philox + von Mises rejection sampler, ~25-45 flop/B, SURVEY A.2): hbm_frac is "
-                        "what the contract asks for, valu_frac (SQ_INSTS_VALU x 4 cycles / 2.4 GHz / 1024 SIMDs) is the "
-                        "binding one")
+        roof["note"] = ("vector-issue bound (Philox + von Mises rejection sampler, SURVEY A.2): frac / hbm_frac is what the contract "
+                        "asks for; issue_frac (instruction mix by class x measured issue cycles per class / 1024 SIMDs / 2.4 GHz) "
+                        "is the binding one, valu_frac the same with every instruction charged 4 cycles")
     result["roofline"] = roof
     # whole step: 16 B x every update of the step against the step time, and the bytes the step's launches cannot avoid
     alg_step = 16.0 * sites * B * (a.n_overrelax + a.n_heatbath)

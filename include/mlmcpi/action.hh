@@ -449,8 +449,9 @@ public:
   double getbeta() const { return beta; }
   /** quenchedschwingeraction.hh:147-165 with RenormalisedQuenchedSchwingerParameters::beta_coarse
    *  (quenchedschwingerrenormalisation.hh:52-83): beta/4 when both directions are coarsened, beta/2
-   *  otherwise; the perturbative correction applies for beta > 4.  (The non-perturbative matching needs a
-   *  GSL root finder and is not reproduced.) */
+   *  otherwise; the perturbative correction and the non-perturbative matching of the topological susceptibility
+   *  (quenchedschwingerrenormalisation.cc:7-64; host code behind mlmcpi_schwinger_beta_coarse_nonperturbative) apply for
+   *  beta > 4. */
   std::shared_ptr<Action> coarse_action() override {
     std::shared_ptr<Lattice2D> coarse_lattice = lattice->get_coarse_lattice();
     if (!coarse_lattice)
@@ -458,7 +459,8 @@ public:
     const bool both = lattice->get_coarsening_type() == CoarsenBoth;
     double beta_c = (both ? 0.25 : 0.5) * beta;
     if (renormalisation == RenormalisationPerturbative && beta > 4.0) beta_c = (both ? 0.25 : 0.5) * (1. + (both ? 1.5 : 0.5) / beta) * beta;
-    if (renormalisation == RenormalisationNonperturbative && beta > 4.0) fatal("nonperturbative renormalisation of beta is not available");
+    if (renormalisation == RenormalisationNonperturbative && beta > 4.0)
+      check(mlmcpi_schwinger_beta_coarse_nonperturbative(beta, lattice->getNcells(), both ? 4 : 2, &beta_c), "schwinger_beta_coarse_nonperturbative");
     return std::make_shared<QuenchedSchwingerAction>(coarse_lattice, lattice, renormalisation, beta_c);
   }
   std::string info_string() const override { return QFTAction::info_string() + ", beta = " + std::to_string(beta); }

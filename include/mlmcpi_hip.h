@@ -350,6 +350,15 @@ int mlmcpi_lattice_hmc_draw(const mlmcpi_lattice_action *act, double *d_phi, uin
                             uint32_t n_rep, uint64_t seed, uint32_t chain0, uint32_t traj0, void *d_work,
                             int32_t *d_accept, double *d_energies, void *stream);
 
+/* ---- host-only analytic helpers of the quenched Schwinger model (no GPU needed) --------------------------
+ * V chi_t(beta, P) = (P / beta) Phi_chi(beta, P) (common/auxilliary.cc:30-33, 44-79, 98-193: the value
+ * QoI2DSusceptibility::evaluate's expectation is compared with, qoi/qft/qoi2dsusceptibility.cc:30-34), and the coarse
+ * coupling matched to it: the root x of chi_t(x beta, P / rho) = chi_t(beta, P) in [0.01, 2] by bisection, times beta
+ * (action/qft/quenchedschwingerrenormalisation.cc:7-64; rho = 4 when both directions are coarsened, else 2; the
+ * reference's fall-back x = 1 / rho when the interval holds no root).  Own quadrature in place of GSL's. */
+int mlmcpi_schwinger_chit_analytical(double beta, uint32_t n_plaq, double *chit);
+int mlmcpi_schwinger_beta_coarse_nonperturbative(double beta, uint32_t n_plaq, int32_t rho_refine, double *beta_coarse);
+
 /* ---- device-side statistics accumulation (common/statistics.cc:4-27, batched) ---------------
  * d_acc holds, per chain, the packed sums [n, sum q, sum q^2, sum q^3, sum q^4] that the
  * cross-rank reduction (one RCCL all-reduce of B*5 doubles) combines; see DESIGN.md. */

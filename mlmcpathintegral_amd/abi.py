@@ -112,6 +112,8 @@ SIGNATURES = {
     "mlmcpi_test_expsin2": (_i, [_u64, _u32, _u32, _vp, _u32, _vp, _vp]),
     "mlmcpi_path_site_updates": (_i, [_vp, _vp, _u32, _vp, _u32, _u32, C.c_int32, _u64, _u32, _u32, _vp]),
     "mlmcpi_lattice_site_updates": (_i, [_vp, _vp, _u32, _vp, _u32, _u32, C.c_int32, _u64, _u32, _u32, _vp]),
+    "mlmcpi_schwinger_chit_analytical": (_i, [_d, _u32, _vp]),
+    "mlmcpi_schwinger_beta_coarse_nonperturbative": (_i, [_d, _u32, C.c_int32, _vp]),
     "mlmcpi_test_vs_draw": (_i, [_u64, _u32, _u32, _d, _vp, _vp, _u32, _vp, _vp]),
     "mlmcpi_vs_table": (_i, [_d, _vp, _vp]),
 }

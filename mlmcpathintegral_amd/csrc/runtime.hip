@@ -201,6 +201,59 @@ int vs_table_device(double scale, const uint32_t **d_table) {
   return MLMCPI_OK;
 }
 
+// ---- analytic topological susceptibility of the quenched Schwinger model and the coupling matched to it (host) -----------
+// common/auxilliary.cc:30-33,44-79 (Phi_chit), :98-193 (compute_In) and action/qft/quenchedschwingerrenormalisation.cc:7-64.
+// The reference integrates with GSL (QAWO / QAG) and finds the root with gsl_root_fsolver_bisection; here: composite
+// 16-point Gauss-Legendre panels over [-pi, pi] (the integrands are analytic; panels narrow enough for the peak of width
+// 1/sqrt(x) at the origin) and a plain bisection with the reference's interval, tolerance and fall-back.
+namespace {
+// nodes / weights of the 16-point Gauss-Legendre rule on [-1, 1] (positive half)
+const double kGLx[8] = {0.0950125098376374401853193, 0.2816035507792589132304605, 0.4580167776572273863424194, 0.6178762444026437484466718,
+                        0.7554044083550030338951012, 0.8656312023878317438804679, 0.9445750230732325760779884, 0.9894009349916499325961542};
+const double kGLw[8] = {0.1894506104550684962853967, 0.1826034150449235888667637, 0.1691565193950025381893121, 0.1495959888165767320815017,
+                        0.1246289712555338720524763, 0.0951585116824927848099251, 0.0622535239386478928628438, 0.0271524594117540948517806};
+
+template <class F>
+double integrate_mpi_pi(F f, double x) {
+  int panels = 64;
+  const int want = (int)ceil(8.0 * sqrt(fabs(x) + 1.0));
+  if (want > panels) panels = want;
+  const double h = 2.0 * kPi / panels;
+  double sum = 0.0;
+  for (int p = 0; p < panels; ++p) {
+    const double mid = -kPi + (p + 0.5) * h;
+    for (int i = 0; i < 8; ++i) sum += kGLw[i] * (f(mid + 0.5 * h * kGLx[i]) + f(mid - 0.5 * h * kGLx[i]));
+  }
+  return 0.5 * h * sum;
+}
+
+// In = exp(-x) I_n(x), and the two integrals the reference calls I'_n and I''_n (auxilliary.cc:98-131)
+void schwinger_In(double x, int nmax, double *In, double *dIn, double *ddIn) {
+  for (int n = 0; n < nmax; ++n) {
+    In[n] = integrate_mpi_pi([&](double phi) { return exp(x * (cos(phi) - 1.0)) * cos(n * phi); }, x) / (2.0 * kPi);
+    dIn[n] = integrate_mpi_pi([&](double phi) { return -1. / (4. * kPi * kPi) * phi * exp(x * (cos(phi) - 1.0)) * sin(n * phi); }, x);
+    ddIn[n] = integrate_mpi_pi([&](double phi) { return 1. / (8. * kPi * kPi * kPi) * phi * phi * exp(x * (cos(phi) - 1.0)) * cos(n * phi); }, x);
+  }
+}
+
+// auxilliary.cc:44-79
+double phi_chit(double beta, unsigned int n_plaq) {
+  const int nmax = 20;
+  double In[nmax], dIn[nmax], ddIn[nmax], weight[nmax], weight_sum = 0.0;
+  schwinger_In(beta, nmax, In, dIn, ddIn);
+  for (int n = 0; n < nmax; ++n) {
+    weight[n] = (1 + (n > 0)) * pow(In[n] / In[0], (double)n_plaq);
+    weight_sum += weight[n];
+  }
+  double r = 0.0;
+  for (int n = 0; n < nmax; ++n)
+    if (weight[n] > 0.0)  // (terms whose weight underflowed: In[n] may be 0 too)
+      r += beta * weight[n] / weight_sum * (ddIn[n] / In[n] - (n_plaq - 1.0) * (dIn[n] * dIn[n]) / (In[n] * In[n]));
+  return r;
+}
+double schwinger_chit(double beta, unsigned int n_plaq) { return n_plaq / beta * phi_chit(beta, n_plaq); }  // auxilliary.cc:30-33
+}  // namespace
+
 // ---- test kernels ------------------------------------------------------------------------------
 __global__ void test_random_kernel(RngKey key, uint32_t purpose, uint32_t sub, uint32_t n, double *out) {
   uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -418,6 +471,33 @@ int mlmcpi_test_vs_draw(uint64_t seed, uint32_t chain, uint32_t step, double sca
   hipLaunchKernelGGL(test_vs_draw_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream), make_key(seed, chain, step),
                      scale, d_xp, d_xm, n, d_table, d_out);
   MLMCPI_LAUNCH_CHECK("test_vs_draw_kernel");
+  return MLMCPI_OK;
+}
+
+int mlmcpi_schwinger_chit_analytical(double beta, uint32_t n_plaq, double *chit) {
+  MLMCPI_REQUIRE(chit && beta > 0.0 && beta <= 2000.0 && n_plaq > 0, "bad arguments (0 < beta <= 2000: the series is unstable beyond, auxilliary.cc:46-52)");
+  *chit = schwinger_chit(beta, n_plaq);
+  return MLMCPI_OK;
+}
+
+int mlmcpi_schwinger_beta_coarse_nonperturbative(double beta, uint32_t n_plaq, int32_t rho_refine, double *beta_coarse) {
+  MLMCPI_REQUIRE(beta_coarse && beta > 0.0 && beta <= 2000.0 && (rho_refine == 2 || rho_refine == 4) && n_plaq >= (uint32_t)rho_refine,
+                 "bad arguments");
+  const double target = schwinger_chit(beta, n_plaq);
+  auto f = [&](double x) { return schwinger_chit(x * beta, n_plaq / rho_refine) - target; };  // quenchedschwingerrenormalisation.hh:125-133
+  double x_lo = 0.01, x_hi = 2.0, f_lo = f(x_lo), f_hi = f(x_hi), x;
+  if ((f_lo > 0 && f_hi > 0) || (f_lo < 0 && f_hi < 0)) {
+    x = rho_refine == 4 ? 0.25 : 0.5;  // no root in the interval: the reference's fall-back
+  } else {
+    for (int k = 0; k < 100; ++k) {  // bisection, relative tolerance 1e-12 on the interval (gsl_root_test_interval)
+      x = 0.5 * (x_lo + x_hi);
+      const double f_mid = f(x);
+      if ((f_mid > 0) == (f_lo > 0)) { x_lo = x; f_lo = f_mid; } else { x_hi = x; }
+      if (fabs(x_hi - x_lo) < 1e-12 * fmin(fabs(x_lo), fabs(x_hi))) break;
+    }
+    x = 0.5 * (x_lo + x_hi);
+  }
+  *beta_coarse = x * beta;
   return MLMCPI_OK;
 }
 

@@ -251,3 +251,46 @@ def test_ho_cholesky_factor_host(orc, M, T, m0, mu2):
     assert abs((L @ L.T)[0, 0] - orc.lib().orc_ho_xsquared_analytical(M, T, m0, mu2)) < 1e-12
     with pytest.raises(abi.MlmcpiError, match="only for the harmonic oscillator"):
         abi.call("mlmcpi_ho_cholesky_factor", C.byref(abi.path_action(abi.ROTOR, M, T, 0.25)), LT.ctypes.data_as(C.c_void_p))
+
+
+# ---- analytic helpers of the quenched Schwinger model (host code of libmlmcpi_hip.so; no GPU) ------------------------------
+def _phi_chit_scipy(beta, n_plaq, nmax=20):
+    """common/auxilliary.cc:44-79 + 98-193 restated with scipy (quad for the reference's I'_n, I''_n; ive for I_n)"""
+    from scipy import integrate, special
+    In = np.array([special.ive(n, beta) for n in range(nmax)])
+    dIn = np.array([integrate.quad(lambda p: -1 / (4 * np.pi ** 2) * p * np.exp(beta * (np.cos(p) - 1)) * np.sin(n * p), -np.pi, np.pi,
+                                   epsabs=1e-15, epsrel=1e-12, limit=400)[0] for n in range(nmax)])
+    ddIn = np.array([integrate.quad(lambda p: 1 / (8 * np.pi ** 3) * p * p * np.exp(beta * (np.cos(p) - 1)) * np.cos(n * p), -np.pi, np.pi,
+                                    epsabs=1e-15, epsrel=1e-12, limit=400)[0] for n in range(nmax)])
+    w = np.array([(1 + (n > 0)) * (In[n] / In[0]) ** n_plaq for n in range(nmax)])
+    ok = w > 0
+    return float(np.sum(beta * w[ok] / w.sum() * (ddIn[ok] / In[ok] - (n_plaq - 1) * dIn[ok] ** 2 / In[ok] ** 2)))
+
+
+@pytest.mark.parametrize("beta,n_plaq,survey", [(1.0, 16, 0.6500978), (4.0, 256, 1.9338785), (1.0, 1024 * 1024, 42610.18),
+                                                (8.0, 64, None), (0.3, 36, None), (40.0, 1024, None)])
+def test_schwinger_chit_analytical(beta, n_plaq, survey):
+    """V chi_t = (P / beta) Phi_chi(beta, P): the product's own quadrature against the scipy restatement of the
+    reference's formulas and against the values SURVEY 8(c) recorded (analytic side of qoi2dsusceptibility.cc:30-34)."""
+    from mlmcpathintegral_amd import abi
+    v = C.c_double()
+    abi.call("mlmcpi_schwinger_chit_analytical", beta, n_plaq, C.byref(v))
+    want = n_plaq / beta * _phi_chit_scipy(beta, n_plaq)
+    assert abs(v.value - want) < 1e-9 * max(1.0, abs(want)), (v.value, want)
+    if survey is not None:
+        assert abs(v.value - survey) < 6e-8 * survey * 10, (v.value, survey)   # the survey printed 7 - 8 digits
+
+
+@pytest.mark.parametrize("beta,n_plaq,rho", [(8.0, 256, 4), (8.0, 256, 2), (16.0, 1024, 4), (6.0, 64, 4), (30.0, 4096, 4)])
+def test_schwinger_beta_coarse_nonperturbative(beta, n_plaq, rho):
+    """quenchedschwingerrenormalisation.cc:7-64: x beta with chi_t(x beta, P / rho) = chi_t(beta, P), x in [0.01, 2]"""
+    from mlmcpathintegral_amd import abi
+    bc, a, b = C.c_double(), C.c_double(), C.c_double()
+    abi.call("mlmcpi_schwinger_beta_coarse_nonperturbative", beta, n_plaq, rho, C.byref(bc))
+    abi.call("mlmcpi_schwinger_chit_analytical", bc.value, n_plaq // rho, C.byref(a))
+    abi.call("mlmcpi_schwinger_chit_analytical", beta, n_plaq, C.byref(b))
+    assert 0.01 * beta <= bc.value <= 2.0 * beta
+    assert abs(a.value - b.value) < 1e-9 * b.value, (bc.value, a.value, b.value)
+    # to O(1 / beta) the matched coupling is the perturbative one (quenchedschwingerrenormalisation.hh:84-104)
+    pert = (1.0 / rho) * (1.0 + (1.5 if rho == 4 else 0.5) / beta) * beta
+    assert abs(bc.value - pert) < 2.5 / beta * pert, (bc.value, pert)

@@ -6,8 +6,27 @@ import json, os, sys
 src, tag = sys.argv[1], sys.argv[2]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 S = json.load(open(os.path.join(src, "summary.json")))
-SIZES = {"schwinger": 1024, "gff": 512, "rotor_hmc": 65536, "quartic_hmc": 32768, "ho_hmc": 128, "quartic_mlmc": 32768, "rotor_sweep": 65536}
-CHAINS = {"schwinger": 32, "gff": 1024, "rotor_hmc": 1024, "quartic_hmc": 2048, "ho_hmc": 8192, "quartic_mlmc": 512, "rotor_sweep": 1024}
+# Issue cost of a wave64 VALU instruction by class, in shader cycles per SIMD at 2.4 GHz, measured with
+# tools/valu_issue_bench.hip (profiles/r02_valu_issue_cost.txt; 4 waves per SIMD, independent instructions).  INT32 is a
+# mix of 2.3-cycle (xor, add, shift) and 4.2 ... 4.5-cycle (mad_u64_u32, mul, bfe, and_or) operations: the Philox rounds
+# that dominate it are 40 of the former to 20 of the latter = 3.1.  `other` = everything the class counters do not see
+# (moves, selects, compares, rounding, lane operations): 4.2.
+ISSUE_CYCLES = {"ADD_F32": 2.6, "MUL_F32": 2.8, "FMA_F32": 2.8, "TRANS_F32": 8.5, "ADD_F64": 4.7, "MUL_F64": 5.0, "FMA_F64": 5.2,
+                "TRANS_F64": 16.9, "CVT": 4.2, "INT32": 3.1, "INT64": 4.5, "other": 4.2}
+
+
+def issue_model(k):
+    """cost-weighted vector-issue time of one launch: sum over classes of count x cycles (wave-instructions x cycles per SIMD)"""
+    if "SQ_INSTS_VALU_FMA_F64" not in k or "SQ_INSTS_VALU_INT32" not in k:
+        return None
+    mix = {c: k.get("SQ_INSTS_VALU_" + c, 0.0) for c in ISSUE_CYCLES if c != "other"}
+    mix["other"] = max(0.0, k["SQ_INSTS_VALU"] - sum(mix.values()))
+    cycles = sum(mix[c] * ISSUE_CYCLES[c] for c in mix)
+    return {"mix": mix, "issue_cycles": cycles, "mean_cycles_per_inst": cycles / k["SQ_INSTS_VALU"]}
+
+
+SIZES = {"schwinger": 1024, "gff": 512, "rotor_hmc": 65536, "quartic_hmc": 32768, "ho_hmc": 128, "quartic_mlmc": 32768, "quartic_mlmc_hier": 32768, "rotor_sweep": 65536}
+CHAINS = {"schwinger": 32, "gff": 1024, "rotor_hmc": 1024, "quartic_hmc": 2048, "ho_hmc": 8192, "quartic_mlmc": 512, "quartic_mlmc_hier": 512, "rotor_sweep": 1024}
 out = {"_how": "tools/profile_all.sh: rocprofv3 --pmc <counters> --kernel-trace on `python3 bench.py --workload W --steps 5 --warmup 2 "
                "--no-cpu-baseline --no-extra-points`, one pass per counter group (SQ group; FETCH_SIZE; WRITE_SIZE), per-launch "
                "averages over every launch of the run.  FETCH_SIZE / WRITE_SIZE are KiB; FETCH_SIZE is doubled (gfx950 counts a "
@@ -16,11 +35,13 @@ out = {"_how": "tools/profile_all.sh: rocprofv3 --pmc <counters> --kernel-trace 
        "entries": [], "valu": [], "kernels_valu_busy": []}
 for w, e in S.items():
     build = (e.get("bench_profiled") or {}).get("kernel_build")
-    tot_insts = tot_ns = 0.0
+    tot_insts = tot_ns = tot_cycles = 0.0
     for name, k in e["kernels"].items():
+        im = issue_model(k)
         if "SQ_INSTS_VALU" in k and "avg_ns" in k:
             tot_insts += k["SQ_INSTS_VALU"] * k["calls"]
             tot_ns += k["avg_ns"] * k["calls"]
+            tot_cycles += (im["issue_cycles"] if im else 4.0 * k["SQ_INSTS_VALU"]) * k["calls"]
         short = name.replace("mlmcpi::", "")
         kind = None
         if "or_patch_kernel" in short or "or_block_kernel" in short or "or_kernel" in short or "sweep_kernel<false" in short:
@@ -41,12 +62,15 @@ for w, e in S.items():
                                     "SQ_INSTS_VALU_per_launch": k["SQ_INSTS_VALU"], "SQ_ACTIVE_INST_VALU": k.get("SQ_ACTIVE_INST_VALU"),
                                     "SQ_BUSY_CYCLES": k.get("SQ_BUSY_CYCLES"), "SQ_INSTS_SALU": k.get("SQ_INSTS_SALU"),
                                     "SQ_INSTS_LDS": k.get("SQ_INSTS_LDS"), "GRBM_GUI_ACTIVE": k.get("GRBM_GUI_ACTIVE"),
-                                    "avg_ns_profiled": k.get("avg_ns"), "build": build, "source": f"profiles/{tag}_profile_summary.json"})
+                                    "avg_ns_profiled": k.get("avg_ns"), "build": build, "source": f"profiles/{tag}_profile_summary.json",
+                                    "issue": im})
     if tot_ns:
         # time-weighted vector-issue utilisation of the library's kernels over the profiled run:
         # wave-instructions x 4 cycles / (1024 SIMDs x 2.4 GHz x kernel time)
         out["kernels_valu_busy"].append({"workload": w, "size": SIZES[w], "chains": CHAINS[w], "wave_insts": tot_insts, "kernel_ns": tot_ns,
-                                         "valu_frac": tot_insts / (tot_ns * 1e-9) / (256 * 4 * 2.4e9 / 4), "build": build,
+                                         "valu_frac": tot_insts / (tot_ns * 1e-9) / (256 * 4 * 2.4e9 / 4),
+                                         # cost-weighted: sum of class counts x measured issue cycles / (1024 SIMDs x 2.4 GHz x time)
+                                         "issue_frac": tot_cycles / (tot_ns * 1e-9) / (256 * 4 * 2.4e9), "build": build,
                                          "dominant_kernel": max(e["kernels"].items(), key=lambda kv: kv[1].get("pct", 0))[0].replace("mlmcpi::", ""),
                                          "source": f"profiles/{tag}_profile_summary.json"})
 json.dump(out, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
@@ -56,4 +80,4 @@ for f in os.listdir(src):
         open(os.path.join(ROOT, "profiles", f"{tag}_{f}"), "w").write(open(os.path.join(src, f)).read())
 print(len(out["entries"]), "traffic entries,", len(out["valu"]), "valu entries,", len(out["kernels_valu_busy"]), "workload utilisations")
 for e in out["kernels_valu_busy"]:
-    print(f"  {e['workload']:14s} valu_frac {e['valu_frac']:.3f}  ({e['dominant_kernel']})")
+    print(f"  {e['workload']:18s} valu_frac {e['valu_frac']:.3f} issue_frac {e['issue_frac']:.3f}  ({e['dominant_kernel']})")

@@ -15,7 +15,7 @@ for wdir in sorted(glob.glob(os.path.join(out, "*", ""))):
             name = row["Name"].split("(")[0].replace("void ", "")
             if "mlmcpi::" in name:
                 entry["kernels"].setdefault(name, {}).update(calls=int(row["Calls"]), avg_ns=float(row["AverageNs"]), pct=float(row["Percentage"]))
-    for sub in ("sq", "FETCH_SIZE", "WRITE_SIZE"):
+    for sub in ("sq", "mix1", "mix2", "FETCH_SIZE", "WRITE_SIZE"):
         acc = collections.defaultdict(lambda: collections.defaultdict(list))
         for f in glob.glob(os.path.join(wdir, sub, "**", "*counter_collection.csv"), recursive=True):
             for row in csv.DictReader(open(f)):
