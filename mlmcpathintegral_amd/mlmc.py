@@ -34,12 +34,18 @@ class PathLevel:
         self.n_draws = 0
         self.step_accepted = torch.zeros(B, dtype=torch.int64, device=self.x.device)
 
-    def thermalise(self, n):
-        """Untimed burn-in (ops.hmc_thermalise), then two-level steps until theta (which starts at zero) has been
-        replaced by an accepted proposal on every chain with near certainty (64 draws: 1e-4 at 13 % acceptance)."""
+    def thermalise(self, n, dt_fine=None):
+        """Untimed burn-in (ops.hmc_thermalise) of the feeding sampler, and of the two-level step's own state theta by a
+        direct HMC run on its level: theta must be an equilibrium sample of the fine action before the first measured step.
+        (r02 started theta at zero and relied on 64 two-level draws to replace it: at the 2 ... 4 % acceptance of the
+        coarse levels of config 5 a quarter of the chains were still at zero, and the level means came out too small.)"""
         ops.hmc_thermalise(self.hmc, self.x, n)
         if self.step is not None:
-            for _ in range(64):
+            fine = self.step.fine
+            self.step.theta = ops.path_initialise(fine, self.B, self.hmc.seed + 2, self.chain0)
+            direct = ops.PathHMC(fine, self.B, self.hmc.nt, dt_fine or 0.02, seed=self.hmc.seed + 2, chain0=self.chain0)
+            ops.hmc_thermalise(direct, self.step.theta, n)
+            for _ in range(16):
                 self.hmc.draw(self.x, count_stats=False)
                 self.step.draw(self.x)
 
@@ -229,7 +235,7 @@ class PathMLMC:
             if self.hierarchical:
                 lv.thermalise(n, self.dts)
             else:
-                lv.thermalise(n)
+                lv.thermalise(n, self.dts[lv.level])
 
     def pass_(self, n_samples):
         """n_samples Y samples of every level instance this rank owns.  The instances are independent, and the coarse ones

@@ -44,6 +44,22 @@ def test_bench_line_has_the_contract_fields():
     assert cpu["kind"] in ("reference", "port")
     # value = units of all ranks / time
     assert abs(r["value"] * r["ms_per_step"] * 1e-3 / (2 * 1024 * 1024 * 11 * r["config"]["chains_total"]) - 1.0) < 1e-6
+    # r03: the communicator record (null on one rank), the C++ path beside the Python-driven one, the cost-weighted issue bound
+    assert "rccl" in r and r["rccl"] is None and r["n_gpus"] == 1
+    cxx = r["cxx_path"]
+    assert abs(cxx["over_python_driven"] - 1.0) < 0.07 and cxx["single_chain"]["chains_per_gpu"] == 1
+    for k in r["kernels"]:
+        if "issue_frac" in k:
+            assert 0.0 < k["issue_frac"] <= k["valu_frac"] + 1e-9 <= 1.0 + 1e-9 and "profile" in k["valu_from"]
+
+
+def test_multi_rank_lines_name_their_communicator():
+    """The N = 2 rehearsals on the one-GPU box (gloo, ranks share the device): the line must say what exchanged the statistics
+    and how many ranks it saw -- and that it was not RCCL."""
+    for f in ("bench_n2_gloo_rehearsal", "bench_mlmc_n2_gloo_rehearsal"):
+        r = json.load(open(os.path.join(ROOT, "profiles", f"{_tag()}_{f}.json")))
+        assert r["n_gpus"] == 2 and r["rccl"]["ranks"] == 2 and r["rccl"]["allreduce_check"] == r["rccl"]["expected"] == 1.0
+        assert r["rccl"]["lib"] is None and "NOT an RCCL run" in r["rccl"]["rehearsal"] and "gloo" in r["stats_collective"]
 
 
 def test_bench_source_keeps_the_oracle_out_of_the_timed_path():
@@ -56,12 +72,23 @@ def test_bench_source_keeps_the_oracle_out_of_the_timed_path():
 def test_secondary_workloads_report_fractions_of_real_bounds():
     """BASELINE configs 2, 3, 5 and the other workloads: committed lines of the final build; no fraction above 1, the
     register-resident HMC kernels carry a vector-issue fraction from the SQ counters of the same kernel build."""
-    for w in ("gff", "rotor_hmc", "quartic_hmc", "ho_hmc", "quartic_mlmc", "rotor_sweep"):
+    for w in ("gff", "rotor_hmc", "quartic_hmc", "ho_hmc", "quartic_mlmc", "quartic_mlmc_hier", "rotor_sweep"):
         r = json.load(open(os.path.join(ROOT, "profiles", f"{_tag()}_bench_{w}.json")))
         assert 0.0 < r["roofline"]["frac"] <= 1.0, w
         assert r["roofline"].get("valu_frac") is None or 0.0 < r["roofline"]["valu_frac"] <= 1.0, w
-        if w.endswith("hmc") or w == "quartic_mlmc":
+        if w.endswith("hmc") or w.startswith("quartic_mlmc"):
             assert r["roofline"]["limited_by"] == "valu" and r["roofline"]["valu_frac"] is not None, w
+
+
+def test_config5_as_the_reference_runs_it_agrees_with_single_level_hmc():
+    """quartic_mlmc_hier (sampler = 'hierarchical') and quartic_mlmc (direct samplers): both telescoping
+    sums within 2 sigma of the single-level HMC estimate on the finest lattice taken in the hierarchical run."""
+    h = json.load(open(os.path.join(ROOT, "profiles", f"{_tag()}_bench_quartic_mlmc_hier.json")))
+    ref = h["mlmc"]["run_to_epsilon"]["single_level_fine_hmc"]
+    assert abs(ref["z"]) < 2.0 and h["mlmc"]["run_to_epsilon"]["reached"]
+    d = json.load(open(os.path.join(ROOT, "profiles", f"{_tag()}_bench_quartic_mlmc.json")))
+    z = (d["mlmc"]["estimate"] - ref["mean"]) / (d["mlmc"]["error"] ** 2 + ref["error"] ** 2) ** 0.5
+    assert abs(z) < 2.0, z
 
 
 def test_traffic_json_is_tied_to_a_kernel_build():

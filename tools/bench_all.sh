@@ -6,7 +6,7 @@ TAG=${1:-all}
 mkdir -p gpurun_out
 timeout -k 10 400 python bench.py --steps 20 --warmup 5 > gpurun_out/bench_${TAG}.json 2> gpurun_out/bench_${TAG}.err || { tail -5 gpurun_out/bench_${TAG}.err; exit 1; }
 cut -c1-600 gpurun_out/bench_${TAG}.json
-for W in gff rotor_hmc quartic_hmc ho_hmc quartic_mlmc rotor_sweep; do
+for W in gff rotor_hmc quartic_hmc ho_hmc quartic_mlmc quartic_mlmc_hier rotor_sweep; do
   NOCPU="--no-cpu-baseline"; case $W in gff|rotor_hmc|quartic_mlmc) NOCPU="";; esac   # CPU leg for the BASELINE configs only
   timeout -k 10 400 python bench.py --workload $W --steps 10 --warmup 2 $NOCPU > gpurun_out/bench_${TAG}_$W.json 2> gpurun_out/bench_${TAG}_$W.err || { echo "$W failed"; tail -5 gpurun_out/bench_${TAG}_$W.err; exit 1; }
   python - <<PY

@@ -25,3 +25,6 @@ for W in ${WORKLOADS:-schwinger gff rotor_hmc quartic_mlmc quartic_mlmc_hier rot
   echo "$W profiled"
 done
 python3 $ROOT/tools/profile_summarise.py $OUT
+# gpurun merges at most 64 MiB back: the raw traces and counter dumps are condensed in summary.json / *_kernel_stats.csv
+find $OUT -name "*kernel_trace.csv" -delete
+find $OUT -name "*counter_collection.csv" -delete
