@@ -6,6 +6,12 @@ TAG=${1:-all}
 mkdir -p gpurun_out
 timeout -k 10 400 python bench.py --steps 20 --warmup 5 > gpurun_out/bench_${TAG}.json 2> gpurun_out/bench_${TAG}.err || { tail -5 gpurun_out/bench_${TAG}.err; exit 1; }
 cut -c1-600 gpurun_out/bench_${TAG}.json
+# the C++ path's own records: the driver's JSON lines as printed
+for B in 32 1; do
+  N=40; [ $B = 1 ] && N=200
+  timeout -k 10 300 host/driver --method throughput --action schwinger --Mt_lat 1024 --sampler heatbath --batch $B --n_samples $N --n_burnin 30 2> gpurun_out/driver_${TAG}_b$B.err | grep '^{' | tail -1 > gpurun_out/driver_${TAG}_b$B.json || { echo "driver b$B failed"; tail -5 gpurun_out/driver_${TAG}_b$B.err; exit 1; }
+  cut -c1-300 gpurun_out/driver_${TAG}_b$B.json
+done
 for W in gff rotor_hmc quartic_hmc ho_hmc quartic_mlmc quartic_mlmc_hier rotor_sweep; do
   NOCPU="--no-cpu-baseline"; case $W in gff|rotor_hmc|quartic_mlmc) NOCPU="";; esac   # CPU leg for the BASELINE configs only
   timeout -k 10 400 python bench.py --workload $W --steps 10 --warmup 2 $NOCPU > gpurun_out/bench_${TAG}_$W.json 2> gpurun_out/bench_${TAG}_$W.err || { echo "$W failed"; tail -5 gpurun_out/bench_${TAG}_$W.err; exit 1; }
