@@ -170,6 +170,15 @@ class SweepWorkload:
                        and not os.environ.get("MLMCPI_SWEEP_TILE"))
         self.fuse = a.fuse or (6 if self.blocks else 4)
         self.plan = or_plan(a.n_overrelax, self.fuse, self.blocks)   # [(depth, launches), ...], at most two entries
+        # The last overrelaxation launch of a Schwinger draw takes the heat-bath sweep (and the QoI) along -- one launch of
+        # schwinger_or_heat_kernel<depth> (lattice2d.hip, sweep_draw_impl): 4 x 4 register-block geometry, depth <= 5,
+        # lattices >= 128, step-envelope sampler (2 beta <= 4; beta = 1 here), not switched off by MLMCPI_OR_HEAT=split.
+        self.or_heat = (kind == "schwinger" and self.blocks and a.n_heatbath == 1 and bool(self.plan) and self.plan[-1][0] <= 5
+                        and size >= 128 and os.environ.get("MLMCPI_OR_HEAT", "") != "split" and not a.no_fused_qoi)
+        self.or_heat_depth = self.plan[-1][0] if self.or_heat else 0
+        if self.or_heat:  # the launches that stay pure overrelaxation
+            d, n = self.plan[-1]
+            self.plan = self.plan[:-1] + ([(d, n - 1)] if n > 1 else [])
         self.sweep = 0
         self.ev = {"or": [], "rem": [], "hb": [], "qoi": []}
 
@@ -211,9 +220,10 @@ class SweepWorkload:
         # fused QoI: one pass over the state less (-0.045 ms per step at 32 chains, -0.006 ms at one chain)
         self.fused = a.n_heatbath > 0 and not a.no_fused_qoi
         if self.fused:  # sampler->draw's last launch sums the QoI of the new sample while the tile is in LDS
-            self.x, self.scratch, q = ops.lattice_sweep_draw_qoi(self.act, cur, oth, cur, 0, a.n_heatbath, a.seed, self.chain0,
-                                                                 s + a.n_overrelax, 1 if self.kind == "schwinger" else 3,
-                                                                 self.fuse)
+            d = self.or_heat_depth  # > 0: that launch also holds the last d overrelaxation sweeps (same launches as one call)
+            self.x, self.scratch, q = ops.lattice_sweep_draw_qoi(self.act, cur, oth, cur, d, a.n_heatbath, a.seed, self.chain0,
+                                                                 s + a.n_overrelax - d, 1 if self.kind == "schwinger" else 3,
+                                                                 d or self.fuse)
         else:
             self.x, self.scratch = ops.lattice_sweep_draw_pingpong(self.act, cur, oth, 0, a.n_heatbath, a.seed, self.chain0,
                                                                    s + a.n_overrelax, self.fuse)
@@ -690,7 +700,8 @@ def report_sweeps(result, a, W, size, B, world, step_ms, ms):
     result["config"] = {"workload": f"{a.workload} {size}x{size}, {a.n_overrelax} overrelaxation + {a.n_heatbath} heat-bath "
                                     "sweeps + QoI + record_sample per step, multicolour order",
                         "chains_per_gpu": B, "chains_total": B * world, "fuse": fuse,
-                        "overrelaxation_launches": [d for d, n in W.plan for _ in range(n)],
+                        "overrelaxation_launches": [d for d, n in W.plan for _ in range(n)] + ([W.or_heat_depth] if W.or_heat else []),
+                        "last_overrelaxation_launch_holds_the_heat_bath": W.or_heat,
                         "parallelism": f"chains sharded over {world} GPU(s), no data-path collective"}
     kernels = []
 
@@ -728,12 +739,17 @@ def report_sweeps(result, a, W, size, B, world, step_ms, ms):
         record(or_name(depth), f"{depth} fused overrelaxation sweeps", W.ev["or" if k == 0 else "rem"], launches, depth, state_rw,
                pmc_entry("entries", chains=B, fuse=depth, kind="overrelax", **wl),
                pmc_entry("valu", kind="overrelax", fuse=depth, **wl))
-    if a.n_heatbath:
+    fused = getattr(W, "fused", False)
+    if W.or_heat:
+        d = W.or_heat_depth
+        record(f"schwinger_or_heat_kernel<{d}>", f"{d} fused overrelaxation sweeps + heat-bath sweep + qoi->evaluate in one launch "
+               "(QoI summed while the tile is in LDS)", W.ev["hb"], 1, d + 1, state_rw,
+               pmc_entry("entries", chains=B, fuse=d + 1, kind="or_heat", **wl), pmc_entry("valu", kind="or_heat", fuse=d + 1, **wl))
+    elif a.n_heatbath:
         record(hb_name, "heat-bath sweep", W.ev["hb"], a.n_heatbath, 1, state_rw,
                pmc_entry("entries", chains=B, fuse=1, kind="heatbath", **wl), pmc_entry("valu", kind="heatbath", **wl))
-    fused = getattr(W, "fused", False)
-    if fused:
-        kernels[-1]["role"] = "heat-bath sweep + qoi->evaluate (QoI summed while the tile is in LDS)"
+        if fused:
+            kernels[-1]["role"] = "heat-bath sweep + qoi->evaluate (QoI summed while the tile is in LDS)"
     qk = record("stats_accumulate_kernel" if fused else
                 ("schwinger_reduce_band_kernel" if a.workload == "schwinger" else "lattice_reduce_kernel") + " (QoI) + stats_accumulate_kernel",
                 "record_sample (the QoI is fused into the heat-bath launch)" if fused else "qoi->evaluate + record_sample", W.ev["qoi"], 1, 1,
@@ -757,7 +773,7 @@ def report_sweeps(result, a, W, size, B, world, step_ms, ms):
     if "issue_frac" in dom:
         roof["issue_frac"] = dom["issue_frac"]
         roof["issue_cycles_per_inst"] = dom["issue_cycles_per_inst"]
-    if dom["role"].startswith("heat-bath sweep") and a.workload == "schwinger":
+    if ("heat-bath sweep" in dom["role"]) and a.workload == "schwinger":
         roof["limited_by"] = "valu"
         roof["note"] = ("vector-issue bound (Philox + von Mises rejection sampler, SURVEY A.2): frac / hbm_frac is what the contract "
                         "asks for; issue_frac (instruction mix by class x measured issue cycles per class / 1024 SIMDs / 2.4 GHz) "
@@ -765,7 +781,7 @@ def report_sweeps(result, a, W, size, B, world, step_ms, ms):
     result["roofline"] = roof
     # whole step: 16 B x every update of the step against the step time, and the bytes the step's launches cannot avoid
     alg_step = 16.0 * sites * B * (a.n_overrelax + a.n_heatbath)
-    floor_step = state_rw * (sum(n for _, n in W.plan) + a.n_heatbath) + (0.0 if fused else 0.5 * state_rw)
+    floor_step = state_rw * (sum(n for _, n in W.plan) + a.n_heatbath) + (0.0 if fused else 0.5 * state_rw)  # W.plan: the pure overrelaxation launches
     result["whole_step"] = {"algorithmic_bytes": alg_step, "algorithmic_GBps": alg_step / (step_ms * 1e-3) / 1e9,
                             # SURVEY 8(d)'s streaming model (16 B per update) against the HBM peak: a rate for comparison
                             # with one-pass-per-sweep implementations, NOT a roofline fraction -- fused launches share one

@@ -48,6 +48,7 @@ struct Tuning {
   bool or_lds = false;                           // MLMCPI_OR_KERNEL=lds: LDS-resident instead of register-tiled overrelaxation
   bool or_patch = false;                         // MLMCPI_OR_KERNEL=patch: 2 x 2 register blocks on 64 x 32 tiles instead of 4 x 4 on 64 x 64
   uint32_t or_threads = 0;                       // MLMCPI_OR_THREADS (LDS-resident kernel's workgroup size; 0: default)
+  bool or_heat_split = false;                    // MLMCPI_OR_HEAT=split: the heat-bath sweep behind the last overrelaxation launch gets a launch of its own
 };
 Tuning tuning();  // a copy taken under the lock: callers snapshot it once per call
 

@@ -604,17 +604,15 @@ struct OrBlockGeom {
   static constexpr int left1(int c) { return c == PH - 1 ? top1(0) : 3 * PW - 1 + c; }
 };
 
-template <int K>
-__global__ void __launch_bounds__(OrBlockGeom<K>::NT)
-    schwinger_or_block_kernel(uint32_t Mt, uint32_t Mx, const double2 *__restrict__ in, double2 *__restrict__ out,
-                              uint32_t tiles_x) {
-  using G = OrBlockGeom<K>;
-  constexpr int TW = G::TW, TH = G::TH, PW = G::PW, PH = G::PH, H = G::H, NPX = G::NPX, NPY = G::NPY, NP = G::NP;
-  extern __shared__ double lds[];
+// The buffer of geometry G (tile + halo G::H) into 4 x 4 register blocks, then KS <= G::H / 2 overrelaxation sweeps on it.
+// Ends behind the barrier of the last colour phase: the plane area of the LDS is dead from there on.
+template <class G, int KS>
+__device__ __forceinline__ void or_block_sweeps(double *lds, const double2 *__restrict__ src, uint32_t Mt, uint32_t Mx,
+                                                uint32_t i0, uint32_t j0, double (&t0)[G::PH][G::PW], double (&t1)[G::PH][G::PW]) {
+  constexpr int PW = G::PW, PH = G::PH, H = G::H, NPX = G::NPX, NPY = G::NPY, NP = G::NP;
+  static_assert(2 * KS <= H, "a sweep costs two sites of halo");
   auto pl = [&](int p) { return lds + p * NP; };
-  const uint32_t tile = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-  const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
-  const uint32_t i0 = tx * TW, j0 = ty * TH;
+  const uint32_t tid = threadIdx.x;
   const bool active = tid < NP;
   const int pj = active ? (int)tid / NPX : 0, pi = active ? (int)tid - pj * NPX : 0;
   const int me = active ? (int)tid : 0;  // idle threads of the last wave: every index is entry 0, nothing is written
@@ -623,8 +621,7 @@ __global__ void __launch_bounds__(OrBlockGeom<K>::NT)
   const int lf = pi > 0 ? me - 1 : me, rt = pi + 1 < NPX ? me + 1 : me;
   const int rtdn = (pi + 1 < NPX ? 1 : 0) + (pj > 0 ? -NPX : 0) + me;
   const int lfup = (pi > 0 ? -1 : 0) + (pj + 1 < NPY ? NPX : 0) + me;
-  const double2 *src = in + (size_t)b * Mt * Mx;
-  double t0[PH][PW], t1[PH][PW];  // [c][a]: links of vertex (PW pi + a, PH pj + c)
+  // t0, t1: [c][a] = links of vertex (PW pi + a, PH pj + c)
 
   // the block's columns in the lattice: H is even, so (gi, gi + 1) never straddles the wrap, (gi + 1, gi + 2) may
   {
@@ -666,7 +663,7 @@ __global__ void __launch_bounds__(OrBlockGeom<K>::NT)
     }
   __syncthreads();
 
-  for (int s = 0; s < K; ++s) {
+  for (int s = 0; s < KS; ++s) {
     // row -1: t0(a, -1), t1(a, -1) for a = 0 .. PW (the last from the block below to the right);
     // column PW: t1(PW, c) for c = -1 .. PH - 1 at index c + 1.  None of these changes during phases 0 and 1.
     double dn0[PW], dn1[PW + 1], rt1[PH + 1];
@@ -740,6 +737,20 @@ __global__ void __launch_bounds__(OrBlockGeom<K>::NT)
       __syncthreads();
     }
   }
+}
+
+template <int K>
+__global__ void __launch_bounds__(OrBlockGeom<K>::NT)
+    schwinger_or_block_kernel(uint32_t Mt, uint32_t Mx, const double2 *__restrict__ in, double2 *__restrict__ out,
+                              uint32_t tiles_x) {
+  using G = OrBlockGeom<K>;
+  constexpr int TW = G::TW, TH = G::TH, PW = G::PW, PH = G::PH, H = G::H, NPX = G::NPX, NP = G::NP;
+  extern __shared__ double lds[];
+  const uint32_t tile = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
+  const uint32_t i0 = tx * TW, j0 = ty * TH;
+  double t0[PH][PW], t1[PH][PW];
+  or_block_sweeps<G, K>(lds, in + (size_t)b * Mt * Mx, Mt, Mx, i0, j0, t0, t1);
 
   // Owned vertices: buffer columns [H, H + TW), rows [H, H + TH).  A thread holds PW consecutive vertices of a row
   // (64 B), so storing block-wise would make every wave instruction write 64 x 16 B at a 64 B stride.  Instead each wave
@@ -771,6 +782,130 @@ __global__ void __launch_bounds__(OrBlockGeom<K>::NT)
       if (uq[i] >= 0 && r >= 0 && r < TH) dst[(size_t)(j0 + r) * Mt + (i0 + uq[i])] = w;
     }
     __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ---- Schwinger: K overrelaxation sweeps and the heat-bath sweep behind them in one launch ------------------------------
+// A draw ends "... K overrelaxation sweeps, heat bath, QoI".  As two launches the state makes two round trips through HBM,
+// and the two kernels leave opposite halves of the CU idle: the overrelaxation launch is bound by its load / store phases
+// and the latencies of its colour phases (vector issue 0.44), the heat bath by vector issue (0.88) with its memory
+// traffic hidden.  Here the workgroup that has just swept a tile K times in registers (or_block_sweeps on the geometry
+// with halo 2K + 2, i.e. OrBlockGeom<K + 1>) lays the tile and the two rings the heat bath reads down as an LDS image (the
+// plane area is dead by then, and large enough), runs the heat-bath sweep of schwinger_sweep_kernel<true, ., 64, 32, true>
+// on it -- same regions (the pruned last-sweep form), same cells, same Philox words, same arithmetic: bit-identical
+// results -- sums the QoI and writes the tile out.  One round trip instead of two, and the two workgroups of a CU are in
+// different phases most of the time: the loads of one run under the sampler arithmetic of the other.
+// Step-envelope sampler only (2 beta <= kVsKappaMax); lattices of at least 128 x 128 that 64 x 64 tiles divide.
+template <int K>
+struct OrHeatGeom {
+  using G = OrBlockGeom<K + 1>;
+  static constexpr int NT = G::NT, HB = 2, IW = G::TW + 2 * HB, IH = G::TH + 2 * HB;
+  static constexpr size_t image_bytes = (size_t)2 * IW * IH * sizeof(double);
+  // the retry pool behind the image: a colour phase leaves 4.4 % of its ~2200 cells for it at beta = 1 (about 100 entries; a
+  // pool that overflows sends cells back to their lanes, which was measured at +20 % on the launch with 64 entries);
+  // 296 entries is what the plane area of the deepest geometry leaves
+  static constexpr uint32_t pool_cap = 296;
+  static constexpr size_t hb_bytes = image_bytes + VsPool<uint32_t>::bytes(pool_cap);
+  static_assert(hb_bytes <= OrBlockGeom<6>::lds_bytes, "two workgroups per CU");
+  static constexpr size_t lds_bytes = G::lds_bytes > hb_bytes ? G::lds_bytes : hb_bytes;
+};
+
+template <int K>
+__global__ void __launch_bounds__(OrHeatGeom<K>::NT, 4)
+    schwinger_or_heat_kernel(uint32_t Mt, uint32_t Mx, double beta, const double2 *__restrict__ in, double2 *__restrict__ out,
+                             uint32_t tiles_x, RngKey key0, int qoi_op, double *__restrict__ qoi_partial,
+                             const uint32_t *__restrict__ vs_table) {
+  using OH = OrHeatGeom<K>;
+  using G = typename OH::G;
+  constexpr int NT = OH::NT, TW = G::TW, TH = G::TH, PW = G::PW, PH = G::PH, H = G::H, NPX = G::NPX, NP = G::NP;
+  constexpr int HB = OH::HB, IW = OH::IW, IH = OH::IH, O = H - HB;  // image (0, 0) = buffer (O, O)
+  extern __shared__ double lds[];
+  __shared__ double qoi_red[NT / kWave];
+  const uint32_t tile = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
+  const uint32_t i0 = tx * TW, j0 = ty * TH;
+  double t0[PH][PW], t1[PH][PW];
+  or_block_sweeps<G, K>(lds, in + (size_t)b * Mt * Mx, Mt, Mx, i0, j0, t0, t1);
+
+  // the image: theta_0 and theta_1 planes of IH x IW vertices; every block that reaches into it puts its part down
+  double *th0 = lds, *th1 = lds + IW * IH;
+  VsPool<uint32_t> vpool = VsPool<uint32_t>::carve(lds + 2 * IW * IH, OH::pool_cap, vs_table);
+  if (tid < NP) {
+    const int pj = (int)tid / NPX, pi = (int)tid - pj * NPX;
+#pragma unroll
+    for (int c = 0; c < PH; ++c) {
+      const int r = PH * pj + c - O;
+      if (r < 0 || r >= IH) continue;
+#pragma unroll
+      for (int a = 0; a < PW; ++a) {
+        const int q = PW * pi + a - O;
+        if (q >= 0 && q < IW) {
+          th0[r * IW + q] = t0[c][a];
+          th1[r * IW + q] = t1[c][a];
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // the heat-bath sweep: the last-sweep regions of schwinger_sweep_kernel with H = HB, bw = IW, oh = TH, ow = TW
+  constexpr uint32_t bw = IW;
+  const uint32_t sc = i0 >= (uint32_t)HB ? i0 - HB : i0 + Mt - HB;  // lattice column of image column 0
+  const uint32_t sr = j0 >= (uint32_t)HB ? j0 - HB : j0 + Mx - HB;
+  auto wrap = [](uint32_t base, uint32_t off, uint32_t n) {
+    const uint32_t v = base + off;
+    return v >= n ? v - n : v;
+  };
+  RngKey skey = key0;
+  skey.chain += b;
+  const double beta2 = 2. * beta;
+  for (uint32_t par = 0; par < 2; ++par) {  // mu = 0: rows [HB, HB + TH] of one parity, columns [HB - 1, HB + TW]
+    const uint32_t r_first = HB + par, nr = (HB + TH - r_first) / 2 + 1;
+    constexpr uint32_t ncol = TW + 2;
+    heatbath_region_step<NT, 5, true, uint32_t>(
+        nr, ncol, r_first * bw + (HB - 1), 2 * bw, 1, skey, vpool,
+        [&](uint32_t o, VsCell &cell) {
+          const uint32_t r = o / bw, c = o - r * bw;
+          vs_cell(beta2, th0[o + bw] + th1[o] - th1[o + 1], th0[o - bw] + th1[o - bw + 1] - th1[o - bw], cell);
+          cell.site = 2 * (wrap(sr, r, Mx) * Mt + wrap(sc, c, Mt));
+        },
+        [&](uint32_t o) {
+          return vs_kappa_exact(beta2, th0[o + bw] + th1[o] - th1[o + 1], th0[o - bw] + th1[o - bw + 1] - th1[o - bw]);
+        },
+        [&](uint32_t o, double v) { th0[o] = v; });
+    __syncthreads();
+  }
+  for (uint32_t par = 0; par < 2; ++par) {  // mu = 1: rows [HB, HB + TH), even columns up to HB + TW, odd ones up to HB + TW - 1
+    const uint32_t c_first = HB + par, c_hi1 = par ? HB + TW - 1 : HB + TW;
+    const uint32_t nc = (c_hi1 - c_first) / 2 + 1;
+    heatbath_region_step<NT, 5, true, uint32_t>(
+        TH, nc, HB * bw + c_first, bw, 2, skey, vpool,
+        [&](uint32_t o, VsCell &cell) {
+          const uint32_t r = o / bw, c = o - r * bw;
+          vs_cell(beta2, th0[o] + th1[o + 1] - th0[o + bw], th0[o + bw - 1] + th1[o - 1] - th0[o - 1], cell);
+          cell.site = 2 * (wrap(sr, r, Mx) * Mt + wrap(sc, c, Mt)) + 1;
+        },
+        [&](uint32_t o) {
+          return vs_kappa_exact(beta2, th0[o] + th1[o + 1] - th0[o + bw], th0[o + bw - 1] + th1[o - 1] - th0[o - 1]);
+        },
+        [&](uint32_t o, double v) { th1[o] = v; });
+    __syncthreads();
+  }
+
+  // write-out and the optional QoI, as in schwinger_sweep_kernel
+  double acc[1] = {0.0};
+  double2 *dst = out + (size_t)b * Mt * Mx;
+  for_region<NT>(TH, TW, [&](uint32_t r, uint32_t c) {
+    const uint32_t o = (r + HB) * bw + (c + HB);
+    dst[(size_t)(j0 + r) * Mt + (i0 + c)] = make_double2(th0[o], th1[o]);
+    if (qoi_op) {
+      const double thp = th0[o] + th1[o + 1] - th0[o + bw] - th1[o];
+      acc[0] += qoi_op == 3 ? cos_reduced(thp) : mod_2pi(thp);
+    }
+  });
+  if (qoi_op) {
+    block_sum<1>(acc, qoi_red);
+    if (threadIdx.x == 0) qoi_partial[(size_t)b * gridDim.x + blockIdx.x] = acc[0];
   }
 }
 
@@ -1628,6 +1763,9 @@ static int init_sweep_kernels() {
 #undef MLMCPI_OR_ATTR
   MLMCPI_HIP_TRY(hipFuncSetAttribute((const void *)schwinger_or_block_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)OrBlockGeom<5>::lds_bytes));
   MLMCPI_HIP_TRY(hipFuncSetAttribute((const void *)schwinger_or_block_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)OrBlockGeom<6>::lds_bytes));
+#define MLMCPI_OR_HEAT_ATTR(KK) MLMCPI_HIP_TRY(hipFuncSetAttribute((const void *)schwinger_or_heat_kernel<KK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)OrHeatGeom<KK>::lds_bytes))
+  MLMCPI_OR_HEAT_ATTR(1); MLMCPI_OR_HEAT_ATTR(2); MLMCPI_OR_HEAT_ATTR(3); MLMCPI_OR_HEAT_ATTR(4); MLMCPI_OR_HEAT_ATTR(5);
+#undef MLMCPI_OR_HEAT_ATTR
   g_lds_attr_set[dev] = true;
   return MLMCPI_OK;
 }
@@ -1759,6 +1897,37 @@ static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, doub
       const bool use_patch = !tune.or_lds;
       if (or_blocks) {  // 4 x 4 register blocks on 64 x 64 tiles (n <= 6)
         dim3 bgrid((act->Mt / 64) * (act->Mx / 64), B);
+        // the last overrelaxation launch of the draw takes the heat-bath sweep behind it along (and the QoI, if that is
+        // the draw's last sweep): schwinger_or_heat_kernel, bit-identical to the two launches (MLMCPI_OR_HEAT=split)
+        if (!tune.or_heat_split && s + n == n_overrelax && n_heatbath >= 1 && n <= 5 && 2. * act->beta <= kVsKappaMax &&
+            act->Mt >= 128 && act->Mx >= 128) {
+          const uint32_t *vs_table = nullptr;
+          if (int rcv = vs_table_device(2. * act->beta, &vs_table)) return rcv;
+          const bool with_qoi = qoi_kind && s + n + 1 == total;
+          void *partial = nullptr;
+          if (with_qoi)
+            if (int rcs = scratch((size_t)B * bgrid.x * sizeof(double), &partial, st)) return rcs;
+          const int op = !with_qoi ? 0 : qoi_kind == 1 ? (int)L_PLAQ : (int)L_CHARGE;
+          const RngKey hkey = make_key(seed, chain0, sweep0 + s + n);
+#define MLMCPI_OR_HEAT(KK) hipLaunchKernelGGL((schwinger_or_heat_kernel<KK>), bgrid, dim3(OrHeatGeom<KK>::NT), OrHeatGeom<KK>::lds_bytes, st, act->Mt, act->Mx, act->beta, in2, out2, act->Mt / 64, hkey, op, (double *)partial, vs_table)
+          switch (n) {
+            case 1: MLMCPI_OR_HEAT(1); break;
+            case 2: MLMCPI_OR_HEAT(2); break;
+            case 3: MLMCPI_OR_HEAT(3); break;
+            case 4: MLMCPI_OR_HEAT(4); break;
+            default: MLMCPI_OR_HEAT(5);
+          }
+#undef MLMCPI_OR_HEAT
+          MLMCPI_LAUNCH_CHECK("schwinger_or_heat_kernel");
+          if (with_qoi) {
+            hipLaunchKernelGGL(lattice_finish_kernel, dim3((B + 3) / 4), dim3(256), 0, st, (const double *)partial, bgrid.x, B, op,
+                               1.0 / ((double)act->Mx * act->Mt), d_qoi);
+            MLMCPI_LAUNCH_CHECK("lattice_finish_kernel");
+          }
+          advance();
+          s += n + 1;
+          continue;
+        }
 #define MLMCPI_OR_BLOCK(KK) hipLaunchKernelGGL((schwinger_or_block_kernel<KK>), bgrid, dim3(OrBlockGeom<KK>::NT), OrBlockGeom<KK>::lds_bytes, st, act->Mt, act->Mx, in2, out2, act->Mt / 64)
         switch (n) {
           case 1: MLMCPI_OR_BLOCK(1); break;

@@ -93,6 +93,10 @@ bool apply_option(Tuning &t, const char *name, const char *value) {
     t.or_patch = v == "patch";
     return v.empty() || v == "lds" || v == "patch" || v == "block";
   }
+  if (n == "MLMCPI_OR_HEAT") {
+    t.or_heat_split = v == "split";
+    return v.empty() || v == "split" || v == "fused";
+  }
   if (n == "MLMCPI_OR_THREADS") {
     const unsigned x = (unsigned)atoi(v.c_str());
     t.or_threads = (x == 256 || x == 512 || x == 1024) ? x : 0;
@@ -102,7 +106,7 @@ bool apply_option(Tuning &t, const char *name, const char *value) {
 }
 void load_tuning_locked() {
   if (g_tuning_loaded) return;
-  for (const char *name : {"MLMCPI_SWEEP_TILE", "MLMCPI_OR_KERNEL", "MLMCPI_OR_THREADS"})
+  for (const char *name : {"MLMCPI_SWEEP_TILE", "MLMCPI_OR_KERNEL", "MLMCPI_OR_THREADS", "MLMCPI_OR_HEAT"})
     if (const char *e = getenv(name)) apply_option(g_tuning, name, e);
   g_tuning_loaded = true;
 }

@@ -510,7 +510,8 @@ def test_lattice_sweeps_match_oracle(gpu_ops, orc, kind, Mt, Mx, kw, B, fuse):
     xd, scratch = dev(x0), torch.empty((B, n), dtype=torch.float64, device="cuda")
     xo = x0.copy()
     sweep = 100
-    for n_or, n_hb in ((1, 0), (5, 0), (0, 1), (2, 1), (4, 2), (6, 1)):
+    # (5, 1), (2, 1), (4, 2) on 64 x 64-divisible lattices >= 128: the last overrelaxation launch takes the heat-bath sweep along
+    for n_or, n_hb in ((1, 0), (5, 0), (0, 1), (2, 1), (4, 2), (6, 1), (5, 1)):
         xd.copy_(dev(xo))  # every case starts from identical inputs on both sides
         gpu_ops.lattice_sweep_draw(act, xd, scratch, n_or, n_hb, SEED, 11, sweep, fuse=fuse)
         for b in range(B):
@@ -522,6 +523,36 @@ def test_lattice_sweeps_match_oracle(gpu_ops, orc, kind, Mt, Mx, kw, B, fuse):
             assert_angles_close(got, xo, tol=HB_TOL[min(n_hb, 2)], what=f"sweeps ({n_or},{n_hb}) fuse={fuse}")
         else:
             assert_close(got, xo, tol=1e-11, what=f"sweeps ({n_or},{n_hb}) fuse={fuse}")
+
+
+@pytest.mark.parametrize("Mt,Mx,B,beta", [(128, 128, 3, 1.0), (192, 128, 2, 2.0), (256, 128, 2, 0.3), (1024, 1024, 2, 1.0)])
+def test_overrelaxation_and_heat_bath_in_one_launch_equal_two_launches(gpu_ops, Mt, Mx, B, beta):
+    """schwinger_or_heat_kernel<K> (the last K <= 5 overrelaxation sweeps of a draw, the heat-bath sweep behind them and
+    the QoI in one launch) against the same draw with the heat bath in a launch of its own (MLMCPI_OR_HEAT=split): states
+    bit for bit, for every depth K, with a second heat-bath sweep behind, and the fused QoI to rounding (its partial sums
+    run over 64 x 64 instead of 64 x 32 tiles)."""
+    from mlmcpathintegral_amd import abi
+    act = abi.lattice_action(abi.SCHWINGER, Mt, Mx, beta=beta)
+    x0 = gpu_ops.lattice_initialise(act, B, SEED, 2)
+    cases = [(1, 1), (2, 1), (3, 1), (4, 2), (5, 1), (10, 1)] if Mt < 1024 else [(5, 1), (10, 1)]
+    for n_or, n_hb in cases:
+        res = {}
+        for mode in ("split", "fused"):
+            abi.set_option("MLMCPI_OR_HEAT", mode)
+            try:
+                x = x0.clone()
+                gpu_ops.lattice_sweep_draw(act, x, torch.empty_like(x), n_or, n_hb, SEED, 2, 31)
+                src = x0.clone()
+                xq, _, q = gpu_ops.lattice_sweep_draw_qoi(act, src, torch.empty_like(src), src, n_or, n_hb, SEED, 2, 31, 1)
+                res[mode] = (x, xq.clone(), q.clone())
+            finally:
+                abi.set_option("MLMCPI_OR_HEAT", "")
+        assert torch.equal(res["split"][0], res["fused"][0]), f"({n_or},{n_hb}): state differs"
+        assert torch.equal(res["split"][1], res["fused"][1]) and torch.equal(res["fused"][0], res["fused"][1])
+        assert_close(res["fused"][2].cpu().numpy(), res["split"][2].cpu().numpy(), tol=1e-13, what=f"fused QoI ({n_or},{n_hb})")
+        assert_close(res["fused"][2].cpu().numpy(), gpu_ops.qoi_avg_plaquette(res["fused"][0], Mt, Mx).cpu().numpy(), tol=1e-12, what="QoI")
+    with pytest.raises(abi.MlmcpiError):
+        abi.set_option("MLMCPI_OR_HEAT", "sideways")
 
 
 @pytest.mark.parametrize("tile", ["64x64x256", "128x32x256", "128x64x256"])

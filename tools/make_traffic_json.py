@@ -50,13 +50,17 @@ for w, e in S.items():
             tot_cycles += (im["issue_cycles"] if im else 4.0 * k["SQ_INSTS_VALU"]) * k["calls"]
         short = name.replace("mlmcpi::", "")
         kind = None
-        if "or_patch_kernel" in short or "or_block_kernel" in short or "or_kernel" in short or "sweep_kernel<false" in short:
+        if "or_heat_kernel" in short:
+            kind = "or_heat"   # K overrelaxation sweeps + the heat-bath sweep in one launch: fuse = K + 1 sweeps
+        elif "or_patch_kernel" in short or "or_block_kernel" in short or "or_kernel" in short or "sweep_kernel<false" in short:
             kind = "overrelax"
         elif "sweep_kernel<true" in short:
             kind = "heatbath"
         fuse = 1
         if "or_patch_kernel<" in short or "or_block_kernel<" in short:
             fuse = int(short.split("<")[1].split(">")[0])
+        if "or_heat_kernel<" in short:
+            fuse = int(short.split("<")[1].split(">")[0]) + 1
         if kind and w in ("schwinger", "gff", "rotor_sweep"):
             if "hbm_bytes_per_launch" in k:
                 out["entries"].append({"workload": w, "size": SIZES[w], "chains": CHAINS[w], "fuse": fuse, "kind": kind, "kernel": short,
