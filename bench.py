@@ -170,10 +170,11 @@ class SweepWorkload:
                        and not os.environ.get("MLMCPI_SWEEP_TILE"))
         self.fuse = a.fuse or (6 if self.blocks else 4)
         self.plan = or_plan(a.n_overrelax, self.fuse, self.blocks)   # [(depth, launches), ...], at most two entries
-        # The last overrelaxation launch of a Schwinger draw takes the heat-bath sweep (and the QoI) along -- one launch of
-        # schwinger_or_heat_kernel<depth> (lattice2d.hip, sweep_draw_impl): 4 x 4 register-block geometry, depth <= 5,
-        # lattices >= 128, step-envelope sampler (2 beta <= 4; beta = 1 here), not switched off by MLMCPI_OR_HEAT=split.
-        self.or_heat = (kind == "schwinger" and self.blocks and a.n_heatbath == 1 and bool(self.plan) and self.plan[-1][0] <= 5
+        # The last overrelaxation launch of a draw takes the heat-bath sweep (and the QoI) along -- one launch of
+        # schwinger_or_heat_kernel<depth> / gff_or_heat_kernel<depth> (lattice2d.hip, sweep_draw_impl): 4 x 4 register-block
+        # geometry, depth <= 5, lattices >= 128, for the Schwinger action the step-envelope sampler (2 beta <= 4; beta = 1
+        # here), not switched off by MLMCPI_OR_HEAT=split.
+        self.or_heat = (self.blocks and a.n_heatbath == 1 and bool(self.plan) and self.plan[-1][0] <= 5
                         and size >= 128 and os.environ.get("MLMCPI_OR_HEAT", "") != "split" and not a.no_fused_qoi)
         self.or_heat_depth = self.plan[-1][0] if self.or_heat else 0
         if self.or_heat:  # the launches that stay pure overrelaxation
@@ -742,7 +743,7 @@ def report_sweeps(result, a, W, size, B, world, step_ms, ms):
     fused = getattr(W, "fused", False)
     if W.or_heat:
         d = W.or_heat_depth
-        record(f"schwinger_or_heat_kernel<{d}>", f"{d} fused overrelaxation sweeps + heat-bath sweep + qoi->evaluate in one launch "
+        record(f"{a.workload}_or_heat_kernel<{d}>", f"{d} fused overrelaxation sweeps + heat-bath sweep + qoi->evaluate in one launch "
                "(QoI summed while the tile is in LDS)", W.ev["hb"], 1, d + 1, state_rw,
                pmc_entry("entries", chains=B, fuse=d + 1, kind="or_heat", **wl), pmc_entry("valu", kind="or_heat", fuse=d + 1, **wl))
     elif a.n_heatbath:

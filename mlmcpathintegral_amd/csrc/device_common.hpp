@@ -553,9 +553,10 @@ constexpr uint32_t kVsTableBytes = kVsClasses * kVsSel + kVsClasses * 16 * 4;
 struct VsTable {  // in LDS
   const uint8_t *code;  // [class][64]
   const float *lw;      // [class][16]: log2 of the acceptance factor of the bin whose left edge is the index
-  // threads 0 .. 255 copy the action's table from global memory (visible after the caller's next barrier)
+  // the workgroup copies the action's table from global memory (visible after the caller's next barrier)
   __device__ static VsTable stage(void *lds, const uint32_t *__restrict__ d_table) {
-    if (d_table && threadIdx.x < kVsTableBytes / 4) ((uint32_t *)lds)[threadIdx.x] = d_table[threadIdx.x];
+    if (d_table)
+      for (uint32_t i = threadIdx.x; i < kVsTableBytes / 4; i += blockDim.x) ((uint32_t *)lds)[i] = d_table[i];
     return VsTable{(const uint8_t *)lds, (const float *)((const uint8_t *)lds + kVsClasses * kVsSel)};
   }
 };

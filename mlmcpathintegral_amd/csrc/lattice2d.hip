@@ -22,7 +22,26 @@
 
 namespace mlmcpi {
 
-
+// Instrumentation build only (make EXTRA=-DMLMCPI_STAMPS; tools/exp_stamps.py): thread 0 of every workgroup of
+// schwinger_or_heat_kernel leaves the 100 MHz wall clock at ten points, plus the XCD / CU it ran on.
+#ifdef MLMCPI_STAMPS
+__device__ unsigned long long g_stamps[16 * 65536];
+#define MLMCPI_STAMP(k)                                                                                            \
+  do {                                                                                                             \
+    if (threadIdx.x == 0 && blockIdx.y * gridDim.x + blockIdx.x < 65536)                                           \
+      g_stamps[(blockIdx.y * gridDim.x + blockIdx.x) * 16 + (k)] = __builtin_amdgcn_s_memrealtime();               \
+  } while (0)
+#define MLMCPI_STAMP_WHERE()                                                                                       \
+  do {                                                                                                             \
+    if (threadIdx.x == 0 && blockIdx.y * gridDim.x + blockIdx.x < 65536)                                           \
+      g_stamps[(blockIdx.y * gridDim.x + blockIdx.x) * 16 + 15] =                                                  \
+          ((unsigned long long)__builtin_amdgcn_s_getreg((20 /*XCC_ID*/) | (0 << 6) | (31 << 11)) << 32) |         \
+          __builtin_amdgcn_s_getreg((4 /*HW_ID*/) | (0 << 6) | (31 << 11));                                        \
+  } while (0)
+#else
+#define MLMCPI_STAMP(k) do { } while (0)
+#define MLMCPI_STAMP_WHERE() do { } while (0)
+#endif
 
 // linear iteration of a workgroup over an nr x nc region without per-element division
 template <int NT, class F>
@@ -644,6 +663,7 @@ __device__ __forceinline__ void or_block_sweeps(double *lds, const double2 *__re
         t0[c][a] = v0.x; t1[c][a] = v0.y; t0[c][a + 1] = v1.x; t1[c][a + 1] = v1.y;
       }
   }
+  MLMCPI_STAMP(1);  // (the loads are issued; the first publish waits for their values)
   // what a neighbour reads of link mu at (a, c): up to three lists, a corner value once
   auto publish = [&](int mu, int a, int c, double v) {
     const int p1 = c == PH - 1 ? (mu ? G::top1(a) : G::top0(a)) : -1;
@@ -662,6 +682,7 @@ __device__ __forceinline__ void or_block_sweeps(double *lds, const double2 *__re
       publish(1, a, c, t1[c][a]);
     }
   __syncthreads();
+  MLMCPI_STAMP(2);  // buffer in registers, rims published
 
   for (int s = 0; s < KS; ++s) {
     // row -1: t0(a, -1), t1(a, -1) for a = 0 .. PW (the last from the block below to the right);
@@ -825,7 +846,10 @@ __global__ void __launch_bounds__(OrHeatGeom<K>::NT, 4)
   const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
   const uint32_t i0 = tx * TW, j0 = ty * TH;
   double t0[PH][PW], t1[PH][PW];
+  MLMCPI_STAMP(0);
+  MLMCPI_STAMP_WHERE();
   or_block_sweeps<G, K>(lds, in + (size_t)b * Mt * Mx, Mt, Mx, i0, j0, t0, t1);
+  MLMCPI_STAMP(3);  // K sweeps done
 
   // the image: theta_0 and theta_1 planes of IH x IW vertices; every block that reaches into it puts its part down
   double *th0 = lds, *th1 = lds + IW * IH;
@@ -847,6 +871,7 @@ __global__ void __launch_bounds__(OrHeatGeom<K>::NT, 4)
     }
   }
   __syncthreads();
+  MLMCPI_STAMP(4);  // image down
 
   // the heat-bath sweep: the last-sweep regions of schwinger_sweep_kernel with H = HB, bw = IW, oh = TH, ow = TW
   constexpr uint32_t bw = IW;
@@ -874,6 +899,7 @@ __global__ void __launch_bounds__(OrHeatGeom<K>::NT, 4)
         },
         [&](uint32_t o, double v) { th0[o] = v; });
     __syncthreads();
+    MLMCPI_STAMP(5 + par);
   }
   for (uint32_t par = 0; par < 2; ++par) {  // mu = 1: rows [HB, HB + TH), even columns up to HB + TW, odd ones up to HB + TW - 1
     const uint32_t c_first = HB + par, c_hi1 = par ? HB + TW - 1 : HB + TW;
@@ -890,6 +916,7 @@ __global__ void __launch_bounds__(OrHeatGeom<K>::NT, 4)
         },
         [&](uint32_t o, double v) { th1[o] = v; });
     __syncthreads();
+    MLMCPI_STAMP(7 + par);
   }
 
   // write-out and the optional QoI, as in schwinger_sweep_kernel
@@ -907,6 +934,7 @@ __global__ void __launch_bounds__(OrHeatGeom<K>::NT, 4)
     block_sum<1>(acc, qoi_red);
     if (threadIdx.x == 0) qoi_partial[(size_t)b * gridDim.x + blockIdx.x] = acc[0];
   }
+  MLMCPI_STAMP(9);
 }
 
 // ---- GFF sweeps --------------------------------------------------------------------------------------
@@ -1202,26 +1230,22 @@ struct GffBlockGeom {
   static constexpr int right(int c) { return c == 0 ? bot(PW - 1) : c == PH - 1 ? top(PW - 1) : 2 * PW + (PH - 2) + (c - 1); }
 };
 
-template <int K>
-__global__ void __launch_bounds__(GffBlockGeom<K>::NT)
-    gff_or_block_kernel(uint32_t Mt, uint32_t Mx, double mu2, const double *__restrict__ in, double *__restrict__ out,
-                        uint32_t tiles_x) {
-  using G = GffBlockGeom<K>;
-  constexpr int TW = G::TW, TH = G::TH, PW = G::PW, PH = G::PH, H = G::H, NPX = G::NPX, NPY = G::NPY, NP = G::NP;
-  static_assert(PW == 4 && PH == 4, "the write-back moves 4 sites per block row");
-  extern __shared__ double lds[];
+// The buffer of geometry G (tile + halo G::H) into 4 x 4 register blocks, then KS <= G::H / 2 overrelaxation sweeps; ends
+// behind the barrier of the last colour phase (the plane area is dead from there on).
+template <class G, int KS>
+__device__ __forceinline__ void gff_block_sweeps(double *lds, const double *__restrict__ src, uint32_t Mt, uint32_t Mx, double mu2,
+                                                 uint32_t i0, uint32_t j0, double (&p)[G::PH][G::PW]) {
+  constexpr int PW = G::PW, PH = G::PH, H = G::H, NPX = G::NPX, NPY = G::NPY, NP = G::NP;
+  static_assert(2 * KS <= H, "a sweep costs two sites of halo");
   auto pl = [&](int p) { return lds + p * NP; };
-  const uint32_t tile = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-  const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
-  const uint32_t i0 = tx * TW, j0 = ty * TH;
+  const uint32_t tid = threadIdx.x;
   const bool active = tid < NP;
   const int pj = active ? (int)tid / NPX : 0, pi = active ? (int)tid - pj * NPX : 0;
   const int me = active ? (int)tid : 0;  // idle threads of the last wave: every index is entry 0, nothing is written
   const int dn = pj > 0 ? me - NPX : me, up = pj + 1 < NPY ? me + NPX : me;
   const int lf = pi > 0 ? me - 1 : me, rt = pi + 1 < NPX ? me + 1 : me;
-  const double *src = in + (size_t)b * Mt * Mx;
   const double two_over_kappa = 2. / (4. + mu2);
-  double p[PH][PW];  // [c][a]: site (PW pi + a, PH pj + c)
+  // p: [c][a] = site (PW pi + a, PH pj + c)
   {
     uint32_t gi[PW / 2], gj[PH];  // H is even: a pair of sites (gi, gi + 1) never straddles the wrap
     gi[0] = (uint32_t)(((uint64_t)i0 + Mt - (H % Mt) + PW * pi) % Mt);
@@ -1252,7 +1276,7 @@ __global__ void __launch_bounds__(GffBlockGeom<K>::NT)
     for (int a = 0; a < PW; ++a) publish(a, c, p[c][a]);
   __syncthreads();
 
-  for (int s = 0; s < K; ++s) {
+  for (int s = 0; s < KS; ++s) {
 #pragma unroll
     for (int col = 0; col < 2; ++col) {
       // neighbour values across the block's edges (they have the other colour: unchanged during this phase)
@@ -1284,6 +1308,21 @@ __global__ void __launch_bounds__(GffBlockGeom<K>::NT)
       __syncthreads();
     }
   }
+}
+
+template <int K>
+__global__ void __launch_bounds__(GffBlockGeom<K>::NT)
+    gff_or_block_kernel(uint32_t Mt, uint32_t Mx, double mu2, const double *__restrict__ in, double *__restrict__ out,
+                        uint32_t tiles_x) {
+  using G = GffBlockGeom<K>;
+  constexpr int TW = G::TW, TH = G::TH, PW = G::PW, PH = G::PH, H = G::H, NPX = G::NPX, NP = G::NP;
+  static_assert(PW == 4 && PH == 4, "the write-back moves 4 sites per block row");
+  extern __shared__ double lds[];
+  const uint32_t tile = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
+  const uint32_t i0 = tx * TW, j0 = ty * TH;
+  double p[PH][PW];
+  gff_block_sweeps<G, K>(lds, in + (size_t)b * Mt * Mx, Mt, Mx, mu2, i0, j0, p);
 
   // Owned sites: buffer columns [H, H + TW), rows [H, H + TH), written back through a per-wave transposition in LDS (the
   // planes are dead after the last barrier) so that a wave instruction covers whole rows: per block row the owners put
@@ -1312,6 +1351,107 @@ __global__ void __launch_bounds__(GffBlockGeom<K>::NT)
       if (uq[i] >= 0 && r >= 0 && r < TH) *(double2 *)(dst + (size_t)(j0 + r) * Mt + (i0 + uq[i])) = w;
     }
     __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ---- GFF: K overrelaxation sweeps and the heat-bath sweep behind them in one launch ----------------------------------
+// The construction of schwinger_or_heat_kernel for the scalar field: gff_block_sweeps on the geometry with halo 2K + 2,
+// then the field on the tile and two rings as an LDS image (with the plane of parked Box-Muller partners behind it), the
+// heat-bath sweep of gff_sweep_kernel<true, 256, 64, 32> in its pruned last-sweep form -- same cells, same Philox
+// words, same arithmetic: bit-identical -- the phi^2 sum and the write-out.
+template <int K>
+struct GffHeatGeom {
+  using G = GffBlockGeom<K + 1>;
+  static constexpr int NT = G::NT, HB = 2, IW = G::TW + 2 * HB, IH = G::TH + 2 * HB;
+  static constexpr size_t image_bytes = (size_t)2 * IW * IH * sizeof(double);  // field + parked normals
+  static constexpr size_t lds_bytes = G::lds_bytes > image_bytes ? G::lds_bytes : image_bytes;
+};
+
+template <int K>
+__global__ void __launch_bounds__(GffHeatGeom<K>::NT, 4)
+    gff_or_heat_kernel(uint32_t Mt, uint32_t Mx, double mu2, const double *__restrict__ in, double *__restrict__ out,
+                       uint32_t tiles_x, RngKey key0, int qoi_op, double *__restrict__ qoi_partial) {
+  using OH = GffHeatGeom<K>;
+  using G = typename OH::G;
+  constexpr int NT = OH::NT, TW = G::TW, TH = G::TH, PW = G::PW, PH = G::PH, H = G::H, NPX = G::NPX, NP = G::NP;
+  constexpr int HB = OH::HB, IW = OH::IW, IH = OH::IH, O = H - HB;  // image (0, 0) = buffer (O, O)
+  extern __shared__ double lds[];
+  __shared__ double qoi_red[NT / kWave];
+  const uint32_t tile = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
+  const uint32_t i0 = tx * TW, j0 = ty * TH;
+  double p[PH][PW];
+  gff_block_sweeps<G, K>(lds, in + (size_t)b * Mt * Mx, Mt, Mx, mu2, i0, j0, p);
+
+  double *phi = lds, *nrm = lds + IW * IH;
+  if (tid < NP) {
+    const int pj = (int)tid / NPX, pi = (int)tid - pj * NPX;
+#pragma unroll
+    for (int c = 0; c < PH; ++c) {
+      const int r = PH * pj + c - O;
+      if (r < 0 || r >= IH) continue;
+#pragma unroll
+      for (int a = 0; a < PW; ++a) {
+        const int q = PW * pi + a - O;
+        if (q >= 0 && q < IW) phi[r * IW + q] = p[c][a];
+      }
+    }
+  }
+  __syncthreads();
+
+  // the heat-bath sweep: the last-sweep regions of gff_sweep_kernel with H = HB, bw = IW, oh = TH, ow = TW
+  constexpr uint32_t bw = IW;
+  const uint32_t sc = i0 >= (uint32_t)HB ? i0 - HB : i0 + Mt - HB;  // lattice column of image column 0 (even)
+  const uint32_t sr = j0 >= (uint32_t)HB ? j0 - HB : j0 + Mx - HB;
+  auto wrap = [](uint32_t base, uint32_t off, uint32_t n) {
+    const uint32_t v = base + off;
+    return v >= n ? v - n : v;
+  };
+  RngKey skey = key0;
+  skey.chain += b;
+  const double inv_kappa = 1. / (4. + mu2), sigma = 1. / sqrt(4. + mu2);
+  auto stencil = [&](uint32_t o) {
+    double Delta = 0.0;
+    Delta += phi[o + 1];
+    Delta += phi[o - 1];
+    Delta += phi[o + bw];
+    Delta += phi[o - bw];
+    return Delta;
+  };
+  {  // colour 0: the tile plus one ring; draws the Box-Muller pair and parks the partner's normal
+    constexpr uint32_t r_lo = HB - 1, nrow = TH + 2, c_lo = HB - 1, nhalf = (TW + 2) / 2;
+    for_region<NT>(nrow, nhalf, [&](uint32_t ri, uint32_t ci) {
+      const uint32_t r = r_lo + ri;
+      const uint32_t c = c_lo + ((r + c_lo) & 1u) + 2 * ci;
+      const uint32_t o = r * bw + c;
+      const uint32_t ell = wrap(sr, r, Mx) * Mt + wrap(sc, c, Mt);
+      double n0, n1;
+      rng_normals(skey, ell >> 1, P_GFF_NORMAL, 0, n0, n1);
+      nrm[r * bw + (c ^ 1u)] = (ell & 1u) ? n0 : n1;
+      phi[o] = fma(stencil(o), inv_kappa, sigma * ((ell & 1u) ? n1 : n0));
+    });
+    __syncthreads();
+  }
+  {  // colour 1: the tile; every cell's pair partner (c ^ 1, same row) was in the colour-0 region
+    constexpr uint32_t r_lo = HB, nrow = TH, c_lo = HB, nhalf = TW / 2;
+    for_region<NT>(nrow, nhalf, [&](uint32_t ri, uint32_t ci) {
+      const uint32_t r = r_lo + ri;
+      const uint32_t o = r * bw + c_lo + ((r + c_lo + 1u) & 1u) + 2 * ci;
+      phi[o] = fma(stencil(o), inv_kappa, sigma * nrm[o]);
+    });
+    __syncthreads();
+  }
+
+  double acc[1] = {0.0};
+  double *dst = out + (size_t)b * Mt * Mx;
+  for_region<NT>(TH, TW, [&](uint32_t r, uint32_t c) {
+    const double v = phi[(r + HB) * bw + (c + HB)];
+    dst[(size_t)(j0 + r) * Mt + (i0 + c)] = v;
+    if (qoi_op) acc[0] += v * v;
+  });
+  if (qoi_op) {
+    block_sum<1>(acc, qoi_red);
+    if (threadIdx.x == 0) qoi_partial[(size_t)b * gridDim.x + blockIdx.x] = acc[0];
   }
 }
 
@@ -1763,7 +1903,9 @@ static int init_sweep_kernels() {
 #undef MLMCPI_OR_ATTR
   MLMCPI_HIP_TRY(hipFuncSetAttribute((const void *)schwinger_or_block_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)OrBlockGeom<5>::lds_bytes));
   MLMCPI_HIP_TRY(hipFuncSetAttribute((const void *)schwinger_or_block_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)OrBlockGeom<6>::lds_bytes));
-#define MLMCPI_OR_HEAT_ATTR(KK) MLMCPI_HIP_TRY(hipFuncSetAttribute((const void *)schwinger_or_heat_kernel<KK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)OrHeatGeom<KK>::lds_bytes))
+#define MLMCPI_OR_HEAT_ATTR(KK) \
+  MLMCPI_HIP_TRY(hipFuncSetAttribute((const void *)schwinger_or_heat_kernel<KK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)OrHeatGeom<KK>::lds_bytes)); \
+  MLMCPI_HIP_TRY(hipFuncSetAttribute((const void *)gff_or_heat_kernel<KK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GffHeatGeom<KK>::lds_bytes))
   MLMCPI_OR_HEAT_ATTR(1); MLMCPI_OR_HEAT_ATTR(2); MLMCPI_OR_HEAT_ATTR(3); MLMCPI_OR_HEAT_ATTR(4); MLMCPI_OR_HEAT_ATTR(5);
 #undef MLMCPI_OR_HEAT_ATTR
   g_lds_attr_set[dev] = true;
@@ -1981,6 +2123,33 @@ static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, doub
       const bool use_gff_patch = !tune.or_lds;
       if (or_blocks) {  // 4 x 4 register blocks on 64 x 64 tiles (n <= 6)
         dim3 bgrid((act->Mt / 64) * (act->Mx / 64), B);
+        // as for the Schwinger action: the last overrelaxation launch takes the heat-bath sweep (and the QoI) along
+        if (!tune.or_heat_split && s + n == n_overrelax && n_heatbath >= 1 && n <= 5 && act->Mt >= 128 && act->Mx >= 128) {
+          const bool with_qoi = qoi_kind && s + n + 1 == total;
+          void *partial = nullptr;
+          if (with_qoi)
+            if (int rcs = scratch((size_t)B * bgrid.x * sizeof(double), &partial, st)) return rcs;
+          const int op = with_qoi ? (int)L_PHI2 : 0;
+          const RngKey hkey = make_key(seed, chain0, sweep0 + s + n);
+#define MLMCPI_GFF_HEAT(KK) hipLaunchKernelGGL((gff_or_heat_kernel<KK>), bgrid, dim3(GffHeatGeom<KK>::NT), GffHeatGeom<KK>::lds_bytes, st, act->Mt, act->Mx, mu2, (const double *)src, dst, act->Mt / 64, hkey, op, (double *)partial)
+          switch (n) {
+            case 1: MLMCPI_GFF_HEAT(1); break;
+            case 2: MLMCPI_GFF_HEAT(2); break;
+            case 3: MLMCPI_GFF_HEAT(3); break;
+            case 4: MLMCPI_GFF_HEAT(4); break;
+            default: MLMCPI_GFF_HEAT(5);
+          }
+#undef MLMCPI_GFF_HEAT
+          MLMCPI_LAUNCH_CHECK("gff_or_heat_kernel");
+          if (with_qoi) {
+            hipLaunchKernelGGL(lattice_finish_kernel, dim3((B + 3) / 4), dim3(256), 0, st, (const double *)partial, bgrid.x, B, op,
+                               1.0 / ((double)act->Mx * act->Mt), d_qoi);
+            MLMCPI_LAUNCH_CHECK("lattice_finish_kernel");
+          }
+          advance();
+          s += n + 1;
+          continue;
+        }
 #define MLMCPI_GFF_BLOCK(KK) hipLaunchKernelGGL((gff_or_block_kernel<KK>), bgrid, dim3(GffBlockGeom<KK>::NT), GffBlockGeom<KK>::lds_bytes, st, act->Mt, act->Mx, mu2, (const double *)src, dst, act->Mt / 64)
         switch (n) {
           case 1: MLMCPI_GFF_BLOCK(1); break;
@@ -2987,5 +3156,14 @@ static int gff_initialise_exact(const mlmcpi_lattice_action *act, double *d_phi,
   }
   return MLMCPI_OK;
 }
+
+#ifdef MLMCPI_STAMPS
+// instrumentation build only: the stamps of the last launch of schwinger_or_heat_kernel, 16 words per workgroup
+int mlmcpi_debug_read_stamps(unsigned long long *h_out, uint32_t n_workgroups) {
+  MLMCPI_HIP_TRY(hipDeviceSynchronize());
+  MLMCPI_HIP_TRY(hipMemcpyFromSymbol(h_out, HIP_SYMBOL(mlmcpi::g_stamps), (size_t)n_workgroups * 16 * sizeof(unsigned long long)));
+  return MLMCPI_OK;
+}
+#endif
 
 }  // extern "C"

@@ -555,6 +555,30 @@ def test_overrelaxation_and_heat_bath_in_one_launch_equal_two_launches(gpu_ops, 
         abi.set_option("MLMCPI_OR_HEAT", "sideways")
 
 
+@pytest.mark.parametrize("M,B,mass", [(128, 3, 3.0), (192, 2, 10.0), (512, 2, 10.0)])
+def test_gff_overrelaxation_and_heat_bath_in_one_launch_equal_two_launches(gpu_ops, M, B, mass):
+    """gff_or_heat_kernel<K> against the two launches it replaces (MLMCPI_OR_HEAT=split): field bit for bit, phi^2 to rounding."""
+    from mlmcpathintegral_amd import abi
+    act = abi.lattice_action(abi.GFF, M, M, mass=mass)
+    x0 = gpu_ops.lattice_initialise(act, B, SEED, 2)
+    for n_or, n_hb in ([(1, 1), (2, 1), (3, 1), (4, 2), (5, 1), (10, 1)] if M < 512 else [(10, 1)]):
+        res = {}
+        for mode in ("split", "fused"):
+            abi.set_option("MLMCPI_OR_HEAT", mode)
+            try:
+                x = x0.clone()
+                gpu_ops.lattice_sweep_draw(act, x, torch.empty_like(x), n_or, n_hb, SEED, 2, 31)
+                src = x0.clone()
+                xq, _, q = gpu_ops.lattice_sweep_draw_qoi(act, src, torch.empty_like(src), src, n_or, n_hb, SEED, 2, 31, 3)
+                res[mode] = (x, xq.clone(), q.clone())
+            finally:
+                abi.set_option("MLMCPI_OR_HEAT", "")
+        assert torch.equal(res["split"][0], res["fused"][0]), f"({n_or},{n_hb}): field differs"
+        assert torch.equal(res["split"][1], res["fused"][1]) and torch.equal(res["fused"][0], res["fused"][1])
+        assert_close(res["fused"][2].cpu().numpy(), res["split"][2].cpu().numpy(), tol=1e-13, what=f"fused phi^2 ({n_or},{n_hb})")
+        assert_close(res["fused"][2].cpu().numpy(), gpu_ops.qoi_phi_squared(res["fused"][0]).cpu().numpy(), tol=1e-12, what="phi^2")
+
+
 @pytest.mark.parametrize("tile", ["64x64x256", "128x32x256", "128x64x256"])
 def test_heatbath_retry_pool_with_several_passes_per_phase(gpu_ops, tile):
     """tiles with more than 5 x 256 cells per colour phase make heatbath_cells take several passes, i.e.
