@@ -1358,12 +1358,15 @@ __global__ void __launch_bounds__(GffBlockGeom<K>::NT)
 // The construction of schwinger_or_heat_kernel for the scalar field: gff_block_sweeps on the geometry with halo 2K + 2,
 // then the field on the tile and two rings as an LDS image (with the plane of parked Box-Muller partners behind it), the
 // heat-bath sweep of gff_sweep_kernel<true, 256, 64, 32> in its pruned last-sweep form -- same cells, same Philox
-// words, same arithmetic: bit-identical -- the phi^2 sum and the write-out.
+// words, same arithmetic: bit-identical -- the phi^2 sum and the write-out.  The second normal of a Box-Muller pair is
+// not parked in LDS here: the thread that draws the pair for a colour-0 cell (r, c) also updates the colour-1 cell
+// (r, c ^ 1) and keeps its normal in a register (the two phases walk the same compile-time index space), so the image is
+// the field alone and three workgroups fit a CU.
 template <int K>
 struct GffHeatGeom {
   using G = GffBlockGeom<K + 1>;
   static constexpr int NT = G::NT, HB = 2, IW = G::TW + 2 * HB, IH = G::TH + 2 * HB;
-  static constexpr size_t image_bytes = (size_t)2 * IW * IH * sizeof(double);  // field + parked normals
+  static constexpr size_t image_bytes = (size_t)IW * IH * sizeof(double);
   static constexpr size_t lds_bytes = G::lds_bytes > image_bytes ? G::lds_bytes : image_bytes;
 };
 
@@ -1383,7 +1386,7 @@ __global__ void __launch_bounds__(GffHeatGeom<K>::NT, 4)
   double p[PH][PW];
   gff_block_sweeps<G, K>(lds, in + (size_t)b * Mt * Mx, Mt, Mx, mu2, i0, j0, p);
 
-  double *phi = lds, *nrm = lds + IW * IH;
+  double *phi = lds;
   if (tid < NP) {
     const int pj = (int)tid / NPX, pi = (int)tid - pj * NPX;
 #pragma unroll
@@ -1418,29 +1421,36 @@ __global__ void __launch_bounds__(GffHeatGeom<K>::NT, 4)
     Delta += phi[o - bw];
     return Delta;
   };
-  {  // colour 0: the tile plus one ring; draws the Box-Muller pair and parks the partner's normal
-    constexpr uint32_t r_lo = HB - 1, nrow = TH + 2, c_lo = HB - 1, nhalf = (TW + 2) / 2;
-    for_region<NT>(nrow, nhalf, [&](uint32_t ri, uint32_t ci) {
-      const uint32_t r = r_lo + ri;
-      const uint32_t c = c_lo + ((r + c_lo) & 1u) + 2 * ci;
-      const uint32_t o = r * bw + c;
-      const uint32_t ell = wrap(sr, r, Mx) * Mt + wrap(sc, c, Mt);
-      double n0, n1;
-      rng_normals(skey, ell >> 1, P_GFF_NORMAL, 0, n0, n1);
-      nrm[r * bw + (c ^ 1u)] = (ell & 1u) ? n0 : n1;
-      phi[o] = fma(stencil(o), inv_kappa, sigma * ((ell & 1u) ? n1 : n0));
-    });
-    __syncthreads();
+  // colour 0: the tile plus one ring, (TH + 2) x (TW + 2) / 2 cells; cell idx = tid + k NT of the thread, k < CELLS
+  constexpr uint32_t nrow = TH + 2, nhalf = (TW + 2) / 2, total = nrow * nhalf, CELLS = (total + NT - 1) / NT;
+  double partner[CELLS];  // the normal of (r, c ^ 1), the colour-1 cell of the same Box-Muller pair
+#pragma unroll
+  for (uint32_t k = 0; k < CELLS; ++k) {
+    const uint32_t idx = tid + k * NT;
+    partner[k] = 0.0;
+    if (idx >= total) continue;
+    const uint32_t ri = idx / nhalf, r = HB - 1 + ri;
+    const uint32_t c = HB - 1 + ((r + HB - 1) & 1u) + 2 * (idx - ri * nhalf);
+    const uint32_t o = r * bw + c;
+    const uint32_t ell = wrap(sr, r, Mx) * Mt + wrap(sc, c, Mt);
+    double n0, n1;
+    rng_normals(skey, ell >> 1, P_GFF_NORMAL, 0, n0, n1);
+    partner[k] = (ell & 1u) ? n0 : n1;
+    phi[o] = fma(stencil(o), inv_kappa, sigma * ((ell & 1u) ? n1 : n0));
   }
-  {  // colour 1: the tile; every cell's pair partner (c ^ 1, same row) was in the colour-0 region
-    constexpr uint32_t r_lo = HB, nrow = TH, c_lo = HB, nhalf = TW / 2;
-    for_region<NT>(nrow, nhalf, [&](uint32_t ri, uint32_t ci) {
-      const uint32_t r = r_lo + ri;
-      const uint32_t o = r * bw + c_lo + ((r + c_lo + 1u) & 1u) + 2 * ci;
-      phi[o] = fma(stencil(o), inv_kappa, sigma * nrm[o]);
-    });
-    __syncthreads();
+  __syncthreads();
+  // colour 1: the tile; the cell (r, c ^ 1) of every colour-0 cell, where that lies inside the tile
+#pragma unroll
+  for (uint32_t k = 0; k < CELLS; ++k) {
+    const uint32_t idx = tid + k * NT;
+    if (idx >= total) continue;
+    const uint32_t ri = idx / nhalf, r = HB - 1 + ri;
+    const uint32_t c = (HB - 1 + ((r + HB - 1) & 1u) + 2 * (idx - ri * nhalf)) ^ 1u;
+    if (r < (uint32_t)HB || r >= (uint32_t)(HB + TH) || c < (uint32_t)HB || c >= (uint32_t)(HB + TW)) continue;
+    const uint32_t o = r * bw + c;
+    phi[o] = fma(stencil(o), inv_kappa, sigma * partner[k]);
   }
+  __syncthreads();
 
   double acc[1] = {0.0};
   double *dst = out + (size_t)b * Mt * Mx;
