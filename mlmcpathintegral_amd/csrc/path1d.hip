@@ -928,14 +928,23 @@ static int path_sweep_impl(const mlmcpi_path_action *act, double *d_x, double *d
   PathP P = make_params(*act);
   hipStream_t st = as_stream(stream);
   const uint32_t total = n_overrelax + n_heatbath;
+  const bool split_heat = tuning().or_heat_split;
   double *src = d_x, *dst = d_w0;
   uint32_t s = 0;
   while (s < total) {
     // overrelaxation sweeps (they come first, sampler order) are fused up to 8 per launch: in one dimension the halo
     // of 2 sites per sweep costs next to nothing; a heat-bath sweep gets a launch of its own (sampler-bound)
     uint32_t n = 1, kinds = 0;
-    if (s < n_overrelax) n = n_overrelax - s < 8 ? n_overrelax - s : 8;
-    else kinds = 1u;
+    if (s < n_overrelax) {
+      n = n_overrelax - s < 8 ? n_overrelax - s : 8;
+      // the last overrelaxation launch takes the heat-bath sweep behind it along (one pass over the state less; the sweeps
+      // of a launch are numbered on from its key, so the draws are those of two launches: MLMCPI_OR_HEAT=split)
+      if (!split_heat && s + n == n_overrelax && n_heatbath >= 1 && n < 8) {
+        kinds = 1u << n;
+        ++n;
+      }
+    } else
+      kinds = 1u;
     const uint32_t halo = 2 * n;
     uint32_t owned = 2048 - 2 * halo;  // even
     if (owned > P.M) owned = P.M;

@@ -407,6 +407,26 @@ def test_rotor_sweeps_match_oracle(gpu_ops, orc, M, B):
         assert_angles_close(xd.cpu().numpy(), xo, tol=tol, what=f"rotor sweeps ({n_or},{n_hb})")
 
 
+def test_rotor_heat_bath_behind_the_last_overrelaxation_launch(gpu_ops):
+    """path_sweep_impl lets the last overrelaxation launch of a draw run the heat-bath sweep as its last sweep; the draws
+    are those of separate launches (MLMCPI_OR_HEAT=split), bit for bit, at the BASELINE size too."""
+    from mlmcpathintegral_amd import abi
+    for M, B in ((4096, 3), (65536, 4)):
+        act = abi.path_action(abi.ROTOR, M, M / 8.0, 0.25)
+        x0 = gpu_ops.path_initialise(act, B, SEED, 1)
+        for n_or, n_hb in ((10, 1), (8, 1), (3, 2), (1, 1), (17, 1)):
+            res = {}
+            for mode in ("split", "fused"):
+                abi.set_option("MLMCPI_OR_HEAT", mode)
+                try:
+                    x = x0.clone()
+                    gpu_ops.path_sweep_draw(act, x, torch.empty_like(x), n_or, n_hb, SEED, 1, 40)
+                    res[mode] = x
+                finally:
+                    abi.set_option("MLMCPI_OR_HEAT", "")
+            assert torch.equal(res["split"], res["fused"]), (M, n_or, n_hb)
+
+
 def test_path_sweep_unsupported_action(gpu_ops):
     """action/action.hh:73-96: heat bath / overrelaxation are errors for HO and quartic."""
     from mlmcpathintegral_amd import abi
