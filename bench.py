@@ -189,14 +189,14 @@ class SweepWorkload:
         return self.ops.qoi_phi_squared(self.x)
 
     def lean_step(self, record=False):
-        """The same step as one ABI call for the draw + QoI (what the C++ sampler issues) and one for record_sample: no
-        per-kernel events, no split of the draw.  Used for the side measurements, where a step is ~0.1 ms and the host
-        cost of five event records and three extra calls would be a tenth of it."""
+        """The same step -- draw + QoI + record_sample -- as ONE ABI call (mlmcpi_lattice_sweep_draw_qoi_record: what the C++
+        sampler's draw_with_qoi issues when it is handed the moments): no per-kernel events, no split of the draw.  Used for
+        the side measurements, where a step is ~0.07 ms and the host cost of five event records and three extra calls would
+        be a tenth of it."""
         a, ops, s = self.a, self.ops, self.sweep
         self.x, self.scratch, q = ops.lattice_sweep_draw_qoi(self.act, self.x, self.scratch, self.x, a.n_overrelax, a.n_heatbath,
                                                              a.seed, self.chain0, s, 1 if self.kind == "schwinger" else 3,
-                                                             a.fuse)
-        ops.stats_accumulate(self.acc, q)
+                                                             a.fuse, acc=self.acc)  # record_sample in the same call
         self.sweep = s + a.n_overrelax + a.n_heatbath
 
     def step(self, record):

@@ -169,11 +169,10 @@ int main(int argc, char **argv) {
     const unsigned n_samples = (unsigned)num("n_samples"), warmup = (unsigned)num("warmup");
     auto sweeper = std::dynamic_pointer_cast<OverrelaxedHeatBathSampler>(sampler);
     const int fused = sweeper ? qoi->fused_kind() : 0;
-    auto one = [&]() {
-      if (!(fused && sweeper->draw_with_qoi(phi_state, fused, (double *)q.ptr()))) {
-        sampler->draw(phi_state);
-        qoi->evaluate_device(phi_state, (double *)q.ptr());
-      }
+    auto one = [&]() {  // draw + QoI + record_sample as one call where the sampler can; else the three steps
+      if (fused && sweeper->draw_with_qoi(phi_state, fused, (double *)q.ptr(), (double *)acc.ptr())) return;
+      sampler->draw(phi_state);
+      qoi->evaluate_device(phi_state, (double *)q.ptr());
       check(mlmcpi_stats_accumulate((double *)acc.ptr(), (const double *)q.ptr(), batch, nullptr), "stats_accumulate");
     };
     for (unsigned i = 0; i < warmup; ++i) one();

@@ -446,16 +446,24 @@ int main(int argc, char **argv) {
     auto check_fused = [&](std::shared_ptr<Action> act, std::shared_ptr<QoI> qoi, const char *what) {
       OverrelaxedHeatBathSampler s(act, hb);
       auto x = std::make_shared<SampleState>(act->sample_size(), 3);
-      DeviceVector dq(3), dref(3);
-      double worst = 0.0;
+      DeviceVector dq(3), dref(3), acc(15);  // acc: record_sample in the same call (per-chain moments n, sum q, sum q^2, ...)
+      check(mlmcpi_memset(acc.ptr(), 0, 15 * sizeof(double), nullptr), "memset");
+      double worst = 0.0, sum_q[3] = {0, 0, 0};
       for (int d = 0; d < 3; ++d) {
-        const bool fused = s.draw_with_qoi(x, qoi->fused_kind(), (double *)dq.ptr());
+        const bool fused = s.draw_with_qoi(x, qoi->fused_kind(), (double *)dq.ptr(), (double *)acc.ptr());
         EXPECT(fused, "%s: draw_with_qoi refused", what);
         qoi->evaluate_device(x, (double *)dref.ptr());
         const auto a = dq.download<double>(), b = dref.download<double>();
-        for (int c = 0; c < 3; ++c) worst = std::fmax(worst, std::fabs(a[c] - b[c]) / std::fmax(1.0, std::fabs(b[c])));
+        for (int c = 0; c < 3; ++c) {
+          worst = std::fmax(worst, std::fabs(a[c] - b[c]) / std::fmax(1.0, std::fabs(b[c])));
+          sum_q[c] += a[c];
+        }
       }
       EXPECT(worst < 1e-10, "%s: fused QoI differs from evaluate_device by %g", what, worst);
+      const auto m = acc.download<double>();
+      for (int c = 0; c < 3; ++c)
+        EXPECT(m[5 * c] == 3.0 && m[5 * c + 1] == sum_q[c], "%s: moments recorded inside the draw: n = %g, sum = %.17g vs %.17g", what,
+               m[5 * c], m[5 * c + 1], sum_q[c]);
       std::printf(" draw_with_qoi (%s): 3 draws x 3 chains, largest relative difference to evaluate_device %.1e\n", what, worst);
     };
     auto schw = std::make_shared<QuenchedSchwingerAction>(lat, nullptr, RenormalisationNone, 1.0);

@@ -67,7 +67,7 @@ public:
   }
   /** sweep_from with the QoI of the new sample summed inside the last launch (qoi_kind: QoI::fused_kind()); returns -1
    *  when the action cannot fuse it (the caller then evaluates the QoI on its own) */
-  virtual int sweep_from_qoi(const double *, double *, double *, unsigned, unsigned, unsigned, uint32_t, int, double *) { return -1; }
+  virtual int sweep_from_qoi(const double *, double *, double *, unsigned, unsigned, unsigned, uint32_t, int, double *, double * = nullptr) { return -1; }
   /** action.hh:130-143: transfers between this level and the next coarser / finer one */
   virtual void copy_from_coarse(const std::shared_ptr<SampleState>, std::shared_ptr<SampleState>) { fatal("cannot copy from coarse lattice."); }
   virtual void copy_from_fine(const std::shared_ptr<SampleState>, std::shared_ptr<SampleState>) { fatal("cannot copy from fine lattice."); }
@@ -304,12 +304,16 @@ public:
     return where;
   }
   int sweep_from_qoi(const double *d_src, double *d_w0, double *d_w1, unsigned batch, unsigned n_or, unsigned n_hb, uint32_t sweep0,
-                     int qoi_kind, double *d_q) override {
+                     int qoi_kind, double *d_q, double *d_acc = nullptr) override {
     // kinds 1, 2 (plaquette QoIs) belong to the Schwinger action, 3 (phi^2) to the GFF
     if (n_hb == 0 || qoi_kind == 0 || (qoi_kind == 3) != (abi.kind == MLMCPI_GFF)) return -1;
     int32_t where = 0;
-    check(mlmcpi_lattice_sweep_draw_qoi(&abi, d_src, d_w0, d_w1, batch, n_or, n_hb, seed, chain0, sweep0, fuse, qoi_kind, d_q, &where,
-                                        nullptr), "lattice_sweep_draw_qoi");
+    if (d_acc)  // record_sample in the same call (per-chain moments on the device)
+      check(mlmcpi_lattice_sweep_draw_qoi_record(&abi, d_src, d_w0, d_w1, batch, n_or, n_hb, seed, chain0, sweep0, fuse, qoi_kind, d_q,
+                                                 d_acc, &where, nullptr), "lattice_sweep_draw_qoi_record");
+    else
+      check(mlmcpi_lattice_sweep_draw_qoi(&abi, d_src, d_w0, d_w1, batch, n_or, n_hb, seed, chain0, sweep0, fuse, qoi_kind, d_q, &where,
+                                          nullptr), "lattice_sweep_draw_qoi");
     return where;
   }
   /** quenchedschwingeraction.cc:92-195, gffaction.cc:97-118: `this` is the level being written to */
@@ -402,9 +406,9 @@ public:
     return QFTAction::sweep_from(d_src, d_w0, d_w1, batch, n_or, n_hb, sweep0);
   }
   int sweep_from_qoi(const double *d_src, double *d_w0, double *d_w1, unsigned batch, unsigned n_or, unsigned n_hb, uint32_t sweep0,
-                     int qoi_kind, double *d_q) override {
+                     int qoi_kind, double *d_q, double *d_acc = nullptr) override {
     if (!plain()) fatal("heat bath / overrelaxation sweeps of the GFF action are only built for the plain level");
-    return QFTAction::sweep_from_qoi(d_src, d_w0, d_w1, batch, n_or, n_hb, sweep0, qoi_kind, d_q);
+    return QFTAction::sweep_from_qoi(d_src, d_w0, d_w1, batch, n_or, n_hb, sweep0, qoi_kind, d_q, d_acc);
   }
   /** GFFAction::draw (gffaction.cc:200-213): exact draw + n_gibbs_smooth Gibbs sweeps; `step` numbers the draws */
   void draw_level(std::shared_ptr<SampleState> phi, uint32_t step) const {

@@ -216,14 +216,15 @@ public:
     if (phi_state != phi_state_cur) phi_state->share(*phi_state_cur);
   }
   /** draw + QoI in one pass over the state: d_q[b] = the QoI (QoI::fused_kind()) of the new sample, summed inside the
-   *  draw's last launch.  Returns false (and does nothing) when the action cannot fuse it. */
-  bool draw_with_qoi(std::shared_ptr<SampleState> phi_state, int qoi_kind, double *d_q) {
-    if (!advance(qoi_kind, d_q)) return false;
+   *  draw's last launch; d_acc != NULL: stats->record_sample(q) into the per-chain device moments d_acc[batch][5] as well
+   *  (mlmcpi_stats_accumulate's layout), in the same call.  Returns false (and does nothing) when the action cannot fuse it. */
+  bool draw_with_qoi(std::shared_ptr<SampleState> phi_state, int qoi_kind, double *d_q, double *d_acc = nullptr) {
+    if (!advance(qoi_kind, d_q, d_acc)) return false;
     if (phi_state != phi_state_cur) phi_state->share(*phi_state_cur);
     return true;
   }
   /** the draw without handing the sample out (callers that read current_state()) */
-  bool advance(int qoi_kind = 0, double *d_q = nullptr) {
+  bool advance(int qoi_kind = 0, double *d_q = nullptr, double *d_acc = nullptr) {
     if (qoi_kind && (n_sweep_heatbath == 0 || random_order)) return false;
     if (random_order) {  // overrelaxedheatbathsampler.cc:8-31 as written: shuffle, then one local update per index
       // (site_updates works in place; a sample handed out earlier keeps its values: SampleState::device_mutable detaches)
@@ -244,7 +245,7 @@ public:
       std::shared_ptr<DeviceBuffer> w0 = free_buffer(src, nullptr);
       std::shared_ptr<DeviceBuffer> w1 = src_is_lent ? free_buffer(src, w0) : src;
       const int where = qoi_kind ? action->sweep_from_qoi(src->p, w0->p, w1->p, phi_state_cur->batch(), n_sweep_overrelax,
-                                                          n_sweep_heatbath, sweep_counter, qoi_kind, d_q)
+                                                          n_sweep_heatbath, sweep_counter, qoi_kind, d_q, d_acc)
                                  : action->sweep_from(src->p, w0->p, w1->p, phi_state_cur->batch(), n_sweep_overrelax,
                                                       n_sweep_heatbath, sweep_counter);
       if (where < 0) return false;

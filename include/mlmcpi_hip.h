@@ -250,6 +250,14 @@ int mlmcpi_lattice_sweep_draw_from(const mlmcpi_lattice_action *act, const doubl
 int mlmcpi_lattice_sweep_draw_qoi(const mlmcpi_lattice_action *act, const double *d_src, double *d_w0, double *d_w1, uint32_t B,
                                   uint32_t n_overrelax, uint32_t n_heatbath, uint64_t seed, uint32_t chain0, uint32_t sweep0,
                                   uint32_t fuse, int32_t qoi_kind, double *d_qoi, int32_t *result_in, void *stream);
+/* One pass of the sampling loop at montecarlo/montecarlosinglelevel.cc:59-77 in one call: sampler->draw, qoi->evaluate and
+ * stats->record_sample -- mlmcpi_lattice_sweep_draw_qoi followed by mlmcpi_stats_accumulate(d_acc, d_qoi, B), with the
+ * moments updated by the launch that finishes the QoI (one launch less per sample; same values).  d_acc[B][5] as for
+ * mlmcpi_stats_accumulate. */
+int mlmcpi_lattice_sweep_draw_qoi_record(const mlmcpi_lattice_action *act, const double *d_src, double *d_w0, double *d_w1,
+                                         uint32_t B, uint32_t n_overrelax, uint32_t n_heatbath, uint64_t seed, uint32_t chain0,
+                                         uint32_t sweep0, uint32_t fuse, int32_t qoi_kind, double *d_qoi, double *d_acc,
+                                         int32_t *result_in, void *stream);
 /* Action::copy_from_fine / copy_from_coarse between a lattice and its next-coarser level, coarsening
  * factors rt, rx in {1, 2} in the temporal / spatial direction (CoarsenBoth = 2,2; CoarsenTemporal = 2,1;
  * CoarsenSpatial = 1,2; lattice/lattice2d.cc:24-47).  `fine` describes the FINE lattice.

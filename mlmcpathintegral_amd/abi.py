@@ -97,6 +97,7 @@ SIGNATURES = {
     "mlmcpi_gff_twolevel_workspace_bytes": (_i, [_vp, _u32, _vp]),
     "mlmcpi_gff_twolevel_draw": (_i, [_vp, _vp, _vp, _vp, _u32, _u64, _u32, _u32, _vp, _vp, _vp, _vp]),
     "mlmcpi_lattice_sweep_draw_qoi": (_i, [_LA, _vp, _vp, _vp, _u32, _u32, _u32, _u64, _u32, _u32, _u32, C.c_int32, _vp, _vp, _vp]),
+    "mlmcpi_lattice_sweep_draw_qoi_record": (_i, [_LA, _vp, _vp, _vp, _u32, _u32, _u32, _u64, _u32, _u32, _u32, C.c_int32, _vp, _vp, _vp, _vp]),
     "mlmcpi_lattice_sweep_draw_from": (_i, [_LA, _vp, _vp, _vp, _u32, _u32, _u32, _u64, _u32, _u32, _u32, _vp, _vp]),
     "mlmcpi_lattice_sweep_draw_pingpong": (_i, [_LA, _vp, _vp, _u32, _u32, _u32, _u64, _u32, _u32, _u32,
                                                 C.POINTER(C.c_int32), _vp]),

@@ -49,6 +49,7 @@ struct Tuning {
   bool or_patch = false;                         // MLMCPI_OR_KERNEL=patch: 2 x 2 register blocks on 64 x 32 tiles instead of 4 x 4 on 64 x 64
   uint32_t or_threads = 0;                       // MLMCPI_OR_THREADS (LDS-resident kernel's workgroup size; 0: default)
   bool or_heat_split = false;                    // MLMCPI_OR_HEAT=split: the heat-bath sweep behind the last overrelaxation launch gets a launch of its own
+  int or_heat_wide = 0;                          // MLMCPI_OR_HEAT=wide|narrow: 1024-thread workgroups for the fused launch (+1 / -1; 0: by the number of tiles)
 };
 Tuning tuning();  // a copy taken under the lock: callers snapshot it once per call
 
@@ -56,6 +57,7 @@ Tuning tuning();  // a copy taken under the lock: callers snapshot it once per c
 // current device: built and uploaded on first use (device_common.hpp, runtime.hip).
 int vs_table_device(double scale, const uint32_t **d_table);
 
+constexpr uint32_t kComputeUnits = 256;  // MI355X
 constexpr uint32_t kMaxFuse = 16;  // max sweeps fused in one launch (kinds travel in a bitmask)
 
 }  // namespace mlmcpi

@@ -632,6 +632,10 @@ __device__ __forceinline__ void or_block_sweeps(double *lds, const double2 *__re
   static_assert(2 * KS <= H, "a sweep costs two sites of halo");
   auto pl = [&](int p) { return lds + p * NP; };
   const uint32_t tid = threadIdx.x;
+  if (tid >= (uint32_t)G::NT) {  // waves beyond the blocks (a caller with a wider workgroup): only the barriers
+    for (int i = 0; i < 1 + 4 * KS; ++i) __syncthreads();
+    return;
+  }
   const bool active = tid < NP;
   const int pj = active ? (int)tid / NPX : 0, pi = active ? (int)tid - pj * NPX : 0;
   const int me = active ? (int)tid : 0;  // idle threads of the last wave: every index is entry 0, nothing is written
@@ -831,14 +835,16 @@ struct OrHeatGeom {
   static constexpr size_t lds_bytes = G::lds_bytes > hb_bytes ? G::lds_bytes : hb_bytes;
 };
 
-template <int K>
-__global__ void __launch_bounds__(OrHeatGeom<K>::NT, 4)
+// WIDE: 1024 threads per workgroup, for launches with at most one workgroup per CU (few chains): the register-block part
+// runs on the first OrHeatGeom<K>::NT threads as before, the heat-bath part on all sixteen waves.
+template <int K, bool WIDE = false>
+__global__ void __launch_bounds__(WIDE ? 1024 : OrHeatGeom<K>::NT, 4)
     schwinger_or_heat_kernel(uint32_t Mt, uint32_t Mx, double beta, const double2 *__restrict__ in, double2 *__restrict__ out,
                              uint32_t tiles_x, RngKey key0, int qoi_op, double *__restrict__ qoi_partial,
                              const uint32_t *__restrict__ vs_table) {
   using OH = OrHeatGeom<K>;
   using G = typename OH::G;
-  constexpr int NT = OH::NT, TW = G::TW, TH = G::TH, PW = G::PW, PH = G::PH, H = G::H, NPX = G::NPX, NP = G::NP;
+  constexpr int NT = WIDE ? 1024 : OH::NT, TW = G::TW, TH = G::TH, PW = G::PW, PH = G::PH, H = G::H, NPX = G::NPX, NP = G::NP;
   constexpr int HB = OH::HB, IW = OH::IW, IH = OH::IH, O = H - HB;  // image (0, 0) = buffer (O, O)
   extern __shared__ double lds[];
   __shared__ double qoi_red[NT / kWave];
@@ -1568,15 +1574,28 @@ __global__ void __launch_bounds__(256) schwinger_reduce_band_kernel(uint32_t Mt,
 }
 
 __global__ void __launch_bounds__(256) lattice_finish_kernel(const double *__restrict__ partial, uint32_t nsplit, uint32_t B,
-                                                              int op, double scale, double *__restrict__ out) {
+                                                              int op, double scale, double *__restrict__ out,
+                                                              double *__restrict__ acc = nullptr) {
   // one wave per chain: lane l sums partials l, l + 64, ... in order, then a fixed shuffle tree -- the result depends on
-  // nsplit only, never on the launch
+  // nsplit only, never on the launch.  acc != NULL: stats->record_sample of the value as well (stats_accumulate_kernel's
+  // recurrence), for callers that would launch that next.
   const uint32_t b = blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64, lane = threadIdx.x % 64;
   if (b >= B) return;
   double s = 0.0;
   for (uint32_t k = lane; k < nsplit; k += 64) s += partial[(size_t)b * nsplit + k];
   for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-  if (lane == 0) out[b] = (op == L_CHARGE) ? (1. / (4. * kPi * kPi)) * s * s : scale * s;  // qoi2dsusceptibility.cc:26
+  if (lane == 0) {
+    const double v = (op == L_CHARGE) ? (1. / (4. * kPi * kPi)) * s * s : scale * s;  // qoi2dsusceptibility.cc:26
+    out[b] = v;
+    if (acc) {
+      double *a = acc + 5 * (size_t)b;
+      a[0] += 1.0;
+      a[1] += v;
+      a[2] += v * v;
+      a[3] += v * v * v;
+      a[4] += v * v * v * v;
+    }
+  }
 }
 
 // gffaction.cc:80-94
@@ -1914,7 +1933,8 @@ static int init_sweep_kernels() {
   MLMCPI_HIP_TRY(hipFuncSetAttribute((const void *)schwinger_or_block_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)OrBlockGeom<5>::lds_bytes));
   MLMCPI_HIP_TRY(hipFuncSetAttribute((const void *)schwinger_or_block_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)OrBlockGeom<6>::lds_bytes));
 #define MLMCPI_OR_HEAT_ATTR(KK) \
-  MLMCPI_HIP_TRY(hipFuncSetAttribute((const void *)schwinger_or_heat_kernel<KK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)OrHeatGeom<KK>::lds_bytes)); \
+  MLMCPI_HIP_TRY(hipFuncSetAttribute((const void *)schwinger_or_heat_kernel<KK, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)OrHeatGeom<KK>::lds_bytes)); \
+  MLMCPI_HIP_TRY(hipFuncSetAttribute((const void *)schwinger_or_heat_kernel<KK, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)OrHeatGeom<KK>::lds_bytes)); \
   MLMCPI_HIP_TRY(hipFuncSetAttribute((const void *)gff_or_heat_kernel<KK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GffHeatGeom<KK>::lds_bytes))
   MLMCPI_OR_HEAT_ATTR(1); MLMCPI_OR_HEAT_ATTR(2); MLMCPI_OR_HEAT_ATTR(3); MLMCPI_OR_HEAT_ATTR(4); MLMCPI_OR_HEAT_ATTR(5);
 #undef MLMCPI_OR_HEAT_ATTR
@@ -1983,7 +2003,8 @@ int mlmcpi_lattice_initialise(const mlmcpi_lattice_action *act, double *d_phi, u
 // has to be a launch of schwinger_sweep_kernel, i.e. the draw must end with a heat-bath sweep), into d_qoi[b].
 static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, double *d_w0, double *d_w1, uint32_t B,
                            uint32_t n_overrelax, uint32_t n_heatbath, uint64_t seed, uint32_t chain0, uint32_t sweep0,
-                           uint32_t fuse, int32_t *result_in, void *stream, int qoi_kind = 0, double *d_qoi = nullptr) {
+                           uint32_t fuse, int32_t *result_in, void *stream, int qoi_kind = 0, double *d_qoi = nullptr,
+                           double *d_acc = nullptr) {
   if (int rc = check_lattice(act)) return rc;
   if (qoi_kind) {
     MLMCPI_REQUIRE(d_qoi && qoi_kind >= 1 && qoi_kind <= 3, "bad QoI arguments");
@@ -2061,7 +2082,10 @@ static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, doub
             if (int rcs = scratch((size_t)B * bgrid.x * sizeof(double), &partial, st)) return rcs;
           const int op = !with_qoi ? 0 : qoi_kind == 1 ? (int)L_PLAQ : (int)L_CHARGE;
           const RngKey hkey = make_key(seed, chain0, sweep0 + s + n);
-#define MLMCPI_OR_HEAT(KK) hipLaunchKernelGGL((schwinger_or_heat_kernel<KK>), bgrid, dim3(OrHeatGeom<KK>::NT), OrHeatGeom<KK>::lds_bytes, st, act->Mt, act->Mx, act->beta, in2, out2, act->Mt / 64, hkey, op, (double *)partial, vs_table)
+          // at most one workgroup per CU: sixteen waves for the heat-bath part (bit-identical; MLMCPI_OR_HEAT=wide|narrow forces)
+          const bool wide = tune.or_heat_wide ? tune.or_heat_wide > 0 : (uint64_t)bgrid.x * B <= kComputeUnits;
+#define MLMCPI_OR_HEAT_W(KK, WW) hipLaunchKernelGGL((schwinger_or_heat_kernel<KK, WW>), bgrid, dim3(WW ? 1024 : OrHeatGeom<KK>::NT), OrHeatGeom<KK>::lds_bytes, st, act->Mt, act->Mx, act->beta, in2, out2, act->Mt / 64, hkey, op, (double *)partial, vs_table)
+#define MLMCPI_OR_HEAT(KK) do { if (wide) MLMCPI_OR_HEAT_W(KK, true); else MLMCPI_OR_HEAT_W(KK, false); } while (0)
           switch (n) {
             case 1: MLMCPI_OR_HEAT(1); break;
             case 2: MLMCPI_OR_HEAT(2); break;
@@ -2070,10 +2094,11 @@ static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, doub
             default: MLMCPI_OR_HEAT(5);
           }
 #undef MLMCPI_OR_HEAT
+#undef MLMCPI_OR_HEAT_W
           MLMCPI_LAUNCH_CHECK("schwinger_or_heat_kernel");
           if (with_qoi) {
             hipLaunchKernelGGL(lattice_finish_kernel, dim3((B + 3) / 4), dim3(256), 0, st, (const double *)partial, bgrid.x, B, op,
-                               1.0 / ((double)act->Mx * act->Mt), d_qoi);
+                               1.0 / ((double)act->Mx * act->Mt), d_qoi, d_acc);
             MLMCPI_LAUNCH_CHECK("lattice_finish_kernel");
           }
           advance();
@@ -2153,7 +2178,7 @@ static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, doub
           MLMCPI_LAUNCH_CHECK("gff_or_heat_kernel");
           if (with_qoi) {
             hipLaunchKernelGGL(lattice_finish_kernel, dim3((B + 3) / 4), dim3(256), 0, st, (const double *)partial, bgrid.x, B, op,
-                               1.0 / ((double)act->Mx * act->Mt), d_qoi);
+                               1.0 / ((double)act->Mx * act->Mt), d_qoi, d_acc);
             MLMCPI_LAUNCH_CHECK("lattice_finish_kernel");
           }
           advance();
@@ -2208,7 +2233,7 @@ static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, doub
                 : launch_sweep<false, true>(g, grid, st, act->Mt, act->Mx, gff_mu2(*act), src, dst, n, kinds, key, op, (double *)partial);
       if (rc) return rc;
       hipLaunchKernelGGL(lattice_finish_kernel, dim3((B + 3) / 4), dim3(256), 0, st, (const double *)partial, grid.x, B, op,
-                         1.0 / ((double)act->Mx * act->Mt), d_qoi);
+                         1.0 / ((double)act->Mx * act->Mt), d_qoi, d_acc);
       MLMCPI_LAUNCH_CHECK("lattice_finish_kernel");
     } else if (schw)
       rc = kinds ? launch_sweep<true, true>(g, grid, st, act->Mt, act->Mx, act->beta, src, dst, n, kinds, key)
@@ -2260,6 +2285,16 @@ int mlmcpi_lattice_sweep_draw_qoi(const mlmcpi_lattice_action *act, const double
   MLMCPI_REQUIRE(qoi_kind >= 1 && qoi_kind <= 3, "qoi_kind %d: 1 = average plaquette, 2 = Q^2 / (4 pi^2), 3 = phi^2 (GFF)", qoi_kind);
   return sweep_draw_impl(act, const_cast<double *>(d_src), d_w0, d_w1, B, n_overrelax, n_heatbath, seed, chain0, sweep0, fuse,
                          result_in, stream, qoi_kind, d_qoi);
+}
+
+int mlmcpi_lattice_sweep_draw_qoi_record(const mlmcpi_lattice_action *act, const double *d_src, double *d_w0, double *d_w1,
+                                         uint32_t B, uint32_t n_overrelax, uint32_t n_heatbath, uint64_t seed, uint32_t chain0,
+                                         uint32_t sweep0, uint32_t fuse, int32_t qoi_kind, double *d_qoi, double *d_acc,
+                                         int32_t *result_in, void *stream) {
+  MLMCPI_REQUIRE(result_in && d_acc, "result_in or d_acc is NULL");
+  MLMCPI_REQUIRE(qoi_kind >= 1 && qoi_kind <= 3, "qoi_kind %d: 1 = average plaquette, 2 = Q^2 / (4 pi^2), 3 = phi^2 (GFF)", qoi_kind);
+  return sweep_draw_impl(act, const_cast<double *>(d_src), d_w0, d_w1, B, n_overrelax, n_heatbath, seed, chain0, sweep0, fuse,
+                         result_in, stream, qoi_kind, d_qoi, d_acc);
 }
 
 int mlmcpi_qoi_phi_squared(const double *d_phi, uint32_t n_vertices, uint32_t B, double *d_out, void *stream) {

@@ -95,7 +95,8 @@ bool apply_option(Tuning &t, const char *name, const char *value) {
   }
   if (n == "MLMCPI_OR_HEAT") {
     t.or_heat_split = v == "split";
-    return v.empty() || v == "split" || v == "fused";
+    t.or_heat_wide = v == "wide" ? 1 : v == "narrow" ? -1 : 0;
+    return v.empty() || v == "split" || v == "fused" || v == "wide" || v == "narrow";
   }
   if (n == "MLMCPI_OR_THREADS") {
     const unsigned x = (unsigned)atoi(v.c_str());

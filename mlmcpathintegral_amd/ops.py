@@ -281,13 +281,19 @@ def lattice_sweep_draw_pingpong(act, a, b, n_overrelax, n_heatbath, seed, chain0
     return (b, a) if flag.value else (a, b)
 
 
-def lattice_sweep_draw_qoi(act, src, w0, w1, n_overrelax, n_heatbath, seed, chain0, sweep0, qoi_kind, fuse=0):
+def lattice_sweep_draw_qoi(act, src, w0, w1, n_overrelax, n_heatbath, seed, chain0, sweep0, qoi_kind, fuse=0, acc=None):
     """draw + QoI in one pass (mlmcpi_lattice_sweep_draw_qoi): reads `src` (w1 may be src), returns (result tensor, the
-    other work tensor, qoi [B]); qoi_kind 1 = average plaquette, 2 = Q^2 / (4 pi^2)"""
+    other work tensor, qoi [B]); qoi_kind 1 = average plaquette, 2 = Q^2 / (4 pi^2).  acc [B, 5]: record_sample of the QoI
+    as well, in the same call (mlmcpi_lattice_sweep_draw_qoi_record)."""
     where = C.c_int32(0)
     q = torch.empty(src.shape[0], dtype=torch.float64, device=src.device)
-    abi.call("mlmcpi_lattice_sweep_draw_qoi", C.byref(act), _p(src), _p(w0), _p(w1), src.shape[0], n_overrelax, n_heatbath, seed,
-             chain0, sweep0, fuse, qoi_kind, _p(q), C.byref(where), _stream())
+    if acc is None:
+        abi.call("mlmcpi_lattice_sweep_draw_qoi", C.byref(act), _p(src), _p(w0), _p(w1), src.shape[0], n_overrelax, n_heatbath, seed,
+                 chain0, sweep0, fuse, qoi_kind, _p(q), C.byref(where), _stream())
+    else:
+        assert acc.shape == (src.shape[0], 5) and acc.dtype == torch.float64 and acc.is_contiguous()
+        abi.call("mlmcpi_lattice_sweep_draw_qoi_record", C.byref(act), _p(src), _p(w0), _p(w1), src.shape[0], n_overrelax, n_heatbath,
+                 seed, chain0, sweep0, fuse, qoi_kind, _p(q), _p(acc), C.byref(where), _stream())
     return (w0, w1, q) if where.value == 0 else (w1, w0, q)
 
 

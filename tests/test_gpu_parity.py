@@ -575,6 +575,27 @@ def test_overrelaxation_and_heat_bath_in_one_launch_equal_two_launches(gpu_ops, 
         abi.set_option("MLMCPI_OR_HEAT", "sideways")
 
 
+@pytest.mark.parametrize("Mt,Mx,B", [(128, 128, 2), (256, 192, 3), (1024, 1024, 1)])
+def test_wide_workgroups_of_the_fused_launch_change_nothing(gpu_ops, Mt, Mx, B):
+    """Launches with at most one workgroup per CU give the heat-bath part of schwinger_or_heat_kernel sixteen waves
+    (1024-thread workgroups; the register-block part stays on its 7 or 8): same draws, bit for bit, at every depth."""
+    from mlmcpathintegral_amd import abi
+    act = abi.lattice_action(abi.SCHWINGER, Mt, Mx, beta=1.0)
+    x0 = gpu_ops.lattice_initialise(act, B, SEED, 4)
+    for n_or, n_hb in ([(1, 1), (2, 1), (3, 1), (4, 2), (5, 1), (10, 1)] if Mt < 1024 else [(10, 1)]):
+        res = {}
+        for mode in ("narrow", "wide", ""):
+            abi.set_option("MLMCPI_OR_HEAT", mode)
+            try:
+                src = x0.clone()
+                x, _, q = gpu_ops.lattice_sweep_draw_qoi(act, src, torch.empty_like(src), src, n_or, n_hb, SEED, 4, 17, 1)
+                res[mode] = (x.clone(), q.clone())
+            finally:
+                abi.set_option("MLMCPI_OR_HEAT", "")
+        assert torch.equal(res["narrow"][0], res["wide"][0]) and torch.equal(res["narrow"][0], res[""][0]), f"({n_or},{n_hb})"
+        assert_close(res["wide"][1].cpu().numpy(), res["narrow"][1].cpu().numpy(), tol=1e-13, what="QoI")
+
+
 @pytest.mark.parametrize("M,B,mass", [(128, 3, 3.0), (192, 2, 10.0), (512, 2, 10.0)])
 def test_gff_overrelaxation_and_heat_bath_in_one_launch_equal_two_launches(gpu_ops, M, B, mass):
     """gff_or_heat_kernel<K> against the two launches it replaces (MLMCPI_OR_HEAT=split): field bit for bit, phi^2 to rounding."""
@@ -985,6 +1006,32 @@ def test_fused_qoi_equals_separate_evaluation(gpu_ops, Mt, Mx, B, n_or, n_hb):
         gpu_ops.lattice_sweep_draw_qoi(act, x0, torch.empty_like(x0), x0.clone(), 2, 0, SEED, 3, 11, 1)
     with pytest.raises(abi.MlmcpiError):  # phi^2 is the GFF's QoI
         gpu_ops.lattice_sweep_draw_qoi(act, x0, torch.empty_like(x0), x0.clone(), n_or, n_hb, SEED, 3, 11, 3)
+
+
+@pytest.mark.parametrize("kind,M,B", [("schwinger", 256, 3), ("schwinger", 48, 2), ("gff", 128, 2)])
+def test_draw_qoi_record_in_one_call_equals_the_three_steps(gpu_ops, kind, M, B):
+    """mlmcpi_lattice_sweep_draw_qoi_record = mlmcpi_lattice_sweep_draw_qoi + mlmcpi_stats_accumulate: same sample, same
+    QoI, same per-chain moments after several samples, bit for bit (the recurrence is the same, on the same value)."""
+    from mlmcpathintegral_amd import abi
+    act = abi.lattice_action(abi.SCHWINGER, M, M, beta=1.0) if kind == "schwinger" else abi.lattice_action(abi.GFF, M, M, mass=3.0)
+    qk = 1 if kind == "schwinger" else 3
+    x0 = gpu_ops.lattice_initialise(act, B, SEED, 6)
+    out = {}
+    for mode in ("three", "one"):
+        x, w = x0.clone(), torch.empty_like(x0)
+        acc = torch.zeros((B, 5), dtype=torch.float64, device="cuda")
+        for t in range(4):
+            if mode == "one":
+                x, w, q = gpu_ops.lattice_sweep_draw_qoi(act, x, w, x, 3, 1, SEED, 6, 4 * t, qk, acc=acc)
+            else:
+                x, w, q = gpu_ops.lattice_sweep_draw_qoi(act, x, w, x, 3, 1, SEED, 6, 4 * t, qk)
+                gpu_ops.stats_accumulate(acc, q)
+        out[mode] = (x.clone(), q.clone(), acc.clone())
+    for a, b in zip(out["three"], out["one"]):
+        assert torch.equal(a, b)
+    assert float(out["one"][2][:, 0].min()) == 4.0
+    with pytest.raises(abi.MlmcpiError):   # a draw that does not end with a heat-bath sweep cannot carry the QoI
+        gpu_ops.lattice_sweep_draw_qoi(act, x0, torch.empty_like(x0), x0.clone(), 2, 0, SEED, 6, 0, qk, acc=torch.zeros((B, 5), dtype=torch.float64, device="cuda"))
 
 
 @pytest.mark.parametrize("M,B,n_or,n_hb", [(512, 3, 5, 1), (64, 2, 0, 1), (20, 2, 3, 2), (192, 2, 1, 1)])
