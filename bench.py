@@ -177,7 +177,14 @@ class SweepWorkload:
         self.or_heat = (self.blocks and a.n_heatbath == 1 and bool(self.plan) and self.plan[-1][0] <= 5
                         and size >= 128 and os.environ.get("MLMCPI_OR_HEAT", "") != "split" and not a.no_fused_qoi)
         self.or_heat_depth = self.plan[-1][0] if self.or_heat else 0
-        if self.or_heat:  # the launches that stay pure overrelaxation
+        # ... and with at most one workgroup of that launch per CU (one chain) the library puts the WHOLE draw into it
+        # (6 <= n_overrelax <= 10, default fuse; sweep_draw_impl: whole_draw)
+        whole = (self.or_heat and kind == "schwinger" and not a.fuse and 6 <= a.n_overrelax <= 10 and (size // 64) ** 2 * B <= 256
+                 and os.environ.get("MLMCPI_OR_HEAT", "") != "narrow")
+        self.whole = whole
+        if whole:
+            self.plan, self.or_heat_depth = [], a.n_overrelax
+        elif self.or_heat:  # the launches that stay pure overrelaxation
             d, n = self.plan[-1]
             self.plan = self.plan[:-1] + ([(d, n - 1)] if n > 1 else [])
         self.sweep = 0
@@ -224,7 +231,7 @@ class SweepWorkload:
             d = self.or_heat_depth  # > 0: that launch also holds the last d overrelaxation sweeps (same launches as one call)
             self.x, self.scratch, q = ops.lattice_sweep_draw_qoi(self.act, cur, oth, cur, d, a.n_heatbath, a.seed, self.chain0,
                                                                  s + a.n_overrelax - d, 1 if self.kind == "schwinger" else 3,
-                                                                 d or self.fuse)
+                                                                 0 if self.whole else (d or self.fuse))
         else:
             self.x, self.scratch = ops.lattice_sweep_draw_pingpong(self.act, cur, oth, 0, a.n_heatbath, a.seed, self.chain0,
                                                                    s + a.n_overrelax, self.fuse)

@@ -1938,6 +1938,9 @@ static int init_sweep_kernels() {
   MLMCPI_HIP_TRY(hipFuncSetAttribute((const void *)gff_or_heat_kernel<KK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GffHeatGeom<KK>::lds_bytes))
   MLMCPI_OR_HEAT_ATTR(1); MLMCPI_OR_HEAT_ATTR(2); MLMCPI_OR_HEAT_ATTR(3); MLMCPI_OR_HEAT_ATTR(4); MLMCPI_OR_HEAT_ATTR(5);
 #undef MLMCPI_OR_HEAT_ATTR
+#define MLMCPI_OR_HEAT_ATTR_W(KK) MLMCPI_HIP_TRY(hipFuncSetAttribute((const void *)schwinger_or_heat_kernel<KK, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)OrHeatGeom<KK>::lds_bytes))
+  MLMCPI_OR_HEAT_ATTR_W(6); MLMCPI_OR_HEAT_ATTR_W(7); MLMCPI_OR_HEAT_ATTR_W(8); MLMCPI_OR_HEAT_ATTR_W(9); MLMCPI_OR_HEAT_ATTR_W(10);
+#undef MLMCPI_OR_HEAT_ATTR_W
   g_lds_attr_set[dev] = true;
   return MLMCPI_OK;
 }
@@ -2019,10 +2022,16 @@ static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, doub
   // register-block kernel applies, 4 otherwise
   const Tuning tune = tuning();  // ONE snapshot per draw: mlmcpi_set_option on another thread cannot split a launch plan
   const bool or_blocks = !tune.or_lds && !tune.or_patch && !tune.tile_w && act->Mt % 64 == 0 && act->Mx % 64 == 0;
-  if (fuse == 0) fuse = or_blocks ? 6 : 4;
+  const bool schw = act->kind == MLMCPI_SCHWINGER;
+  // One chain (at most one workgroup of the fused launch per CU: nothing to overlap a second launch's load and store
+  // phases with): the whole draw in ONE launch of schwinger_or_heat_kernel<n_overrelax, wide> while its halo fits a
+  // workgroup (n_overrelax <= 10) -- the library default only; a caller's `fuse` is kept.
+  const bool whole_draw = fuse == 0 && schw && or_blocks && !tune.or_heat_split && tune.or_heat_wide >= 0 && n_heatbath >= 1 &&
+                          n_overrelax >= 6 && n_overrelax <= 10 && 2. * act->beta <= kVsKappaMax && act->Mt >= 128 && act->Mx >= 128 &&
+                          (uint64_t)(act->Mt / 64) * (act->Mx / 64) * B <= kComputeUnits;
+  if (fuse == 0) fuse = whole_draw ? n_overrelax : or_blocks ? 6 : 4;
   if (fuse > kMaxFuse) fuse = kMaxFuse;
   hipStream_t st = as_stream(stream);
-  const bool schw = act->kind == MLMCPI_SCHWINGER;
   const uint32_t total = n_overrelax + n_heatbath;
   const size_t state_bytes = (size_t)B * act->Mt * act->Mx * (schw ? 16 : 8);
   if (int rc = init_sweep_kernels()) return rc;
@@ -2059,7 +2068,7 @@ static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, doub
     const RngKey key = make_key(seed, chain0, sweep0 + s);
     dim3 grid(g.tg.tiles_x * g.tiles_y, B);
     int rc;
-    if (schw && !kinds && !g.overridden && act->Mt % 64 == 0 && act->Mx % 32 == 0 && n <= 6) {
+    if (schw && !kinds && !g.overridden && act->Mt % 64 == 0 && act->Mx % 32 == 0 && (n <= 6 || whole_draw)) {
       // specialised overrelaxation kernel (bit-identical to the generic one)
       const size_t lds = (size_t)2 * (32 + 4 * n) * (64 + 4 * n + 1) * sizeof(double);
       dim3 sgrid((act->Mt / 64) * (act->Mx / 32), B);
@@ -2072,7 +2081,7 @@ static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, doub
         dim3 bgrid((act->Mt / 64) * (act->Mx / 64), B);
         // the last overrelaxation launch of the draw takes the heat-bath sweep behind it along (and the QoI, if that is
         // the draw's last sweep): schwinger_or_heat_kernel, bit-identical to the two launches (MLMCPI_OR_HEAT=split)
-        if (!tune.or_heat_split && s + n == n_overrelax && n_heatbath >= 1 && n <= 5 && 2. * act->beta <= kVsKappaMax &&
+        if (!tune.or_heat_split && s + n == n_overrelax && n_heatbath >= 1 && (n <= 5 || whole_draw) && 2. * act->beta <= kVsKappaMax &&
             act->Mt >= 128 && act->Mx >= 128) {
           const uint32_t *vs_table = nullptr;
           if (int rcv = vs_table_device(2. * act->beta, &vs_table)) return rcv;
@@ -2091,7 +2100,12 @@ static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, doub
             case 2: MLMCPI_OR_HEAT(2); break;
             case 3: MLMCPI_OR_HEAT(3); break;
             case 4: MLMCPI_OR_HEAT(4); break;
-            default: MLMCPI_OR_HEAT(5);
+            case 5: MLMCPI_OR_HEAT(5); break;
+            case 6: MLMCPI_OR_HEAT_W(6, true); break;  // whole_draw (wide workgroups only)
+            case 7: MLMCPI_OR_HEAT_W(7, true); break;
+            case 8: MLMCPI_OR_HEAT_W(8, true); break;
+            case 9: MLMCPI_OR_HEAT_W(9, true); break;
+            default: MLMCPI_OR_HEAT_W(10, true);
           }
 #undef MLMCPI_OR_HEAT
 #undef MLMCPI_OR_HEAT_W
