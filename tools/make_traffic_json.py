@@ -60,7 +60,7 @@ for w, e in S.items():
         if "or_patch_kernel<" in short or "or_block_kernel<" in short:
             fuse = int(short.split("<")[1].split(">")[0])
         if "or_heat_kernel<" in short:
-            fuse = int(short.split("<")[1].split(">")[0]) + 1
+            fuse = int(short.split("<")[1].split(">")[0].split(",")[0]) + 1   # <K> or <K, wide>
         if kind and w in ("schwinger", "gff", "rotor_sweep"):
             if "hbm_bytes_per_launch" in k:
                 out["entries"].append({"workload": w, "size": SIZES[w], "chains": CHAINS[w], "fuse": fuse, "kind": kind, "kernel": short,

@@ -2,6 +2,10 @@
 # Round profile: per workload one `rocprofv3 --kernel-trace --stats` run of bench.py, one SQ counter pass, and (sweep
 # workloads) the two TCC passes for HBM traffic.  Every --pmc pass is on its own beside --kernel-trace only; the program
 # goes directly after `--`.  Output: gpurun_out/prof_<tag>/<workload>/{stats,sq,mix1,mix2,FETCH_SIZE,WRITE_SIZE}
+# The eight workloads do not fit one gpurun call comfortably: run WORKLOADS="schwinger gff rotor_sweep" with tag T and the
+# rest with tag Tb (two gpurun calls), then merge Tb's summary.json and *_kernel_stats.csv into gpurun_out/prof_T/ (json
+# dict update; tools/make_traffic_json.py reads that directory).  Do NOT re-run profile_summarise.py afterwards: the raw
+# traces are deleted at the end of this script and it would write an empty summary.
 set -o pipefail
 TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:?}
