@@ -294,3 +294,22 @@ def test_schwinger_beta_coarse_nonperturbative(beta, n_plaq, rho):
     # to O(1 / beta) the matched coupling is the perturbative one (quenchedschwingerrenormalisation.hh:84-104)
     pert = (1.0 / rho) * (1.0 + (1.5 if rho == 4 else 0.5) / beta) * beta
     assert abs(bc.value - pert) < 2.5 / beta * pert, (bc.value, pert)
+
+
+def test_tuning_options_are_checked_by_name_and_value():
+    """mlmcpi_set_option (host code; the knobs never change results): every documented knob with every documented value is
+    accepted, anything else is MLMCPI_ERR_INVALID with a message -- a typo in a benchmark's environment must not be a
+    silent no-op at run time."""
+    from mlmcpathintegral_amd import abi
+    good = {"MLMCPI_SWEEP_TILE": ["64x32x256", "128x64x512", ""], "MLMCPI_OR_KERNEL": ["block", "patch", "lds", ""],
+            "MLMCPI_OR_THREADS": ["256", "512", "1024", ""], "MLMCPI_OR_HEAT": ["fused", "split", "wide", "narrow", ""]}
+    for name, values in good.items():
+        for v in values:
+            abi.set_option(name, v)
+    for name, v in (("MLMCPI_OR_HEAT", "sideways"), ("MLMCPI_OR_KERNEL", "blocks"), ("MLMCPI_SWEEP_TILE", "63x32x256"),
+                    ("MLMCPI_SWEEP_TILE", "64x32x100"), ("MLMCPI_OR_THREADS", "300"), ("MLMCPI_NO_SUCH_KNOB", "1")):
+        with pytest.raises(abi.MlmcpiError) as e:
+            abi.set_option(name, v)
+        assert "unknown option or value" in str(e.value)
+    for name in good:
+        abi.set_option(name, "")
