@@ -150,7 +150,11 @@ def establish(rank, world, dist, torch, make_exchange, prepare=None, agree_devic
         if float(ok.item()) != 1.0:
             print(f"[rank {rank}] statistics exchange, {stage}: {err or 'failed on another rank'}; exiting with status 3",
                   file=sys.stderr, flush=True)
-            sys.exit(3)
+            # Status 3 on EVERY rank, whatever the process group's worker threads do while the interpreter is taken down: a
+            # normal exit from here lets gloo / RCCL threads race the teardown, and now and then one of them aborts the
+            # process ("terminate called without an active exception", status 134) -- still red, but not the documented code.
+            sys.stdout.flush()
+            os._exit(3)
 
     def attempt(f):
         try:

@@ -527,7 +527,7 @@ __device__ __forceinline__ void heatbath_cells(uint32_t total, const RngKey &key
 // arithmetic at all and the accepted angle is a linear function of random bits:
 //     bins of |x|     edges (0, 1, 2, 3, 4, 6, 8, 12, 16) pi/16: eight bins, finer where the density is high;
 //     bin k is proposed with probability q_k / 64 (six random bits through a 64-entry selector), |x| uniform inside it
-//                     (46 random bits), sign from one more bit;
+//                     (35 random bits), sign from one more bit;
 //     accepted with probability  exp(kappa (cos x - 1)) 2^lw[k],   2^lw[k] = (w_k / q_k) / max_j (H_j w_j / q_j),
 // i.e. target / (proposal density x envelope constant), H_j = the target at the left edge of bin j (its maximum there).
 // The q_k follow the shape of the target, which depends on kappa; so there are kVsClasses tables, for eight ranges of
@@ -537,14 +537,18 @@ __device__ __forceinline__ void heatbath_cells(uint32_t total, const RngKey &key
 // only gets narrower).  Acceptance 0.70 ... 0.89 (0.79 on average; wrapped Cauchy: 0.82).  The tables are built by the
 // host for the action's scale (runtime.hip, vs_build_tables; exported as mlmcpi_vs_table so that the oracle's own
 // construction can be compared with it) and copied to LDS by the kernels: 512 selector bytes + 8 x 16 floats.
-// The test is screened in fp32 (24 bits of |x|, one polynomial cosine, v_exp_f32) against the 11 leading bits of u2 with a
-// guard band that covers every fp32 rounding on the way; when the band does not decide (one attempt in ~10^3), the exact
-// fp64 test with the full u2 takes over, as for the wrapped-Cauchy sampler, so the decision is always the one of the
-// exact test -- which is what the oracle computes (oracle.cc, dev_vonmises_table).  Random numbers: the same Philox
-// calls and bit fields as above (word pair = one attempt; bit 0 sign, bits 1..11 leading bits of u2, bits 12..63: six
-// selector bits on top of 46 position bits).
+// The test is screened in fp32 (24 bits of |x|, one polynomial cosine, v_exp_f32) against the kVsU2Bits = 22 leading bits of
+// u2 with a guard band that covers every fp32 rounding on the way; when the band does not decide (one attempt in ~3 10^4),
+// the exact fp64 test with the full u2 takes over, as for the wrapped-Cauchy sampler, so the decision is always the one of
+// the exact test -- which is what the oracle computes (oracle.cc, dev_vonmises_table).  (With 11 leading bits, as the
+// wrapped-Cauchy sampler has them, one attempt in 2048 was open and 4-6 % of the wave iterations took the detour through
+// the exact test -- a Philox call, an fp64 logarithm and cosine behind a function call: measured at 8 % of the fused
+// sweep launch.)  Random numbers: the same Philox calls (word pair = one attempt), fields: bit 0 sign, bits 1..22 leading
+// bits of u2, bits 23..57 position inside the bin (35 bits: 2 10^-11 rad), bits 58..63 selector.
 constexpr double kVsKappaMax = 4.0;  // host rule (lattice2d.hip / path1d.hip; the oracle applies the same): kappa_max <= 4
 constexpr int kVsClasses = 8, kVsBins = 8, kVsSel = 64;
+constexpr uint32_t kVsU2Bits = 22, kVsU2Mask = (1u << kVsU2Bits) - 1;  // leading bits of the acceptance uniform (bits 1..22 of the attempt)
+constexpr float kVsU2Scale = (float)(1u << kVsU2Bits);
 // In LDS (and in the device copy the host uploads): code[class][64], one byte per selector value = left edge of its bin
 // (low nibble) and the bin's width (high nibble), both in units of pi/16 -- an attempt needs no other decoding --, then
 // lw[class][16] floats indexed by that left edge (8 of the 16 slots are used).
@@ -600,32 +604,36 @@ __device__ __forceinline__ double vs_kappa_exact(double scale, double x_p, doubl
   return vm_clamp(scale * fabs(cos_half(x_m - x_p)));
 }
 
-// |x| of the attempt (lo, hi), fp64: (pi/16) (edge + width pos), pos = the 46 bits below the selector; code = the bin's byte
+// |x| of the attempt (lo, hi), fp64: (pi/16) (edge + width pos), pos = the 35 bits below the selector (bits 23..57); code = the bin's byte
 __device__ __forceinline__ double vs_theta(uint32_t lo, uint32_t hi, uint32_t code) {
-  // mantissa = 000000 | 46 position bits: m = 1 + pos / 64
-  const double m = __hiloint2double((int)(((hi >> 12) & 0x3FFFu) | 0x3FF00000u), (int)__builtin_amdgcn_alignbit(hi, lo, 12));
+  // mantissa = 000000 | 35 position bits | 11 zeros: m = 1 + pos / 64
+  const double m = __hiloint2double((int)(((hi >> 12) & 0x3FFFu) | 0x3FF00000u),
+                                    (int)(__builtin_amdgcn_alignbit(hi, lo, 12) & ~0x7FFu));
   const double w64 = (double)((code >> 4) << 6), e = (double)(code & 15u);
   return (kPi / 16.0) * fma(w64, m, e - w64);   // one rounding of edge + width pos, as in the oracle
 }
 
-// screening decision of one attempt: 1 accepted, 0 rejected, -1 open; the bin's code byte comes back for the caller
-__device__ __forceinline__ int vs_try(uint32_t lo, uint32_t hi, float kp, uint32_t cls, const VsTable &tab, uint32_t &code) {
+// screening decision of one attempt: accepted / rejected (neither: open); the bin's code byte comes back for the caller
+__device__ __forceinline__ void vs_try(uint32_t lo, uint32_t hi, float kp, uint32_t cls, const VsTable &tab, uint32_t &code,
+                                       bool &accepted, bool &rejected) {
   code = tab.code[cls * kVsSel + (hi >> 26)];
   const uint32_t e16 = code & 15u;
   const float posf = (float)((hi >> 2) & 0xFFFFFFu) * (1.0f / 16777216.0f);      // the leading 24 position bits
   const float c = cosf_0_pi(0.196349541f * fmaf((float)(code >> 4), posf, (float)e16));
-  // acceptance probability x 2048 (the scale of the 11 leading bits b of u2: u2 in [b, b + 1) / 2048)
-  const float a2048 = __builtin_amdgcn_exp2f(fmaf(kp, c - 1.0f, tab.lw[cls * 16 + e16] + 11.0f));
+  // acceptance probability a; u2 lies in [b, b + 1) / 2^22 with the leading bits b (exact in fp32)
+  const float a = __builtin_amdgcn_exp2f(fmaf(kp, c - 1.0f, tab.lw[cls * 16 + e16]));
   // error budget of log2(a): |x| to 24 bits (1e-7 kappa'), the cosine (1.5e-7 kappa'), kappa' itself (2e-7 kappa' from
   // the fp32 cosine behind it), the fma (1e-6 at |log2 a| <= 16): < 4e-7 (1 + kappa') in all, i.e. < 3e-7 (1 + kappa')
-  // relative on a, plus v_exp_f32's own ~2e-7.  The band is 30 times that.
-  const float band = vs_band(kp), b = (float)((lo >> 1) & 0x7FFu);
-  return b + 1.0f <= a2048 * (1.0f - band) ? 1 : (b >= a2048 * (1.0f + band) ? 0 : -1);
+  // relative on a, plus v_exp_f32's own ~2e-7.  The band is 30 times that.  (The two scaled band factors depend on the
+  // cell only: they are hoisted out of the attempt.)
+  const float band = vs_band(kp), b = (float)((lo >> 1) & kVsU2Mask);
+  accepted = b + 1.0f <= a * ((1.0f - band) * kVsU2Scale);
+  rejected = b >= a * ((1.0f + band) * kVsU2Scale);
 }
 
-// the exact test: u2 = (b + tail) / 2048 against exp(kappa (cos x - 1)) 2^lw, in logarithms
+// the exact test: u2 = (b + tail) / 2^22 against exp(kappa (cos x - 1)) 2^lw, in logarithms
 __device__ __forceinline__ int vs_exact(uint32_t lo, uint32_t hi, uint32_t code, double tail, double kappa, float lw) {
-  const double u2 = ((double)((lo >> 1) & 0x7FFu) + tail) * (1.0 / 2048.0);
+  const double u2 = ((double)((lo >> 1) & kVsU2Mask) + tail) * (1.0 / (double)(1u << kVsU2Bits));
   const double la = fma(kappa, cospi_unit(vs_theta(lo, hi, code) * (1.0 / kPi)) - 1.0, 0.69314718055994531 * (double)lw);
   return (u2 <= 0.0 || log_unit(u2) <= la) ? 1 : 0;
 }
@@ -651,18 +659,21 @@ __device__ __forceinline__ bool vs_attempt_pair(const RngKey &k, uint32_t site, 
   const uint32_t w3 = (P_VONMISES << 24) | sub0 | pair;
   const U4 q = philox4x32_10(site, k.chain, k.step, w3, k.k0, k.k1);
   uint32_t ba, bb;
-  int sa = vs_try(q.x, q.y, kp, cls, tab, ba), sb = vs_try(q.z, q.w, kp, cls, tab, bb);
-  if (sa < 0 || (sa == 0 && sb < 0)) {
+  bool acc_a, rej_a, acc_b, rej_b;  // lane masks: the decisions stay on the scalar side
+  vs_try(q.x, q.y, kp, cls, tab, ba, acc_a, rej_a);
+  vs_try(q.z, q.w, kp, cls, tab, bb, acc_b, rej_b);
+  // open: the first attempt undecided, or rejected and the second undecided
+  if (!acc_a && (!rej_a || (!acc_b && !rej_b))) {
     const uint32_t r = vs_exact_pair(k.k0, k.k1, k.chain, k.step, site, w3, q, ba | (bb << 8), tab.lw[cls * 16 + (ba & 15u)],
-                                     tab.lw[cls * 16 + (bb & 15u)], kappa_exact(), sa, sb);
-    sa = (int)(r & 3u) == 3 ? -1 : (int)(r & 3u);
-    sb = (int)(r >> 2) == 3 ? -1 : (int)(r >> 2);
+                                     tab.lw[cls * 16 + (bb & 15u)], kappa_exact(), rej_a ? 0 : -1, acc_b ? 1 : rej_b ? 0 : -1);
+    acc_a = (r & 3u) == 1u;
+    acc_b = (r >> 2) == 1u;
   }
-  const bool first = sa == 1;
+  const bool first = acc_a;
   const uint32_t lo = first ? q.x : q.z, hi = first ? q.y : q.w;
   theta = vs_theta(lo, hi, first ? ba : bb);
   negative = (lo & 1u) != 0;
-  return sa == 1 || sb == 1 || pair + 1 >= kMaxVmPairs;
+  return acc_a || acc_b || pair + 1 >= kMaxVmPairs;
 }
 
 // Retry pool of the step-envelope phases.  After the first pair of attempts ~5 % of the cells are still open.  An entry

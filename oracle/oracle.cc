@@ -291,10 +291,11 @@ inline double dev_vonmises_table(const DevRng &rng, uint32_t site, double scale,
       const uint64_t bits = ((uint64_t)hi << 32) | lo;
       int sel = (int)(hi >> 26), k = 0;
       while (sel >= T.q[cls][k]) sel -= T.q[cls][k++];
-      const double pos = (double)((bits >> 12) & ((1ull << 46) - 1)) * (1.0 / 70368744177664.0);  // 46 bits
+      // fields of an attempt: bit 0 sign, bits 1..22 the leading bits of u2, bits 23..57 position in the bin, 58..63 selector
+      const double pos = (double)((bits >> 23) & ((1ull << 35) - 1)) * (1.0 / 34359738368.0);  // 35 bits
       theta = (kPi / 16.0) * ((double)e16[k] + (double)(e16[k + 1] - e16[k]) * pos);
       negative = (lo & 1u) != 0;
-      const double u2 = ((double)((lo >> 1) & 0x7FFu) + u01(e.v[2 * h], e.v[2 * h + 1])) * (1.0 / 2048.0);
+      const double u2 = ((double)((lo >> 1) & 0x3FFFFFu) + u01(e.v[2 * h], e.v[2 * h + 1])) * (1.0 / 4194304.0);
       accepted = u2 <= 0.0 || std::log(u2) <= kappa * (std::cos(theta) - 1.0) + 0.69314718055994531 * (double)T.lw[cls][k];
     }
     if (accepted) break;

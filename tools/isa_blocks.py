@@ -4,7 +4,7 @@
 import collections, re, subprocess, sys
 src, pat = sys.argv[1], sys.argv[2]
 minv = int(sys.argv[3]) if len(sys.argv) > 3 else 30
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only"] + sys.argv[4:] + [
                        "-Iinclude", "-o", "/tmp/_isa.s", src], stderr=subprocess.DEVNULL)
 lines = open("/tmp/_isa.s").read().split("\n")
 start, funcs = None, {}
