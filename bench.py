@@ -371,16 +371,20 @@ def main():
         fuse = 1
         state = {"sweep": 0}
 
+        state.update(x=x, w=scratch)
+
         def step(record):
+            # sampler->draw, qoi->evaluate (topological susceptibility, summed while the segments of the last launch are in
+            # LDS) and stats->record_sample in one ABI call: mlmcpi_path_sweep_draw_qoi
             if record:
                 e0, e1 = ev(), ev()
                 e0.record()
-            ops.path_sweep_draw(act, x, scratch, a.n_overrelax, a.n_heatbath, a.seed, chain0, state["sweep"])
+            state["x"], state["w"], _ = ops.path_sweep_draw_qoi(act, state["x"], state["w"], state["x"], a.n_overrelax, a.n_heatbath,
+                                                                 a.seed, chain0, state["sweep"], acc=acc)
             state["sweep"] += a.n_overrelax + a.n_heatbath
             if record:
                 e1.record()
                 events.append((e0, e1))
-            ops.stats_accumulate(acc, ops.qoi_susceptibility(x, size / 8.0))
         for _ in range(a.thermalise):
             step(False)
         acc_of = lambda: acc
@@ -559,12 +563,15 @@ def main():
             report_sweeps(result, a, W, size, B, world, step_ms, ms)
         elif a.workload == "rotor_sweep":
             launch_ms = ms(events) / a.steps
-            floor = 16.0 * size * B * (1 + (a.n_overrelax + 7) // 8)  # one read + one write of the state per launch
+            # one read + one write of the state per launch; the heat-bath sweep rides on the last overrelaxation launch when
+            # that holds fewer than 8 sweeps (path_sweep_impl), the QoI on the last launch of the draw
+            split = os.environ.get("MLMCPI_OR_HEAT", "") == "split" or a.n_overrelax % 8 == 0
+            floor = 16.0 * size * B * ((a.n_overrelax + 7) // 8 + (a.n_heatbath if split else max(0, a.n_heatbath - 1)))
             result["config"] = {"workload": f"rotor M_lat={size}, {a.n_overrelax} overrelaxation + {a.n_heatbath} heat-bath "
                                             "sweeps per step, even/odd order", "chains_per_gpu": B, "chains_total": B * world,
                                 "parallelism": f"chains sharded over {world} GPU(s), no data-path collective"}
             result["roofline"] = register_resident_roofline(
-                "rotor_sweep_kernel<true> + rotor_sweep_kernel<false> (all sweeps of a step)", launch_ms, floor,
+                "rotor_sweep_kernel<false> + rotor_sweep_kernel<true,true> (all sweeps of a step, QoI and record_sample)", launch_ms, floor,
                 16.0 * units_per_step, pmc_entry("kernels_valu_busy", workload=a.workload, size=size, chains=B),
                 "overrelaxation sweeps are fused 8 per launch on LDS-resident segments; the heat-bath sweep is "
                 "VALU bound (von Mises sampler)")

@@ -252,6 +252,15 @@ public:
           "path_sweep_draw_from");
     return where;
   }
+  /** kind 4 = QoISusceptibility, summed inside the draw's last launch (and recorded into d_acc, if given) */
+  int sweep_from_qoi(const double *d_src, double *d_w0, double *d_w1, unsigned batch, unsigned n_or, unsigned n_hb, uint32_t sweep0,
+                     int qoi_kind, double *d_q, double *d_acc = nullptr) override {
+    if (qoi_kind != 4 || n_or + n_hb == 0) return -1;
+    int32_t where = 0;
+    check(mlmcpi_path_sweep_draw_qoi(&abi, d_src, d_w0, d_w1, batch, n_or, n_hb, seed, chain0, sweep0, d_q, d_acc, &where, nullptr),
+          "path_sweep_draw_qoi");
+    return where;
+  }
   /** rotoraction.hh:195-213 */
   double getWcurvature(const double x_m, const double x_p) const { return 2.0 * m0 / a_lat * std::fabs(std::cos(0.5 * (x_p - x_m))); }
   double getWminimum(const double x_m, const double x_p) const {

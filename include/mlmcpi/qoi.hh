@@ -57,6 +57,7 @@ public:
     if (x->size() != M_lat) fatal("Evaluating QoISusceptibility on path of wrong size.");
     check(mlmcpi_qoi_susceptibility(x->device(), M_lat, T_final, x->batch(), d_out, nullptr), "qoi_susceptibility");
   }
+  int fused_kind() const override { return 4; }  // mlmcpi_path_sweep_draw_qoi (rotor sweeps)
 private:
   const unsigned int M_lat;
   const double T_final;

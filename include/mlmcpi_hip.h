@@ -150,6 +150,14 @@ int mlmcpi_path_sweep_draw(const mlmcpi_path_action *act, double *d_x, double *d
 int mlmcpi_path_sweep_draw_from(const mlmcpi_path_action *act, const double *d_src, double *d_w0, double *d_w1, uint32_t B,
                                 uint32_t n_overrelax, uint32_t n_heatbath, uint64_t seed, uint32_t chain0, uint32_t sweep0,
                                 int32_t *result_in, void *stream);
+/* mlmcpi_path_sweep_draw_from with the topological susceptibility of the new sample (QoISusceptibility,
+ * qoi/qm/qoisusceptibility.cc:8-23: chi = Q^2 / T, Q = sum_j mod_2pi(x_j - x_{j-1}) / 2 pi) summed inside the draw's last
+ * launch, while the segments are in LDS: d_qoi[b]; and, with d_acc != NULL, stats->record_sample of it into d_acc[B][5] in
+ * the same call (mlmcpi_stats_accumulate's recurrence): one pass of the loop at montecarlo/montecarlosinglelevel.cc:59-77.
+ * Same value as mlmcpi_qoi_susceptibility on the result up to the order of the summation. */
+int mlmcpi_path_sweep_draw_qoi(const mlmcpi_path_action *act, const double *d_src, double *d_w0, double *d_w1, uint32_t B,
+                               uint32_t n_overrelax, uint32_t n_heatbath, uint64_t seed, uint32_t chain0, uint32_t sweep0,
+                               double *d_qoi, double *d_acc, int32_t *result_in, void *stream);
 
 /* Action::heatbath_update / overrelaxation_update(state, l) (action/action.hh:73-96; rotoraction.cc:20-56): the update of
  * site l for every chain of the batch -- of the n sites d_sites[0 .. n) (device memory) in list order when d_sites is not

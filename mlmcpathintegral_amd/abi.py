@@ -64,6 +64,7 @@ SIGNATURES = {
     "mlmcpi_path_hmc_run_layout": (_i, [_PA, _u32, _u32, C.POINTER(C.c_int32)]),
     "mlmcpi_path_sweep_draw": (_i, [_PA, _vp, _vp, _u32, _u32, _u32, _u64, _u32, _u32, _vp]),
     "mlmcpi_path_sweep_draw_from": (_i, [_PA, _vp, _vp, _vp, _u32, _u32, _u32, _u64, _u32, _u32, _vp, _vp]),
+    "mlmcpi_path_sweep_draw_qoi": (_i, [_PA, _vp, _vp, _vp, _u32, _u32, _u32, _u64, _u32, _u32, _vp, _vp, _vp, _vp]),
     "mlmcpi_path_twolevel_workspace_bytes": (_i, [_PA, _u32, C.POINTER(_sz)]),
     "mlmcpi_path_twolevel_draw": (_i, [_PA, _PA, _vp, _vp, _u32, _u64, _u32, _u32, _vp, _vp, _vp, _vp]),
     "mlmcpi_path_twolevel_draw_masked": (_i, [_PA, _PA, _vp, _vp, _u32, _u64, _u32, _u32, _vp, _vp, _vp, _vp, _vp]),

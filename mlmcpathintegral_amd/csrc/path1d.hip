@@ -107,13 +107,22 @@ __global__ void __launch_bounds__(256) path_reduce_kernel(PathP P, const double 
 
 // out[b] = finish(sum_s partial[b][s]); one thread per chain, fixed summation order
 __global__ void path_finish_kernel(const double *__restrict__ partial, uint32_t nsplit, uint32_t B, int op,
-                                   double scale, double *__restrict__ out) {
+                                   double scale, double *__restrict__ out, double *__restrict__ acc = nullptr) {
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   double s = 0.0;
   for (uint32_t k = 0; k < nsplit; ++k) s += partial[(size_t)b * nsplit + k];
   // R_WINDING: chi = Q^2 / (4 pi^2 T)  (qoisusceptibility.cc:20-22); others: scale * sum
-  out[b] = (op == R_WINDING) ? (1. / (4. * kPi * kPi)) * (s * s) * scale : scale * s;
+  const double v = (op == R_WINDING) ? (1. / (4. * kPi * kPi)) * (s * s) * scale : scale * s;
+  out[b] = v;
+  if (acc) {  // stats->record_sample of the value as well (the recurrence of stats_accumulate_kernel)
+    double *a = acc + 5 * (size_t)b;
+    a[0] += 1.0;
+    a[1] += v;
+    a[2] += v * v;
+    a[3] += v * v * v;
+    a[4] += v * v * v * v;
+  }
 }
 
 template <int KIND>
@@ -486,9 +495,13 @@ __global__ void __launch_bounds__(256) path_transfer_kernel(uint32_t Mc, double 
 template <bool HEAT, bool STEP = false>
 __global__ void __launch_bounds__(256)
     rotor_sweep_kernel(PathP P, const double *__restrict__ in, double *__restrict__ out, uint32_t owned_len,
-                       uint32_t nsweeps, uint32_t kinds, RngKey key0, uint32_t pool_cap, const uint32_t *__restrict__ vs_table) {
+                       uint32_t nsweeps, uint32_t kinds, RngKey key0, uint32_t pool_cap, const uint32_t *__restrict__ vs_table,
+                       double *__restrict__ winding_partial = nullptr) {
   extern __shared__ double buf[];
-  const uint32_t b = blockIdx.y, seg = blockIdx.x, M = P.M, halo = 2 * nsweeps;
+  __shared__ double qoi_red[4];
+  // winding_partial != NULL: the segment's share of sum_j mod_2pi(x_j - x_{j-1}) (qoi/qm/qoisusceptibility.cc:8-23) of the
+  // NEW state goes out with it; the left neighbour of the first owned site has to be exact for that: one more pair of halo sites
+  const uint32_t b = blockIdx.y, seg = blockIdx.x, M = P.M, halo = 2 * nsweeps + (winding_partial ? 2u : 0u);
   HbPool pool = HbPool::carve(buf + owned_len + 2 * halo, HEAT && !STEP ? pool_cap : 0u);  // behind the segment image
   VsPool<uint32_t> vpool = VsPool<uint32_t>::carve(buf + owned_len + 2 * halo, HEAT && STEP ? pool_cap : 0u, STEP ? vs_table : nullptr);
   const uint32_t o0 = seg * owned_len, olen = min(owned_len, M - o0);
@@ -556,7 +569,15 @@ __global__ void __launch_bounds__(256)
     }
   }
   double *xout = out + (size_t)b * M;
-  for (uint32_t k = threadIdx.x; k < olen; k += blockDim.x) xout[o0 + k] = buf[halo + k];
+  double acc[1] = {0.0};
+  for (uint32_t k = threadIdx.x; k < olen; k += blockDim.x) {
+    xout[o0 + k] = buf[halo + k];
+    if (winding_partial) acc[0] += mod_2pi(buf[halo + k] - buf[halo + k - 1]);
+  }
+  if (winding_partial) {
+    block_sum<1>(acc, qoi_red);
+    if (threadIdx.x == 0) winding_partial[(size_t)b * gridDim.x + seg] = acc[0];
+  }
 }
 
 // Site-at-a-time rotor updates (rotoraction.cc:20-56 through Action::heatbath_update / overrelaxation_update,
@@ -918,7 +939,7 @@ int mlmcpi_path_hmc_draw(const mlmcpi_path_action *act, double *d_x, uint32_t B,
 // see sweep_draw_impl of lattice2d.hip: reads d_x first, then alternates between d_w0 and d_w1 (which may be d_x)
 static int path_sweep_impl(const mlmcpi_path_action *act, double *d_x, double *d_w0, double *d_w1, uint32_t B,
                            uint32_t n_overrelax, uint32_t n_heatbath, uint64_t seed, uint32_t chain0,
-                           uint32_t sweep0, int32_t *result_in, void *stream) {
+                           uint32_t sweep0, int32_t *result_in, void *stream, double *d_qoi = nullptr, double *d_acc = nullptr) {
   if (int rc = check_action(act)) return rc;
   // action/action.hh:73-96: only the rotor implements local updates among the 1-D actions
   if (act->kind != MLMCPI_ROTOR)
@@ -945,7 +966,9 @@ static int path_sweep_impl(const mlmcpi_path_action *act, double *d_x, double *d
       }
     } else
       kinds = 1u;
-    const uint32_t halo = 2 * n;
+    // the draw's last launch can sum the topological charge of the new state while the segment is in LDS (d_qoi)
+    const bool with_qoi = d_qoi && s + n == total;
+    const uint32_t halo = 2 * n + (with_qoi ? 2 : 0);
     uint32_t owned = 2048 - 2 * halo;  // even
     if (owned > P.M) owned = P.M;
     const uint32_t nseg = (P.M + owned - 1) / owned;
@@ -959,16 +982,24 @@ static int path_sweep_impl(const mlmcpi_path_action *act, double *d_x, double *d
     const uint32_t *vs_table = nullptr;
     if (kinds && step)
       if (int rc = vs_table_device(2.0 * P.m0 / P.a, &vs_table)) return rc;
+    void *partial = nullptr;
+    if (with_qoi)
+      if (int rc = scratch((size_t)B * nseg2 * sizeof(double), &partial, st)) return rc;
     if (kinds && step)
       hipLaunchKernelGGL((rotor_sweep_kernel<true, true>), dim3(nseg2, B), dim3(256), lds + VsPool<uint32_t>::bytes(pool_cap), st, P,
-                         (const double *)src, dst, owned, n, kinds, make_key(seed, chain0, sweep0 + s), pool_cap, vs_table);
+                         (const double *)src, dst, owned, n, kinds, make_key(seed, chain0, sweep0 + s), pool_cap, vs_table, (double *)partial);
     else if (kinds)
       hipLaunchKernelGGL(rotor_sweep_kernel<true>, dim3(nseg2, B), dim3(256), lds + HbPool::bytes(pool_cap), st, P,
-                         (const double *)src, dst, owned, n, kinds, make_key(seed, chain0, sweep0 + s), pool_cap, vs_table);
+                         (const double *)src, dst, owned, n, kinds, make_key(seed, chain0, sweep0 + s), pool_cap, vs_table, (double *)partial);
     else
       hipLaunchKernelGGL(rotor_sweep_kernel<false>, dim3(nseg2, B), dim3(256), lds, st, P, (const double *)src, dst, owned, n,
-                         kinds, make_key(seed, chain0, sweep0 + s), 0u, vs_table);
+                         kinds, make_key(seed, chain0, sweep0 + s), 0u, vs_table, (double *)partial);
     MLMCPI_LAUNCH_CHECK("rotor_sweep_kernel");
+    if (with_qoi) {
+      hipLaunchKernelGGL(path_finish_kernel, dim3((B + 255) / 256), dim3(256), 0, st, (const double *)partial, nseg2, B,
+                         (int)R_WINDING, 1.0 / act->T_final, d_qoi, d_acc);
+      MLMCPI_LAUNCH_CHECK("path_finish_kernel");
+    }
     src = dst;
     dst = (dst == d_w0) ? d_w1 : d_w0;
     s += n;
@@ -1014,6 +1045,15 @@ int mlmcpi_path_sweep_draw_from(const mlmcpi_path_action *act, const double *d_s
   MLMCPI_REQUIRE(n_overrelax + n_heatbath > 0, "no sweeps requested: the result would be the (read-only) input");
   return path_sweep_impl(act, const_cast<double *>(d_src), d_w0, d_w1, B, n_overrelax, n_heatbath, seed, chain0, sweep0,
                          result_in, stream);
+}
+
+int mlmcpi_path_sweep_draw_qoi(const mlmcpi_path_action *act, const double *d_src, double *d_w0, double *d_w1, uint32_t B,
+                               uint32_t n_overrelax, uint32_t n_heatbath, uint64_t seed, uint32_t chain0, uint32_t sweep0,
+                               double *d_qoi, double *d_acc, int32_t *result_in, void *stream) {
+  MLMCPI_REQUIRE(result_in && d_qoi, "result_in or d_qoi is NULL");
+  MLMCPI_REQUIRE(n_overrelax + n_heatbath > 0, "no sweeps requested: the result would be the (read-only) input");
+  return path_sweep_impl(act, const_cast<double *>(d_src), d_w0, d_w1, B, n_overrelax, n_heatbath, seed, chain0, sweep0,
+                         result_in, stream, d_qoi, d_acc);
 }
 
 // workspace: theta' [B*M] (the trial state; kept at the r02 size, which also held reduction partials)

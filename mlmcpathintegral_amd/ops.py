@@ -220,6 +220,19 @@ def path_sweep_draw(act, x, scratch, n_overrelax, n_heatbath, seed, chain0, swee
              chain0, sweep0, _stream())
 
 
+def path_sweep_draw_qoi(act, src, w0, w1, n_overrelax, n_heatbath, seed, chain0, sweep0, acc=None):
+    """draw + topological susceptibility in one pass (mlmcpi_path_sweep_draw_qoi; rotor): reads `src` (w1 may be src),
+    returns (result tensor, the other work tensor, chi [B]); acc [B, 5]: record_sample of chi in the same call."""
+    _check_state(src, act.M)
+    where = C.c_int32(0)
+    q = torch.empty(src.shape[0], dtype=torch.float64, device=src.device)
+    if acc is not None:
+        assert acc.shape == (src.shape[0], 5) and acc.dtype == torch.float64 and acc.is_contiguous()
+    abi.call("mlmcpi_path_sweep_draw_qoi", C.byref(act), _p(src), _p(w0), _p(w1), src.shape[0], n_overrelax, n_heatbath, seed,
+             chain0, sweep0, _p(q), None if acc is None else _p(acc), C.byref(where), _stream())
+    return (w0, w1, q) if where.value == 0 else (w1, w0, q)
+
+
 def _site_args(x, sites):
     """(d_sites, n, single) for the site-update entry points: an int, or a uint32 / int32 device tensor of site indices"""
     if isinstance(sites, int):

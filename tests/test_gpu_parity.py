@@ -427,6 +427,31 @@ def test_rotor_heat_bath_behind_the_last_overrelaxation_launch(gpu_ops):
             assert torch.equal(res["split"], res["fused"]), (M, n_or, n_hb)
 
 
+@pytest.mark.parametrize("M,B", [(64, 2), (4096, 3), (65536, 2)])
+def test_rotor_draw_qoi_record_in_one_call_equals_the_three_steps(gpu_ops, M, B):
+    """mlmcpi_path_sweep_draw_qoi: the state is the plain draw's, bit for bit; the susceptibility summed inside the last
+    launch equals mlmcpi_qoi_susceptibility on it to rounding; the moments recorded in the same call are those of
+    mlmcpi_stats_accumulate on that value."""
+    from mlmcpathintegral_amd import abi
+    act = abi.path_action(abi.ROTOR, M, M / 8.0, 0.25)
+    x0 = gpu_ops.path_initialise(act, B, SEED, 9)
+    for n_or, n_hb in ((10, 1), (8, 1), (3, 0), (0, 2)):
+        plain = x0.clone()
+        gpu_ops.path_sweep_draw(act, plain, torch.empty_like(plain), n_or, n_hb, SEED, 9, 50)
+        acc = torch.zeros((B, 5), dtype=torch.float64, device="cuda")
+        src = x0.clone()
+        res, _, q = gpu_ops.path_sweep_draw_qoi(act, src, torch.empty_like(src), src, n_or, n_hb, SEED, 9, 50, acc=acc)
+        assert torch.equal(res, plain), (n_or, n_hb)
+        ref = gpu_ops.qoi_susceptibility(plain, M / 8.0)
+        assert_close(q.cpu().numpy(), ref.cpu().numpy(), tol=1e-10, what=f"fused susceptibility ({n_or},{n_hb})")
+        want = torch.zeros((B, 5), dtype=torch.float64, device="cuda")
+        gpu_ops.stats_accumulate(want, q)
+        assert torch.equal(acc, want)
+        src = x0.clone()   # (the first call was free to use its input as a work buffer)
+        res2, _, q2 = gpu_ops.path_sweep_draw_qoi(act, src, torch.empty_like(src), src, n_or, n_hb, SEED, 9, 50)
+        assert torch.equal(q2, q) and torch.equal(res2, plain)
+
+
 def test_path_sweep_unsupported_action(gpu_ops):
     """action/action.hh:73-96: heat bath / overrelaxation are errors for HO and quartic."""
     from mlmcpathintegral_amd import abi
