@@ -483,12 +483,13 @@ def main():
 
     # side measurements of the default workload (same kernels, other batch sizes), after the timed region
     if a.workload == "schwinger" and not a.no_extra_points and a.chains == 0:
-        for name, b_extra, k_extra in (("single_chain", 1, max(a.steps, 20)), ("chains_128", 128, max(2, a.steps // 4))):
+        # (a single-chain step is ~0.06 ms: 200 of them, so that the figure does not hang on a handful of launches)
+        for name, b_extra, k_extra in (("single_chain", 1, max(10 * a.steps, 200)), ("chains_128", 128, max(2, a.steps // 4))):
             Wx = SweepWorkload(a, torch, abi, ops, "schwinger", size, b_extra, rank * b_extra)
             lean = a.n_heatbath > 0 and not a.no_fused_qoi
             for _ in range(min(a.thermalise, 10)):
                 Wx.step(False)
-            el = time_steps(torch, dist, 1, Wx.lean_step if lean else Wx.step, k_extra, 2)
+            el = time_steps(torch, dist, 1, Wx.lean_step if lean else Wx.step, k_extra, 2 if b_extra > 1 else 10)
             extra[name] = {"chains_per_gpu": b_extra, "steps": k_extra, "ms_per_step": 1e3 * el / k_extra,
                            "value_per_gpu": Wx.sites * (a.n_overrelax + a.n_heatbath) * b_extra * k_extra / el,
                            "unit": "updates/s"}
