@@ -2042,9 +2042,10 @@ static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, doub
   };
   uint32_t s = 0;
   while (s < total) {
-    // Only overrelaxation sweeps are fused: they are bound by the passes over the state, and a fused launch trades
-    // halo recomputation (cheap for them) for passes.  A heat-bath sweep is bound by its sampler arithmetic, which a
-    // wider halo would only multiply, so it always gets a launch of its own (halo 2).
+    // Overrelaxation sweeps are fused: they are bound by the passes over the state, and a fused launch trades halo
+    // recomputation (cheap for them) for passes.  A heat-bath sweep is bound by its sampler arithmetic, which a wider halo
+    // would only multiply: no sweep follows it inside a launch.  As the LAST sweep of an overrelaxation launch it needs no
+    // halo of its own beyond the two rings it reads (the *_or_heat_kernel branches below); otherwise it gets a launch to itself.
     uint32_t n = 1;
     if (s < n_overrelax) {
       const uint32_t rem = n_overrelax - s;
