@@ -105,6 +105,12 @@ def pmc_entry(section, **match):
     return None
 
 
+def under_profiler():
+    env = os.environ
+    return bool(env.get("ROCP_TOOL_LIBRARIES") or env.get("ROCPROFILER_REGISTER_FORCE_LOAD")
+                or "rocprof" in env.get("LD_PRELOAD", "") or env.get("ROCPROF_OUTPUT_PATH"))
+
+
 def cpu_baseline(a, size):
     """Reference-order oracle on the host cores; run BEFORE this process touches the GPU."""
     wl = {"schwinger": "schwinger", "gff": "gff", "rotor_hmc": "rotor", "quartic_hmc": "quartic", "ho_hmc": "harmonic",
@@ -137,7 +143,7 @@ def cxx_path(a, size):
         cmd = [exe, "--method", "throughput", "--action", "schwinger", "--Mt_lat", str(size), "--sampler", "heatbath",
                "--batch", str(batch), "--n_samples", str(samples), "--n_burnin", "30", "--seed", str(a.seed),
                "--n_sweep_overrelax", str(a.n_overrelax), "--n_sweep_heatbath", str(a.n_heatbath)]
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
         lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
         if r.returncode != 0 or not lines:
             out[name] = {"error": (r.stderr or r.stdout)[-300:]}
@@ -299,11 +305,14 @@ def main():
     size = a.size or DEFAULT_SIZE[a.workload]
     B = a.chains or DEFAULT_CHAINS[a.workload]
 
+    # Under a profiler (rocprofv3 preloads its tool library, which has initialised the GPU in this process already and
+    # would be inherited by the children and mix their kernels into the same output directory) no child process is started.
+    profiled = under_profiler()
     cpu = None
-    if world == 1 and not a.no_cpu_baseline:
+    if world == 1 and not a.no_cpu_baseline and not profiled:
         cpu = cpu_baseline(a, size)
     cxx = None
-    if world == 1 and a.workload == "schwinger" and not a.no_extra_points and a.chains == 0:
+    if world == 1 and a.workload == "schwinger" and not a.no_extra_points and a.chains == 0 and not profiled:
         cxx = cxx_path(a, size)  # child processes; this one has not touched the GPU yet
 
     import torch
@@ -422,7 +431,8 @@ def main():
         from mlmcpathintegral_amd import mlmc
         n_level = 5
         T_hier = a.t_final or size / 8.0
-        est = mlmc.PathMLMC(abi.QUARTIC, size, T_hier, n_level, B, nt=a.nt, seed=a.seed, rank=rank, world=world,
+        # dt0 = the step size of the direct (untimed) burn-in runs on the fine levels: the value the direct workload uses
+        est = mlmc.PathMLMC(abi.QUARTIC, size, T_hier, n_level, B, nt=a.nt, dt0=0.02, seed=a.seed, rank=rank, world=world,
                             params=dict(lam=1.0, x0=1.0), hierarchical=True, dt_coarse=a.dt or 0.095)
         est.exchange = exchange
         est.thermalise(400)   # untimed: every chain starts from an equilibrium sample of its level (direct HMC, once)

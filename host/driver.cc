@@ -32,7 +32,7 @@ int main(int argc, char **argv) {
       {"sampler", "hmc"}, {"nt", "100"}, {"dt", "0.1"}, {"n_burnin", "100"}, {"n_samples", "20000"}, {"n_sweep_overrelax", "10"},
       {"n_sweep_heatbath", "1"}, {"autotune", "1"}, {"window", "20"}, {"method", "singlelevel"}, {"n_level", "3"},
       {"epsilon", "0.01"}, {"coarsening", "both"}, {"coarsesampler", "hmc"}, {"renormalisation", "none"}, {"n_meas", "200"},
-      {"batch", "1"}, {"seed", "2481317"}, {"warmup", "5"}};
+      {"batch", "1"}, {"seed", "2481317"}, {"warmup", "5"}, {"random_order", "0"}};
   for (int i = 1; i + 1 < argc; i += 2) {
     if (std::strncmp(argv[i], "--", 2) || !o.count(argv[i] + 2)) fatal(std::string("unknown option ") + argv[i]);
     o[argv[i] + 2] = argv[i + 1];
@@ -118,6 +118,10 @@ int main(int argc, char **argv) {
     hb.n_sweep_overrelax = (unsigned)num("n_sweep_overrelax"); hb.n_sweep_heatbath = (unsigned)num("n_sweep_heatbath");
     hb.n_burnin = (unsigned)num("n_burnin");
     hb.batch = batch;
+    // heatbath.random_order of the reference's parameter file (template: true).  Default here: 0, the multicolour kernels.
+    hb.random_order = num("random_order") != 0;
+    std::cerr << "heatbath: random_order = " << (hb.random_order ? "true (shuffled index set, site-at-a-time updates)"
+                                                                 : "false (multicolour sweep kernels)") << std::endl;
     return std::make_shared<OverrelaxedHeatBathSamplerFactory>(hb);
   };
   std::shared_ptr<SamplerFactory> factory;

@@ -232,10 +232,35 @@ double integrate_mpi_pi(F f, double x) {
   return 0.5 * h * sum;
 }
 
+// exp(-x) I_n(x), n < nmax (the reference: gsl_sf_bessel_In_scaled, auxilliary.cc:159): Miller's downward recurrence
+// f_{k-1} = f_{k+1} + (2k / x) f_k from far above the orders wanted, normalised by exp(x) = I_0 + 2 sum_k I_k.  Every term is
+// positive, so the relative accuracy is that of the recurrence (~1e-15) also where I_n is 1e-23 of I_0 -- a quadrature
+// with absolute error 1e-16 returns noise of either sign there.
+void bessel_In_scaled(double x, int nmax, double *In) {
+  const int N = nmax + 64 + (int)(12.0 * sqrt(fabs(x)));
+  double f_up = 0.0, f = 1e-280, sum = 0.0;
+  for (int n = 0; n < nmax; ++n) In[n] = 0.0;
+  for (int k = N; k >= 1; --k) {  // f = f_k, f_up = f_{k+1}
+    const double f_dn = f_up + (2.0 * k / x) * f;
+    sum += 2.0 * f;
+    if (k < nmax) In[k] = f;
+    f_up = f;
+    f = f_dn;
+    if (f > 1e250) {  // rescale everything computed so far
+      const double s = 1e-250;
+      f *= s; f_up *= s; sum *= s;
+      for (int n = 0; n < nmax; ++n) In[n] *= s;
+    }
+  }
+  In[0] = f;
+  sum += f;
+  for (int n = 0; n < nmax; ++n) In[n] /= sum;
+}
+
 // In = exp(-x) I_n(x), and the two integrals the reference calls I'_n and I''_n (auxilliary.cc:98-131)
 void schwinger_In(double x, int nmax, double *In, double *dIn, double *ddIn) {
+  bessel_In_scaled(x, nmax, In);
   for (int n = 0; n < nmax; ++n) {
-    In[n] = integrate_mpi_pi([&](double phi) { return exp(x * (cos(phi) - 1.0)) * cos(n * phi); }, x) / (2.0 * kPi);
     dIn[n] = integrate_mpi_pi([&](double phi) { return -1. / (4. * kPi * kPi) * phi * exp(x * (cos(phi) - 1.0)) * sin(n * phi); }, x);
     ddIn[n] = integrate_mpi_pi([&](double phi) { return 1. / (8. * kPi * kPi * kPi) * phi * phi * exp(x * (cos(phi) - 1.0)) * cos(n * phi); }, x);
   }
@@ -486,8 +511,10 @@ int mlmcpi_schwinger_chit_analytical(double beta, uint32_t n_plaq, double *chit)
 }
 
 int mlmcpi_schwinger_beta_coarse_nonperturbative(double beta, uint32_t n_plaq, int32_t rho_refine, double *beta_coarse) {
-  MLMCPI_REQUIRE(beta_coarse && beta > 0.0 && beta <= 2000.0 && (rho_refine == 2 || rho_refine == 4) && n_plaq >= (uint32_t)rho_refine,
-                 "bad arguments");
+  // the root is bracketed on x in [0.01, 2], so Phi_chit is evaluated at 2 beta: the reference aborts there for
+  // 2 beta > 2000 (auxilliary.cc:46-52, the series is unstable beyond), and so does this
+  MLMCPI_REQUIRE(beta_coarse && beta > 0.0 && 2.0 * beta <= 2000.0 && (rho_refine == 2 || rho_refine == 4) && n_plaq >= (uint32_t)rho_refine,
+                 "bad arguments (0 < beta <= 1000: the bracket [0.01, 2] beta must stay below 2000; rho_refine 2 or 4; n_plaq >= rho_refine)");
   const double target = schwinger_chit(beta, n_plaq);
   auto f = [&](double x) { return schwinger_chit(x * beta, n_plaq / rho_refine) - target; };  // quenchedschwingerrenormalisation.hh:125-133
   double x_lo = 0.01, x_hi = 2.0, f_lo = f(x_lo), f_hi = f(x_hi), x;

@@ -158,14 +158,14 @@ class HierPathLevel(PathLevel):
         self.sampler.thermalise(n, 24, dt_top=None if dts is None else dts[self.sampler.top])
         # tau_int of the coarse sampler's QoI: the reference's windowed estimator (common/statistics.cc:38-61:
         # 1 + 2 sum_{k < window} (1 - k/n) C_k / C_0), with the autocovariances C_k averaged over all chains of the batch
-        n = 8 * self.window
-        q = torch.stack([self.qoi(self.sampler.draw(count=False)).clone() for _ in range(n)])   # [n, B]
+        n_series = 8 * self.window   # length of the tau_int series; `n` stays the burn-in length the caller asked for
+        q = torch.stack([self.qoi(self.sampler.draw(count=False)).clone() for _ in range(n_series)])   # [n_series, B]
         d = q - q.mean()
         c0 = float((d * d).mean())
         tau = 1.0
         if c0 > 0.0:
             for k in range(1, self.window):
-                tau += 2.0 * (1.0 - k / n) * float((d[:-k] * d[k:]).mean()) / c0
+                tau += 2.0 * (1.0 - k / n_series) * float((d[:-k] * d[k:]).mean()) / c0
         self.tau_coarse = max(1.0, tau)
         # ceil(2 tau_int), montecarlomultilevel.cc:173 (a stationary series cannot exceed 1 + 2 (window - 1))
         self.n_sub = min(max(1, int(-(-2.0 * self.tau_coarse // 1))), 2 * (1 + 2 * self.window))
@@ -173,8 +173,9 @@ class HierPathLevel(PathLevel):
             # the level's own state: an equilibrium sample of its action by a direct HMC run (untimed, once)
             fine = self.step.fine
             self.step.theta = ops.path_initialise(fine, self.B, self.sampler.hmc.seed + 2, self.chain0)
-            direct = ops.PathHMC(fine, self.B, self.hmc.nt, (dts or {}).get(self.level, 0.02) if isinstance(dts, dict) else
-                                 (dts[self.level] if dts else 0.02), seed=self.sampler.hmc.seed + 2, chain0=self.chain0)
+            direct = ops.PathHMC(fine, self.B, self.hmc.nt, dts[self.level] if dts else 0.02,
+                                 seed=self.sampler.hmc.seed + 2, chain0=self.chain0)
+            self.n_burnin_theta = n   # (tests read it back)
             ops.hmc_thermalise(direct, self.step.theta, n)
             for _ in range(16):
                 self.step.draw(self.sampler.draw(count=False))

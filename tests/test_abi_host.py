@@ -268,7 +268,10 @@ def _phi_chit_scipy(beta, n_plaq, nmax=20):
 
 
 @pytest.mark.parametrize("beta,n_plaq,survey", [(1.0, 16, 0.6500978), (4.0, 256, 1.9338785), (1.0, 1024 * 1024, 42610.18),
-                                                (8.0, 64, None), (0.3, 36, None), (40.0, 1024, None)])
+                                                (8.0, 64, None), (0.3, 36, None), (40.0, 1024, None),
+                                                # small P: the weights (I_n / I_0)^P of the high orders are not negligible
+                                                # a priori, and I_19(0.5) = 1e-29 I_0 (a quadrature returns noise there)
+                                                (0.5, 4, None), (2.0, 4, None), (0.5, 16, None), (1800.0, 4096, None)])
 def test_schwinger_chit_analytical(beta, n_plaq, survey):
     """V chi_t = (P / beta) Phi_chi(beta, P): the product's own quadrature against the scipy restatement of the
     reference's formulas and against the values SURVEY 8(c) recorded (analytic side of qoi2dsusceptibility.cc:30-34)."""
@@ -294,6 +297,16 @@ def test_schwinger_beta_coarse_nonperturbative(beta, n_plaq, rho):
     # to O(1 / beta) the matched coupling is the perturbative one (quenchedschwingerrenormalisation.hh:84-104)
     pert = (1.0 / rho) * (1.0 + (1.5 if rho == 4 else 0.5) / beta) * beta
     assert abs(bc.value - pert) < 2.5 / beta * pert, (bc.value, pert)
+
+
+def test_schwinger_beta_coarse_keeps_the_reference_domain():
+    """The bracket [0.01, 2] beta evaluates Phi_chit at 2 beta, which the reference refuses beyond 2000
+    (auxilliary.cc:46-52): so does the port, instead of returning a root from the unstable region."""
+    from mlmcpathintegral_amd import abi
+    bc = C.c_double()
+    abi.call("mlmcpi_schwinger_beta_coarse_nonperturbative", 1000.0, 4096, 4, C.byref(bc))
+    with pytest.raises(abi.MlmcpiError, match="beta <= 1000"):
+        abi.call("mlmcpi_schwinger_beta_coarse_nonperturbative", 1000.5, 4096, 4, C.byref(bc))
 
 
 def test_tuning_options_are_checked_by_name_and_value():

@@ -207,3 +207,42 @@ def test_level_instances_shard_over_eight_ranks():
         assert r[1] == shares[r[0]]
         assert torch.allclose(torch.tensor(r[2], dtype=torch.float64), serial, rtol=1e-13, atol=0)
     assert chains.combine_levels(serial)[0] == pytest.approx(float(serial[:, 1].sum()))
+
+
+def test_hier_level_burns_its_own_state_in_for_the_length_asked(monkeypatch):
+    """HierPathLevel.thermalise reassigned its argument to the tau_int series length (160), so the level's own
+    state theta got 160 burn-in trajectories instead of the 400 the caller asked for.  Host logic only: the device calls
+    are replaced by recorders."""
+    import types
+    from mlmcpathintegral_amd import mlmc
+    calls = {"thermalise": [], "dt": []}
+
+    class FakeSampler:
+        top = 1
+        hmc = types.SimpleNamespace(seed=5, nt=100)
+
+        def thermalise(self, n_hmc, n_draws, dt_top=None):
+            calls["sampler"] = (n_hmc, n_draws, dt_top)
+
+        def draw(self, count=True):
+            return torch.arange(4, dtype=torch.float64)
+
+    class FakeStep:
+        fine = object()
+        theta = None
+
+        def draw(self, x):
+            return torch.zeros(4)
+
+    monkeypatch.setattr(mlmc.ops, "path_initialise", lambda *a, **k: torch.zeros(4, dtype=torch.float64))
+    monkeypatch.setattr(mlmc.ops, "PathHMC", lambda act, B, nt, dt, **k: calls["dt"].append(dt) or "hmc")
+    monkeypatch.setattr(mlmc.ops, "hmc_thermalise", lambda hmc, x, n: calls["thermalise"].append(n))
+    lv = object.__new__(mlmc.HierPathLevel)
+    lv.level, lv.B, lv.chain0, lv.window, lv.coarsest = 0, 4, 0, 20, False
+    lv.sampler, lv.hmc, lv.step = FakeSampler(), FakeSampler.hmc, FakeStep()
+    lv.qoi = lambda x: x
+    lv.thermalise(400, [0.02, 0.03])
+    assert calls["sampler"] == (400, 24, 0.03)
+    assert calls["thermalise"] == [400] and lv.n_burnin_theta == 400
+    assert calls["dt"] == [0.02]
+    assert lv.n_sub >= 1

@@ -14,6 +14,6 @@ timeout -k 10 600 python bench.py --steps 10 --warmup 2 > gpurun_out/bench_$TAG.
 cat gpurun_out/bench_$TAG.json; tail -3 gpurun_out/bench_$TAG.err
 if [ $rc -ne 0 ]; then exit $rc; fi
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d ${GRAFT_REPO_ROOT:?}/gpurun_out/prof_$TAG -- python3 ${GRAFT_REPO_ROOT:?}/bench.py --steps 5 --warmup 1 --no-cpu-baseline > ${GRAFT_REPO_ROOT:?}/gpurun_out/prof_$TAG.log 2>&1
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d ${GRAFT_REPO_ROOT:?}/gpurun_out/prof_$TAG -- python3 ${GRAFT_REPO_ROOT:?}/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extra-points > ${GRAFT_REPO_ROOT:?}/gpurun_out/prof_$TAG.log 2>&1
 echo "rocprof exit $?"
 find ${GRAFT_REPO_ROOT:?}/gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -2 | xargs -r head -12

@@ -3,7 +3,7 @@
 # WRITE_SIZE in separate passes (TCC slots), no tracing domains besides the kernel trace.
 set -o pipefail
 TAG=${1:-pmc}; shift
-ARGS=${@:---steps 3 --warmup 1 --no-cpu-baseline}
+ARGS=${@:---steps 3 --warmup 1 --no-cpu-baseline --no-extra-points}
 OUT=${GRAFT_REPO_ROOT:?}/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
