@@ -158,6 +158,107 @@ def test_smoothed_coarse_action_interpolates_between_plain_and_exact_marginal():
     assert err[0] > err[1] > err[2] > err[3] and err[3] < 1e-9 * np.abs(Q_marginal).max(), err
 
 
+# ---- the reference author's own numpy construction (tests/golden/gff_qhat.json, made by make_gff_qhat_fixture.py) --------
+def _qhat_fixture():
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "gff_qhat.json")) as f:
+        return json.load(f)
+
+
+def _fixture_fields(Mlat):
+    """the three deterministic fields of make_gff_qhat_fixture.py (Cartesian coordinates: permutation-free)"""
+    i, j = np.meshgrid(np.arange(Mlat), np.arange(Mlat), indexing="ij")
+    return [np.sin(0.7 * i + 1.3 * j + 0.2), np.cos(2.0 * np.pi * i / Mlat) * (1.0 + 0.1 * j), ((3 * i + 5 * j) % 7) / 7.0 - 0.4]
+
+
+def _rotated_coords(Mt, n):
+    from mlmcpathintegral_amd import abi
+    out = []
+    for ell in range(n):
+        i, j = C.c_int(), C.c_int()
+        abi.load().mlmcpi_vertex_lin2cart(Mt, Mt, 1, ell, C.byref(i), C.byref(j))
+        out.append((i.value, j.value))
+    return out
+
+
+@pytest.mark.parametrize("case", [c for c in _qhat_fixture()["qhat"] if c["order"] == "lattice2d" or c["nsmooth"] == 0],
+                         ids=lambda c: f"M{c['Mlat']}-n{c['nsmooth']}-{c['order']}")
+def test_qhat_matches_the_reference_authors_numpy_construction(orc, case):
+    """Q-hat of the first rotated level, Sigma_iter = Sigma + G^n (Sigma_initial - Sigma) G^n^T inverted
+    (gffaction.cc:133-166), against /root/reference/python/gibbs_smoother.py:41-55 run by the fixture generator -- the
+    reference author's own construction of the same object, with the same stencils (coarse mu2 = 2 x fine).  Library
+    (mlmcpi_gff_level_matrix) and oracle both reproduce 1/2 phi^T Q-hat phi for three fields and the diagonal and one row
+    of Sigma_iter = Q-hat^-1.  For nsmooth > 0 the matrix depends on the order of the Gibbs sweep: the cases compared are
+    the ones the generator built in Lattice2D's numbering of the rotated vertices (order = lattice2d)."""
+    Mlat, n = case["Mlat"], case["nsmooth"]
+    for lv in (Level(Mlat, ROTATE, 1, case["mass"], n), OLevel(orc, Mlat, ROTATE, 1, case["mass"], n)):
+        Q = lv.matrix(0)
+        coords = _rotated_coords(Mlat, lv.N)
+        for f, want in zip(_fixture_fields(Mlat), case["energies"]):
+            phi = np.array([f[i, j] for i, j in coords])
+            assert abs(0.5 * phi @ Q @ phi - want) < 1e-10 * max(1.0, abs(want))
+        Sigma = np.linalg.inv(Q)
+        lin = {c: l for l, c in enumerate(coords)}
+        for i, j, v in case["sigma_iter_diag"]:
+            assert abs(Sigma[lin[(i, j)], lin[(i, j)]] - v) < 1e-10 * abs(v)
+        for i, j, v in case["sigma_iter_row0"]:
+            assert abs(Sigma[lin[(0, 0)], lin[(i, j)]] - v) < 1e-11
+
+
+def test_gibbs_sweep_order_matters_for_qhat():
+    """why only the lattice2d-ordered cases can be compared for nsmooth > 0: the same construction swept in the Python
+    class's own vertex order gives a different Q-hat (energies differ in the 3rd-4th digit), and the same one for nsmooth = 0"""
+    cases = {(c["Mlat"], c["nsmooth"], c["order"]): c for c in _qhat_fixture()["qhat"]}
+    for Mlat in (8, 16):
+        a, b = cases[(Mlat, 0, "python")], cases[(Mlat, 0, "lattice2d")]
+        assert np.allclose(a["energies"], b["energies"], rtol=1e-12)
+        a, b = cases[(Mlat, 2, "python")], cases[(Mlat, 2, "lattice2d")]
+        assert not np.allclose(a["energies"], b["energies"], rtol=1e-6)
+
+
+def test_three_level_acceptance_is_the_plain_vs_marginal_mismatch():
+    """with three GFF levels (16 x 16 -> rotated -> 8 x 8) the lower two-level step accepts about 8 %.  The
+    reading: the fill-in of the rotated level (gffconditionedfineaction.cc:7-25) is exact for the PLAIN stencil there, so
+    a proposal on that level is distributed (nearly) like the plain stencil's Gaussian, while the level's action is the
+    Gibbs-smoothed Q-hat, close to the 9-point marginal of the finer level: an independence Metropolis test between the two.
+    (a) numpy, with the library's own matrices: the expected acceptance of exactly that step is 0.05 ... 0.12;
+    (b) the reference author's Python experiment of the same test (GFFAction.draw_5pt / draw_9pt / evaluate_*,
+        gff_twolevel_coarse.py:8-152, run by the fixture generator at the same mu2 on square lattices of 64 and 144
+        vertices) brackets it: 0.20 at 64, 0.055 at 144 vertices; the rotated level has 128."""
+    rng = np.random.default_rng(7)
+    Mt, mass, n_gibbs = 16, 10.0, 2
+    # (a level handle takes the extents of ITS lattice: level 2 of the 16 x 16 hierarchy is the unrotated 8 x 8 lattice)
+    l1, l2 = Level(Mt, ROTATE, 1, mass, n_gibbs), Level(Mt // 2, ROTATE, 2, mass, n_gibbs)
+    assert l2.N == l1.n_coarse and abs(l2.mu2 - 2.0 * l1.mu2) < 1e-14
+    Q1, Q2 = l1.matrix(0), l2.matrix(0)
+    pairs, fineonly = l1.tables()
+    fidx, cidx = pairs[0::2], pairs[1::2]
+    nb = _neighbours(Mt, True)
+    kappa = 4.0 + l1.mu2
+    C1, C2 = np.linalg.cholesky(np.linalg.inv(Q1)), np.linalg.cholesky(np.linalg.inv(Q2))
+
+    def cfa(theta):  # -log density of the fine-only vertices given the coarse ones (up to a constant)
+        mean = theta[nb[fineonly, :4]].sum(axis=1) / kappa
+        return 0.5 * kappa * np.sum((theta[fineonly] - mean) ** 2)
+
+    acc = []
+    for _ in range(4000):
+        theta = C1 @ rng.standard_normal(l1.N)                      # current state ~ the level's action
+        x_new = C2 @ rng.standard_normal(l2.N)                      # coarse proposal ~ the coarser level's action
+        prop = np.zeros(l1.N)
+        prop[fidx] = x_new[cidx]
+        prop[fineonly] = prop[nb[fineonly, :4]].sum(axis=1) / kappa + rng.standard_normal(len(fineonly)) / math.sqrt(kappa)
+        x_old = np.zeros(l2.N)
+        x_old[cidx] = theta[fidx]
+        dS = (0.5 * prop @ Q1 @ prop - 0.5 * theta @ Q1 @ theta) - (0.5 * x_new @ Q2 @ x_new - 0.5 * x_old @ Q2 @ x_old) \
+            - (cfa(prop) - cfa(theta))
+        acc.append(min(1.0, math.exp(-dS)))
+    p = float(np.mean(acc))
+    ref = {a["ndof"]: a["mean_acceptance_probability"] for a in _qhat_fixture()["independence_acceptance_5pt_vs_9pt"]}
+    assert ref[144] < p < ref[64], (p, ref)
+    assert 0.05 < p < 0.12, p
+
+
 # ---- GPU -----------------------------------------------------------------------------------------------------------------
 def _dev(abi, name, *args):
     abi.call(name, *args)
