@@ -8,7 +8,11 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmlmcpi_hip.so")
+# MLMCPI_LIB_VARIANT=<suffix>: load libmlmcpi_hip_<suffix>.so from the same directory instead -- an experiment build of the
+# same sources with other -D switches (make -C mlmcpathintegral_amd/csrc variant VARIANT=<suffix> EXTRA=-D...), so that two
+# builds can be timed on ONE GPU box (box-to-box spread is 7 %).  Tools only; tests and bench lines use the product build.
+_VARIANT = os.environ.get("MLMCPI_LIB_VARIANT", "")
+LIB_PATH = os.path.join(_HERE, f"libmlmcpi_hip_{_VARIANT}.so" if _VARIANT else "libmlmcpi_hip.so")
 
 HARMONIC, QUARTIC, ROTOR, GFF, SCHWINGER = range(5)
 

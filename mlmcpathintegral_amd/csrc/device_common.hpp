@@ -547,46 +547,73 @@ __device__ __forceinline__ void heatbath_cells(uint32_t total, const RngKey &key
 // bits of u2, bits 23..57 position inside the bin (35 bits: 2 10^-11 rad), bits 58..63 selector.
 constexpr double kVsKappaMax = 4.0;  // host rule (lattice2d.hip / path1d.hip; the oracle applies the same): kappa_max <= 4
 constexpr int kVsClasses = 8, kVsBins = 8, kVsSel = 64;
-constexpr uint32_t kVsU2Bits = 22, kVsU2Mask = (1u << kVsU2Bits) - 1;  // leading bits of the acceptance uniform (bits 1..22 of the attempt)
-constexpr float kVsU2Scale = (float)(1u << kVsU2Bits);
-// In LDS (and in the device copy the host uploads): code[class][64], one byte per selector value = left edge of its bin
-// (low nibble) and the bin's width (high nibble), both in units of pi/16 -- an attempt needs no other decoding --, then
-// lw[class][16] floats indexed by that left edge (8 of the 16 slots are used).
-constexpr uint32_t kVsTableBytes = kVsClasses * kVsSel + kVsClasses * 16 * 4;
+constexpr uint32_t kVsU2Bits = 22;  // leading bits of the acceptance uniform carried by the attempt itself
+// The 64 bits (lo, hi) of an attempt (r04 layout: every field is one shift or one conversion away from its use):
+//   lo[31..10]  b, the 22 leading bits of the acceptance uniform u2 = (b + tail) / 2^22 (tail: the refine call, rarely);
+//               (float)lo is u2 2^32 to within 2^10, which is all the screening test needs
+//   lo[9]       sign of the angle
+//   lo[8..0]    the low 9 of the 35 position bits
+//   hi[31..26]  bin selector
+//   hi[25..0]   the high 26 position bits; (float)(hi << 6) is the position 2^32, rounded to 24 bits
+// Device image of the tables (bytes; built by the host for the action's scale, runtime.hip vs_device_image):
+//   code[class][64]   1 B   8 x (bin of the selector value): a byte offset into the next two tables
+//   scr[bin]          8 B   float2 {pi/2 - edge, -width 2^-32}: y = pi/2 - |x| = fma(scr.y, (float)(hi << 6), scr.x), cos|x| = sin y
+//   lw[class][bin]    8 B   float log2 of the bin's acceptance factor (+ 4 B of padding: lw and code share the class offset 64 cls)
+//   fin[bin]          16 B  double2 {64 width, edge - 64 width} in units of pi/16: |x| = (pi/16) fma(fin.x, m, fin.y), m = 1 + position / 64
+//   consts            16 B  float {s_acc, s_rej, 0, 0}: thresholds of the screening test for this scale (below)
+constexpr uint32_t kVsCodeOff = 0, kVsScrOff = 512, kVsLwOff = 576, kVsFinOff = 1088, kVsConstOff = 1216, kVsTableBytes = 1232;
+// host side of the same encoding: left edge and width of bin k in units of pi/16 (edges 0 1 2 3 4 6 8 12, widths 1 1 1 1 2 2 4 4)
+__host__ __device__ constexpr uint32_t vs_edge16(uint32_t k) { return (0xC8643210u >> (4u * k)) & 15u; }
+__host__ __device__ constexpr uint32_t vs_width16(uint32_t k) { return (0x44221111u >> (4u * k)) & 15u; }
+// Screening test.  a = the acceptance probability in fp32 (error budget below), L = (float)lo.  The exact u2 2^32 lies within
+// 2^10 (1 + 2^-22) of L, so
+//     accepted for sure   L <= a 2^32 (1 - band) - kVsU2Slack,       rejected for sure   L >= a 2^32 (1 + band) + kVsU2Slack;
+// neither: the exact fp64 test with the full u2 decides (one attempt in ~10^4).  Error budget of log2(a): |x| to 24 bits
+// (1e-7 kappa'), the sine polynomial (1.2e-7 kappa'), kappa' itself (2e-7 kappa' from the fp32 cosine behind it), the fma (1e-6
+// at |log2 a| <= 16): < 4e-7 (1 + kappa'), i.e. < 3e-7 (1 + kappa') relative on a, plus v_exp_f32's own ~2e-7 and 2^-23 for
+// the conversion of lo and the threshold's own rounding.  The band is 1e-5 (1 + kappa'_max) for the whole launch (kappa'_max =
+// scale log2 e): more than 20 times that, and two constants (s_acc = 2^32 (1 - band), s_rej = 2^32 (1 + band)) instead of
+// five instructions per cell.
+constexpr float kVsU2Slack = 1100.0f;
+__host__ __device__ inline float vs_band_of_scale(double scale) { return (float)(1e-5 * (1.0 + scale * 1.4426950408889634)); }
 
-struct VsTable {  // in LDS
-  const uint8_t *code;  // [class][64]
-  const float *lw;      // [class][16]: log2 of the acceptance factor of the bin whose left edge is the index
+struct VsTable {
+  const uint8_t *base;   // LDS in the sweeps; global memory in the site-at-a-time kernels and the test hook
+  float s_acc, s_rej;
+  __device__ static VsTable at(const void *image, const uint32_t *__restrict__ d_table) {
+    VsTable t{(const uint8_t *)image, 0.f, 0.f};
+    if (d_table) {  // uniform address: scalar loads
+      t.s_acc = __uint_as_float(d_table[kVsConstOff / 4]);
+      t.s_rej = __uint_as_float(d_table[kVsConstOff / 4 + 1]);
+    }
+    return t;
+  }
   // the workgroup copies the action's table from global memory (visible after the caller's next barrier)
   __device__ static VsTable stage(void *lds, const uint32_t *__restrict__ d_table) {
     if (d_table)
       for (uint32_t i = threadIdx.x; i < kVsTableBytes / 4; i += blockDim.x) ((uint32_t *)lds)[i] = d_table[i];
-    return VsTable{(const uint8_t *)lds, (const float *)((const uint8_t *)lds + kVsClasses * kVsSel)};
+    return at(lds, d_table);
   }
+  __device__ static VsTable in_global(const uint32_t *__restrict__ d_table) { return at(d_table, d_table); }
 };
-// host side of the same encoding: left edge and width of bin k in units of pi/16 (edges 0 1 2 3 4 6 8 12, widths 1 1 1 1 2 2 4 4)
-__host__ __device__ constexpr uint32_t vs_edge16(uint32_t k) { return (0xC8643210u >> (4u * k)) & 15u; }
-__host__ __device__ constexpr uint32_t vs_width16(uint32_t k) { return (0x44221111u >> (4u * k)) & 15u; }
 
-// cos(x), x in [0, pi], fp32: sin(pi/2 - x) by its Taylor polynomial to x^11 (truncation 6e-8, rounding ~1e-7)
-__device__ __forceinline__ float cosf_0_pi(float x) {
-  const float y = 1.57079633f - x, y2 = y * y;
-  float p = -2.50521084e-08f;          // -1/11!
-  p = fmaf(p, y2, 2.75573192e-06f);    //  1/9!
-  p = fmaf(p, y2, -1.98412698e-04f);   // -1/7!
-  p = fmaf(p, y2, 8.33333333e-03f);    //  1/5!
-  p = fmaf(p, y2, -1.66666667e-01f);   // -1/3!
+// sin(y), |y| <= pi/2, fp32: odd minimax polynomial of degree 9 (approximation error 4.6e-9; 1.2e-7 with the fp32 rounding,
+// measured over 2 10^6 arguments -- the degree-11 Taylor polynomial this replaces: 1.6e-7)
+__device__ __forceinline__ float sinf_half_pi(float y) {
+  const float y2 = y * y;
+  float p = 2.600053086e-06f;
+  p = fmaf(p, y2, -1.980661437e-04f);
+  p = fmaf(p, y2, 8.333017279e-03f);
+  p = fmaf(p, y2, -1.666665710e-01f);
   return fmaf(y * y2, p, y);
 }
 
 struct VsCell {
   double centre;   // the draw is mod_2pi(centre +- |x|)
   float kp;        // kappa log2(e), fp32: screening only
-  uint32_t cls;    // which table
+  uint32_t cls;    // 64 x (which table): the byte offset of the class in code[][] and lw[][]
   uint32_t site;   // Philox counter word 0
 };
-// guard band of the screening test, relative to the acceptance probability (see vs_try)
-__device__ __forceinline__ float vs_band(float kp) { return 1e-5f * (1.0f + kp); }
 
 // Cell set-up shared by the Schwinger links (x_p, x_m = the two staple sums, scale = 2 beta) and the rotor sites
 // (x_p, x_m = the neighbours, scale = 2 m0 / a): conditional exp(scale/2 [cos(x - x_p) + cos(x - x_m)])
@@ -596,57 +623,49 @@ __device__ __forceinline__ void vs_cell(double scale, double x_p, double x_m, Vs
   const double v = (x_m - x_p) * (0.25 / kPi);
   const double t = fabs(v - rint(v));
   c.centre = fma(0.5, x_p + x_m, t > 0.25 ? kPi : 0.0);
-  const double w = fabs(t - 0.25);                                   // [0, 1/4]; NaN for a NaN state
-  c.cls = min((uint32_t)(32.0 * w), (uint32_t)(kVsClasses - 1));    // (uint32_t)NaN = 0
-  c.kp = fmaxf((float)scale * fabsf(cosf_0_pi(6.28318531f * (float)t)), 0.0f) * 1.44269504f;   // fmaxf: NaN -> 0
+  const double w = fabs(t - 0.25);                                          // [0, 1/4]; NaN for a NaN state
+  c.cls = min((uint32_t)(32.0 * w), (uint32_t)(kVsClasses - 1)) * kVsSel;  // (uint32_t)NaN = 0
+  // |cos(2 pi t)| = |sin(pi/2 - 2 pi t)|, t in [0, 1/2]
+  c.kp = fmaxf((float)scale * fabsf(sinf_half_pi(fmaf(-6.28318531f, (float)t, 1.57079633f))), 0.0f) * 1.44269504f;   // fmaxf: NaN -> 0
 }
 __device__ __forceinline__ double vs_kappa_exact(double scale, double x_p, double x_m) {
   return vm_clamp(scale * fabs(cos_half(x_m - x_p)));
 }
 
-// |x| of the attempt (lo, hi), fp64: (pi/16) (edge + width pos), pos = the 35 bits below the selector (bits 23..57); code = the bin's byte
-__device__ __forceinline__ double vs_theta(uint32_t lo, uint32_t hi, uint32_t code) {
-  // mantissa = 000000 | 35 position bits | 11 zeros: m = 1 + pos / 64
-  const double m = __hiloint2double((int)(((hi >> 12) & 0x3FFFu) | 0x3FF00000u),
-                                    (int)(__builtin_amdgcn_alignbit(hi, lo, 12) & ~0x7FFu));
-  const double w64 = (double)((code >> 4) << 6), e = (double)(code & 15u);
-  return (kPi / 16.0) * fma(w64, m, e - w64);   // one rounding of edge + width pos, as in the oracle
+// |x| of the attempt (lo, hi), fp64: (pi/16) (edge + width pos), pos = the 35 position bits / 2^35; code = 8 x the bin
+__device__ __forceinline__ double vs_theta(uint32_t lo, uint32_t hi, uint32_t code, const VsTable &tab) {
+  // mantissa = 000000 | 26 bits of hi | 9 bits of lo | 11 zeros: m = 1 + pos / 64
+  const double m = __hiloint2double((int)(((hi >> 12) & 0x3FFFu) | 0x3FF00000u), (int)__builtin_amdgcn_alignbit(hi, lo << 23, 12));
+  const double2 f = *(const double2 *)(tab.base + kVsFinOff + 2u * code);
+  return (kPi / 16.0) * fma(f.x, m, f.y);   // edge + width pos is exact in fp64: one rounding, as in the oracle
 }
 
-// screening decision of one attempt: accepted / rejected (neither: open); the bin's code byte comes back for the caller
-__device__ __forceinline__ void vs_try(uint32_t lo, uint32_t hi, float kp, uint32_t cls, const VsTable &tab, uint32_t &code,
-                                       bool &accepted, bool &rejected) {
-  code = tab.code[cls * kVsSel + (hi >> 26)];
-  const uint32_t e16 = code & 15u;
-  const float posf = (float)((hi >> 2) & 0xFFFFFFu) * (1.0f / 16777216.0f);      // the leading 24 position bits
-  const float c = cosf_0_pi(0.196349541f * fmaf((float)(code >> 4), posf, (float)e16));
-  // acceptance probability a; u2 lies in [b, b + 1) / 2^22 with the leading bits b (exact in fp32)
-  const float a = __builtin_amdgcn_exp2f(fmaf(kp, c - 1.0f, tab.lw[cls * 16 + e16]));
-  // error budget of log2(a): |x| to 24 bits (1e-7 kappa'), the cosine (1.5e-7 kappa'), kappa' itself (2e-7 kappa' from
-  // the fp32 cosine behind it), the fma (1e-6 at |log2 a| <= 16): < 4e-7 (1 + kappa') in all, i.e. < 3e-7 (1 + kappa')
-  // relative on a, plus v_exp_f32's own ~2e-7.  The band is 30 times that.  (The two scaled band factors depend on the
-  // cell only: they are hoisted out of the attempt.)
-  const float band = vs_band(kp), b = (float)((lo >> 1) & kVsU2Mask);
-  accepted = b + 1.0f <= a * ((1.0f - band) * kVsU2Scale);
-  rejected = b >= a * ((1.0f + band) * kVsU2Scale);
+// acceptance probability of one attempt in fp32; the bin's code comes back for the caller
+__device__ __forceinline__ float vs_accept_prob(uint32_t hi, float kp, uint32_t cls, const VsTable &tab, uint32_t &code) {
+  const uint8_t *row = tab.base + cls;   // the class's rows of code[][] and (kVsLwOff further on) of lw[][]
+  code = row[hi >> 26];
+  const float2 scr = *(const float2 *)(tab.base + kVsScrOff + code);
+  const float sn = sinf_half_pi(fmaf(scr.y, (float)(hi << 6), scr.x));   // cos|x|
+  return __builtin_amdgcn_exp2f(fmaf(kp, sn - 1.0f, *(const float *)(row + kVsLwOff + code)));
 }
 
 // the exact test: u2 = (b + tail) / 2^22 against exp(kappa (cos x - 1)) 2^lw, in logarithms
-__device__ __forceinline__ int vs_exact(uint32_t lo, uint32_t hi, uint32_t code, double tail, double kappa, float lw) {
-  const double u2 = ((double)((lo >> 1) & kVsU2Mask) + tail) * (1.0 / (double)(1u << kVsU2Bits));
-  const double la = fma(kappa, cospi_unit(vs_theta(lo, hi, code) * (1.0 / kPi)) - 1.0, 0.69314718055994531 * (double)lw);
+__device__ __forceinline__ int vs_exact(uint32_t lo, uint32_t hi, uint32_t code, double tail, double kappa, float lw, const VsTable &tab) {
+  const double u2 = ((double)(lo >> (32 - kVsU2Bits)) + tail) * (1.0 / (double)(1u << kVsU2Bits));
+  const double la = fma(kappa, cospi_unit(vs_theta(lo, hi, code, tab) * (1.0 / kPi)) - 1.0, 0.69314718055994531 * (double)lw);
   return (u2 <= 0.0 || log_unit(u2) <= la) ? 1 : 0;
 }
 
-// The open decisions of a pair of attempts, taken exactly (one attempt in ~10^3 gets here).  Not inlined: the fp64
+// The open decisions of a pair of attempts, taken exactly (one attempt in ~10^4 gets here).  Not inlined: the fp64
 // polynomial coefficients of this path would otherwise be hoisted into scalar registers for the whole kernel and push
 // the hot loop's own constants out (the hot loop then reloads them with v_readlane every iteration).
 __device__ __attribute__((noinline)) uint32_t vs_exact_pair(uint32_t k0, uint32_t k1, uint32_t chain, uint32_t step, uint32_t site,
                                                             uint32_t w3, U4 q, uint32_t codes, float lwa, float lwb, double kappa,
-                                                            int sa, int sb) {
+                                                            int sa, int sb, const uint8_t *tab_base) {
+  const VsTable tab{tab_base, 0.f, 0.f};
   const U4 e = philox4x32_10(site, chain, step, w3 | kVmRefine, k0, k1);
-  if (sa < 0) sa = vs_exact(q.x, q.y, codes & 0xFFu, u01(e.x, e.y), kappa, lwa);
-  if (sa == 0 && sb < 0) sb = vs_exact(q.z, q.w, codes >> 8, u01(e.z, e.w), kappa, lwb);
+  if (sa < 0) sa = vs_exact(q.x, q.y, codes & 0xFFu, u01(e.x, e.y), kappa, lwa, tab);
+  if (sa == 0 && sb < 0) sb = vs_exact(q.z, q.w, codes >> 8, u01(e.z, e.w), kappa, lwb, tab);
   return (uint32_t)(sa & 3) | ((uint32_t)(sb & 3) << 2);   // two's complement in two bits each: 3 = open (cannot remain), 1, 0
 }
 
@@ -658,112 +677,180 @@ __device__ __forceinline__ bool vs_attempt_pair(const RngKey &k, uint32_t site, 
                                                 uint32_t sub0 = 0) {
   const uint32_t w3 = (P_VONMISES << 24) | sub0 | pair;
   const U4 q = philox4x32_10(site, k.chain, k.step, w3, k.k0, k.k1);
-  uint32_t ba, bb;
-  bool acc_a, rej_a, acc_b, rej_b;  // lane masks: the decisions stay on the scalar side
-  vs_try(q.x, q.y, kp, cls, tab, ba, acc_a, rej_a);
-  vs_try(q.z, q.w, kp, cls, tab, bb, acc_b, rej_b);
-  // open: the first attempt undecided, or rejected and the second undecided
-  if (!acc_a && (!rej_a || (!acc_b && !rej_b))) {
-    const uint32_t r = vs_exact_pair(k.k0, k.k1, k.chain, k.step, site, w3, q, ba | (bb << 8), tab.lw[cls * 16 + (ba & 15u)],
-                                     tab.lw[cls * 16 + (bb & 15u)], kappa_exact(), rej_a ? 0 : -1, acc_b ? 1 : rej_b ? 0 : -1);
-    acc_a = (r & 3u) == 1u;
-    acc_b = (r >> 2) == 1u;
+  uint32_t ca, cb;
+  const float pa = vs_accept_prob(q.y, kp, cls, tab, ca), pb = vs_accept_prob(q.w, kp, cls, tab, cb);
+  const float la = (float)q.x, lb = (float)q.z;
+  bool acc_a = la <= fmaf(pa, tab.s_acc, -kVsU2Slack), acc_b = lb <= fmaf(pb, tab.s_acc, -kVsU2Slack);  // lane masks
+  if (!acc_a) {
+    const bool rej_a = la >= fmaf(pa, tab.s_rej, kVsU2Slack), rej_b = lb >= fmaf(pb, tab.s_rej, kVsU2Slack);
+    // open: the first attempt undecided, or rejected and the second undecided
+    if (!rej_a || (!acc_b && !rej_b)) {
+      const uint8_t *row = tab.base + cls + kVsLwOff;
+      const uint32_t r = vs_exact_pair(k.k0, k.k1, k.chain, k.step, site, w3, q, ca | (cb << 8), *(const float *)(row + ca),
+                                       *(const float *)(row + cb), kappa_exact(), rej_a ? 0 : -1, acc_b ? 1 : rej_b ? 0 : -1, tab.base);
+      acc_a = (r & 3u) == 1u;
+      acc_b = (r >> 2) == 1u;
+    }
   }
   const bool first = acc_a;
   const uint32_t lo = first ? q.x : q.z, hi = first ? q.y : q.w;
-  theta = vs_theta(lo, hi, first ? ba : bb);
-  negative = (lo & 1u) != 0;
+  theta = vs_theta(lo, hi, first ? ca : cb, tab);
+  negative = (lo & 0x200u) != 0;
   return acc_a || acc_b || pair + 1 >= kMaxVmPairs;
 }
 
-// Retry pool of the step-envelope phases.  After the first pair of attempts ~5 % of the cells are still open.  An entry
-// is just the cell's LDS offset and the index of its next pair -- everything else (stencil, centre, kappa) is recomputed
-// from the tile image, which the phase does not change under the cell.  Rounds: every thread takes entries of the
-// current buffer, gives each ONE pair of attempts and pushes what is still open into the other buffer; one barrier
-// per round; a round of at most one wave's worth of entries (nearly always the first) is finished by wave 0 in place.
-// Three counters in rotation (read in round r, filled for round r + 1, cleared for round r + 2) make one barrier per
-// round enough.
+// Work distribution of a step-envelope colour phase.  After the first pair of attempts ~5 % of the cells are still open.
+// Until r03 every thread owned a fixed list of cells (t, t + NT, ...), the open ones went into an LDS pool, and the pool
+// was worked off in rounds behind barriers: one or two waves walking a dependent chain while the others waited -- measured
+// at 12-16 % of the whole sampling step for 4.4 % of the cells.  Now the cells of a phase are a QUEUE (one LDS counter):
+// a wave hands the next cells to exactly those of its lanes that have none (one returning atomic per wave and iteration),
+// and a lane whose pair of attempts failed simply keeps its cell for the next iteration, alongside the fresh cells of its
+// neighbours.  Retries cost their 5 % of lane-iterations and nothing else, and the waves of a workgroup finish within one
+// iteration of each other, whatever their share of retries.  Only the cells that are still open when the queue has run
+// dry (about three per wave) go through a list in LDS -- entry = LDS offset of the cell and the index of its next pair;
+// stencil, centre and kappa are recomputed from the tile image, which the phase does not change under the cell -- and
+// are finished in place behind ONE barrier, one entry per thread (wave 0 as a rule).  Which random numbers a cell
+// consumes is fixed by (site, attempt), and cells of one colour phase do not read each other, so the result does not
+// depend on which lane draws which cell, nor when.
 template <class E>  // uint16_t: offset in 12 bits, next pair in 4 (compile-time 64 x 32 tiles); uint32_t: 16 + 16
 struct VsPool {
   static constexpr uint32_t kOffBits = sizeof(E) == 2 ? 12 : 16;
   static constexpr uint32_t kMaxPair = (1u << (8 * sizeof(E) - kOffBits)) - 1;
-  E *buf0;               // two buffers of `cap` entries, one behind the other (no pointer array: it would live in scratch)
-  uint32_t *count;       // [3]
-  uint32_t cap, round;   // capacity per buffer (0: no pool); rounds so far (uniform over the workgroup)
+  E *buf;                // `cap` entries
+  uint32_t *ctr;         // [0], [1]: queue heads of even / odd uses; [2], [3]: list lengths of even / odd uses
+  uint32_t cap, use;     // capacity of the list (0: none, leftovers are finished where they are); uses so far (uniform)
   VsTable tab;
-  // LDS bytes: table | counters | buffers
-  static __host__ __device__ constexpr size_t bytes(uint32_t cap) { return kVsTableBytes + 16 + ((size_t)2 * cap * sizeof(E) + 7) / 8 * 8; }
-  __device__ E *buf(uint32_t round_) const { return buf0 + ((round_ & 1u) ? cap : 0u); }
-  __device__ static VsPool carve(double *lds, uint32_t cap, const uint32_t *d_table) {  // call from every thread
+  // LDS bytes: table | counters | list
+  static __host__ __device__ constexpr size_t bytes(uint32_t cap) { return kVsTableBytes + 16 + ((size_t)cap * sizeof(E) + 7) / 8 * 8; }
+  // call from every thread; the counters are visible after the caller's next barrier.  d_table == NULL: a kernel
+  // instance that never draws from the step envelope -- nothing in LDS is touched.
+  __device__ static VsPool carve(double *lds, uint32_t cap, const uint32_t *d_table) {
     VsPool p;
     p.tab = VsTable::stage(lds, d_table);
-    p.count = (uint32_t *)((uint8_t *)lds + kVsTableBytes);
-    p.buf0 = (E *)(p.count + 4);
+    p.ctr = (uint32_t *)((uint8_t *)lds + kVsTableBytes);
+    p.buf = (E *)(p.ctr + 4);
     p.cap = cap;
-    p.round = 0;
-    if (cap && threadIdx.x < 3) p.count[threadIdx.x] = 0;
+    p.use = 0;
+    if (d_table && threadIdx.x < 4) p.ctr[threadIdx.x] = 0;
     return p;
   }
 };
 
 // One colour phase.  off_of(idx) = LDS offset of cell idx of the phase; setup(off, cell) = centre, class, kappa', Philox
-// site from the tile image; kappa_exact(off) = the fp64 concentration (rare); commit(off, angle).
-// Round 0 walks the cells of the phase (thread t: cells t, t + NT, ...), later rounds the pool; both go through ONE copy
-// of the attempt code (the rare exact test would otherwise be inlined four times over and spill).
+// site from the tile image; kappa_exact(off) = the fp64 concentration (rare); commit(off, angle).  The caller puts a
+// barrier behind the call (every call site has one: the next phase reads what this one wrote).  One copy of the set-up
+// and of the attempt code serves fresh cells, retries and the leftover list (S is not used any more).
 template <int NT, int S, class E, class OffOf, class Setup, class KappaExact, class Commit>
 __device__ __forceinline__ void heatbath_cells_step(uint32_t total, const RngKey &key, VsPool<E> &pool, OffOf off_of, Setup setup,
                                                     KappaExact kappa_exact, Commit commit) {
   using P = VsPool<E>;
   constexpr uint32_t kOffMask = (1u << P::kOffBits) - 1;
-  uint32_t r = pool.round, n = total;
-  bool first = true, tail = false;
+  const uint32_t u = pool.use & 1u;
+  uint32_t *const queue = pool.ctr + u, *const left = pool.ctr + 2 + u;
+  // the counters of the NEXT use: last touched in the previous use, which ended before the caller's barrier behind it
+  if (threadIdx.x == 0) pool.ctr[u ^ 1u] = pool.ctr[2 + (u ^ 1u)] = 0;
+  const uint32_t lane = threadIdx.x & (kWave - 1);
+  bool have = false, dry = false, tail = false;
+  uint32_t off = 0, pair = 0, tail_next = threadIdx.x, n_left = 0;
+  VsCell c;
+#ifdef MLMCPI_QUEUE_PREFETCH
+  // The wave reserves cells 64 at a time, one reservation ahead of its needs: the returning atomic of a reservation is
+  // issued an iteration before its result is used, so its LDS round trip runs under the attempt code instead of in
+  // front of the stencil reads.  [cb, cb + cn): the reservation being handed out; nb: the next one (64 cells).
+  uint32_t cb = 0, cn = 0, nb = 0;
+  {
+    uint32_t b0 = 0;
+    if (lane == 0) b0 = atomicAdd(queue, 2u * kWave);
+    cb = (uint32_t)__builtin_amdgcn_readfirstlane((int)b0);
+    cn = kWave;
+    nb = cb + kWave;
+  }
+  uint32_t pending = 0;       // lane 0: result of the reservation issued in the previous iteration
+  bool have_pending = false;  // (uniform)
+#endif
   for (;;) {
-    // counter of round r + 2: read in round r - 1, pushed to in round r + 1
-    if (pool.cap && threadIdx.x == 0) pool.count[(r + 2) % 3] = 0;
-    for (uint32_t i = threadIdx.x; i < n; i += NT) {
-      uint32_t off, pair = 0;
-      if (first) {
-        off = off_of(i);
-      } else {
-        const uint32_t e = pool.buf(r)[i];
-        off = e & kOffMask;
-        pair = e >> P::kOffBits;
-      }
-      VsCell c;
-      setup(off, c);
-      double th = 0.0;
-      bool neg = false, in_place = tail;
-      for (;;) {  // one pair of attempts; more of them only for a cell that cannot go (back) to the pool
-        const bool done = vs_attempt_pair(key, c.site, pair, c.kp, c.cls, pool.tab, [&] { return kappa_exact(off); }, th, neg);
-        if (done) {
-          commit(off, mod_2pi_fast(c.centre + (neg ? -th : th)));
-          break;
-        }
-        ++pair;
-        if (!in_place) {
-          in_place = true;
-          if (pool.cap && pair <= P::kMaxPair) {
-            const uint32_t slot = atomicAdd(pool.count + (r + 1) % 3, 1u);
-            if (slot < pool.cap) {
-              pool.buf(r + 1)[slot] = (E)(off | (pair << P::kOffBits));
-              break;
+    bool fetched = false;
+    uint32_t f_off = 0, f_pair = 0;
+    if (!tail) {
+      if (!dry) {
+        const uint64_t need = __ballot(!have);
+        if (need) {  // wave-uniform
+          const uint32_t n = (uint32_t)__popcll(need);
+          const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+#ifdef MLMCPI_QUEUE_PREFETCH
+          if (n >= cn && have_pending) {  // cells of the next reservation are needed now: its atomic was issued an iteration ago
+            nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)pending);
+            have_pending = false;
+          }
+          const uint32_t idx = rank < cn ? cb + rank : nb + (rank - cn);
+          if (n >= cn) {  // the current reservation is used up: the next one takes its place, and a new one is asked for
+            const uint32_t used = n - cn;
+            cb = nb + used;
+            cn = kWave - used;
+            nb = total;   // (placeholder until the reservation asked for below is read, at the top of a later iteration)
+            if (cb < total) {
+              if (lane == 0) pending = atomicAdd(queue, (uint32_t)kWave);
+              have_pending = true;
             }
+          } else {
+            cb += n;
+            cn -= n;
+          }
+          dry = cb >= total;   // reservations only grow: nothing below `total` can come any more
+#else
+          uint32_t base = 0;
+          if (lane == 0) base = atomicAdd(queue, n);
+          base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+          dry = base + n >= total;
+          const uint32_t idx = base + rank;
+#endif
+          if (!have && idx < total) {
+            f_off = off_of(idx);
+            fetched = true;
+          }
+        }
+      }
+    } else if (!have && tail_next < n_left) {
+      const uint32_t e = pool.buf[tail_next];
+      tail_next += NT;
+      f_off = e & kOffMask;
+      f_pair = e >> P::kOffBits;
+      fetched = true;
+    }
+    if (fetched) {
+      off = f_off;
+      pair = f_pair;
+      setup(off, c);
+      have = true;
+    }
+    if (!__any(have)) {  // wave-uniform
+      if (tail) break;
+      __syncthreads();   // every wave gets here exactly once per call: the list of this phase is complete
+      tail = true;
+      n_left = min(*left, pool.cap);
+      continue;
+    }
+    if (have) {
+      double th = 0.0;
+      bool neg = false;
+      if (vs_attempt_pair(key, c.site, pair, c.kp, c.cls, pool.tab, [&] { return kappa_exact(off); }, th, neg)) {
+        commit(off, mod_2pi_fast(c.centre + (neg ? -th : th)));
+        have = false;
+      } else {
+        ++pair;
+        // no fresh cells left to share the next iteration with: hand the cell over (a full list, or a pair index the
+        // entry cannot hold, keeps it here, where the loop goes on until it is done)
+        if (dry && !tail && pair <= P::kMaxPair) {
+          const uint32_t slot = atomicAdd(left, 1u);
+          if (slot < pool.cap) {
+            pool.buf[slot] = (E)(off | (pair << P::kOffBits));
+            have = false;
           }
         }
       }
     }
-    if (!pool.cap || tail) break;
-    __syncthreads();
-    ++r;
-    first = false;
-    n = min(pool.count[r % 3], pool.cap);
-    if (n <= kWave) {  // the tail: wave 0 finishes it in place, one entry per lane; nothing is pushed any more
-      tail = true;
-      if (threadIdx.x == 0) pool.count[r % 3] = 0;  // (a wave that reads the counter after this sees 0 entries and leaves as well)
-      if (n == 0 || threadIdx.x >= kWave) break;
-    }
   }
-  pool.round = r;
+  ++pool.use;
 }
 
 // one draw x ~ exp(kappa cos(x - centre)) for the conditional between x_p and x_m (test hook; the sweeps go through

@@ -142,20 +142,16 @@ __device__ __forceinline__ void heatbath_region_step(uint32_t nr, uint32_t nc, u
                                   setup, kappa_exact, commit);
     return;
   }
-  uint32_t cur = threadIdx.x, ri = cur / nc, ci = cur - ri * nc;
-  const uint32_t dr = NT / nc, dc = NT - dr * nc;
+  // runtime nc: cells are handed out by a queue (heatbath_cells_step), in no particular order per thread, so (row, column)
+  // come from a division -- by a reciprocal computed once, exact for the indices that occur (idx < 2^16 <= 2^24 / nc)
+  const float rcp = 1.0f / (float)nc;
   heatbath_cells_step<NT, S, E>(nr * nc, key, pool,
-                                [&](uint32_t idx) {  // a thread's cells come in increasing order, NT apart
-                                  while (cur < idx) {
-                                    cur += NT;
-                                    ri += dr;
-                                    ci += dc;
-                                    if (ci >= nc) {
-                                      ci -= nc;
-                                      ++ri;
-                                    }
-                                  }
-                                  return origin + ri * row_stride + ci * col_stride;
+                                [&](uint32_t idx) {
+                                  uint32_t ri = (uint32_t)(((float)idx + 0.5f) * rcp);
+                                  int32_t ci = (int32_t)(idx - ri * nc);
+                                  if (ci < 0) { --ri; ci += (int32_t)nc; }
+                                  else if (ci >= (int32_t)nc) { ++ri; ci -= (int32_t)nc; }
+                                  return origin + ri * row_stride + (uint32_t)ci * col_stride;
                                 },
                                 setup, kappa_exact, commit);
 }
@@ -1687,7 +1683,7 @@ __global__ void __launch_bounds__(64)
     double *th = state + (size_t)b * 2 * Mt * Mx;
     auto link = [&](uint32_t i, uint32_t j, uint32_t mu) -> double & { return th[2 * (Mt * j + i) + mu]; };
     const bool step = 2. * coupling <= kVsKappaMax;
-    const VsTable tab{(const uint8_t *)vs_table, (const float *)((const uint8_t *)vs_table + kVsClasses * kVsSel)};
+    const VsTable tab = VsTable::in_global(vs_table);
     for (uint32_t q = 0; q < n; ++q) {
       const uint32_t l = sites ? sites[q] : single;
       const uint32_t mu = l & 1u, v = l >> 1, j = v / Mt, i = v - j * Mt;

@@ -593,7 +593,7 @@ __global__ void __launch_bounds__(64)
   double *x = x_all + (size_t)b * P.M;
   const double sig_scale = 2.0 * P.m0 / P.a;
   const bool step = sig_scale <= kVsKappaMax;
-  const VsTable tab{(const uint8_t *)vs_table, (const float *)((const uint8_t *)vs_table + kVsClasses * kVsSel)};
+  const VsTable tab = VsTable::in_global(vs_table);
   for (uint32_t q = 0; q < n; ++q) {
     const uint32_t l = sites ? sites[q] : single;
     const double xm = x[l == 0 ? P.M - 1 : l - 1], xp = x[l + 1 == P.M ? 0 : l + 1];

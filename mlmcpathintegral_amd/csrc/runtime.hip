@@ -164,21 +164,30 @@ void vs_build_tables(double scale, int *q_out, float *lw) {
   }
 }
 
-// the device image (device_common.hpp, VsTable): code[class][64] | lw[class][16]
+// the device image (device_common.hpp, "Device image of the tables"): code | scr | lw | fin | consts
 static void vs_device_image(double scale, uint32_t *image) {
   int q[kVsClasses * kVsBins];
   float lw[kVsClasses * kVsBins];
   vs_build_tables(scale, q, lw);
   memset(image, 0, kVsTableBytes);
-  uint8_t *code = (uint8_t *)image;
-  float *lw16 = (float *)(code + kVsClasses * kVsSel);
+  uint8_t *bytes = (uint8_t *)image;
   for (int c = 0; c < kVsClasses; ++c) {
     int pos = 0;
     for (int k = 0; k < kVsBins; ++k) {
-      for (int i = 0; i < q[c * kVsBins + k]; ++i) code[c * kVsSel + pos++] = (uint8_t)(vs_edge16(k) | (vs_width16(k) << 4));
-      lw16[c * 16 + vs_edge16(k)] = lw[c * kVsBins + k];
+      for (int i = 0; i < q[c * kVsBins + k]; ++i) bytes[kVsCodeOff + c * kVsSel + pos++] = (uint8_t)(8 * k);
+      memcpy(bytes + kVsLwOff + c * kVsSel + 8 * k, &lw[c * kVsBins + k], 4);
     }
   }
+  for (int k = 0; k < kVsBins; ++k) {
+    const double e = vs_edge16(k), w = vs_width16(k);
+    const float scr[2] = {(float)(0.5 * kPi - (kPi / 16.0) * e), (float)(-(kPi / 16.0) * w / 4294967296.0)};
+    const double fin[2] = {64.0 * w, e - 64.0 * w};
+    memcpy(bytes + kVsScrOff + 8 * k, scr, 8);
+    memcpy(bytes + kVsFinOff + 16 * k, fin, 16);
+  }
+  const float band = vs_band_of_scale(scale);
+  const float consts[4] = {4294967296.0f * (1.0f - band), 4294967296.0f * (1.0f + band), 0.f, 0.f};
+  memcpy(bytes + kVsConstOff, consts, 16);
 }
 
 namespace {

@@ -75,8 +75,9 @@ def main():
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    # One chain per core the job may actually use: the scheduler affinity, cut down to the cgroup CPU quota when there is
-    # one, and to 16 (the CPU share of a 1-GPU job on the GPU boxes, where the affinity mask shows the whole host).
+    # One chain per core the job may use: the scheduler affinity, cut down to the cgroup CPU quota when there is one
+    # ("1 chain per core on all host cores").  A second point on 16 cores -- the CPU share of a
+    # 1-GPU job on the GPU boxes, whose affinity mask shows the whole host -- is taken when more than 16 are available.
     quota = avail
     try:
         q, period = open("/sys/fs/cgroup/cpu.max").read().split()
@@ -84,17 +85,25 @@ def main():
             quota = max(1, int(int(q) / int(period)))
     except (OSError, ValueError):
         pass
-    cores = a.cores or min(avail, quota, 16)
+    cores = a.cores or min(avail, quota)
     import oracle as O
     O.build()  # compile once, before forking
     job = (a.workload, a.size, a.draws, a.n_overrelax, a.n_heatbath, a.nt, a.dt)
-    t0 = time.perf_counter()
-    with mp.get_context("fork").Pool(cores) as pool:
-        res = pool.map(_worker, [job] * cores)
-    wall = time.perf_counter() - t0
-    rate = sum(u / el for u, el in res)  # all processes run concurrently: aggregate rate
-    print(json.dumps({"value": rate, "per_core": rate / cores, "cores": cores, "cores_available": avail, "wall_s": wall,
-                      "sample": f"{a.draws} draws per core of {a.workload} {a.size}, one chain per core"}))
+
+    def run(n):
+        t0 = time.perf_counter()
+        with mp.get_context("fork").Pool(n) as pool:
+            res = pool.map(_worker, [job] * n, chunksize=1)
+        wall = time.perf_counter() - t0
+        rate = sum(u / el for u, el in res)  # all processes run concurrently: aggregate rate
+        return {"value": rate, "per_core": rate / n, "cores": n, "wall_s": wall}
+
+    out = run(cores)
+    out.update(cores_available=avail, cpu_quota=quota,
+               sample=f"{a.draws} draws per core of {a.workload} {a.size}, one chain per core")
+    if cores > 16 and not a.cores:
+        out["point_16"] = run(16)
+    print(json.dumps(out))
 
 
 if __name__ == "__main__":

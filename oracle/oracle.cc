@@ -288,14 +288,15 @@ inline double dev_vonmises_table(const DevRng &rng, uint32_t site, double scale,
     bool accepted = false;
     for (int h = 0; h < 2 && !accepted; ++h) {
       const uint32_t lo = w.v[2 * h], hi = w.v[2 * h + 1];
-      const uint64_t bits = ((uint64_t)hi << 32) | lo;
       int sel = (int)(hi >> 26), k = 0;
       while (sel >= T.q[cls][k]) sel -= T.q[cls][k++];
-      // fields of an attempt: bit 0 sign, bits 1..22 the leading bits of u2, bits 23..57 position in the bin, 58..63 selector
-      const double pos = (double)((bits >> 23) & ((1ull << 35) - 1)) * (1.0 / 34359738368.0);  // 35 bits
+      // fields of an attempt (r04 layout): lo[31..10] the 22 leading bits of u2, lo[9] sign, lo[8..0] the low 9 position
+      // bits; hi[31..26] selector, hi[25..0] the high 26 position bits
+      const uint64_t pos35 = ((uint64_t)(hi & 0x3FFFFFFu) << 9) | (lo & 0x1FFu);
+      const double pos = (double)pos35 * (1.0 / 34359738368.0);  // 35 bits
       theta = (kPi / 16.0) * ((double)e16[k] + (double)(e16[k + 1] - e16[k]) * pos);
-      negative = (lo & 1u) != 0;
-      const double u2 = ((double)((lo >> 1) & 0x3FFFFFu) + u01(e.v[2 * h], e.v[2 * h + 1])) * (1.0 / 4194304.0);
+      negative = (lo & 0x200u) != 0;
+      const double u2 = ((double)(lo >> 10) + u01(e.v[2 * h], e.v[2 * h + 1])) * (1.0 / 4194304.0);
       accepted = u2 <= 0.0 || std::log(u2) <= kappa * (std::cos(theta) - 1.0) + 0.69314718055994531 * (double)T.lw[cls][k];
     }
     if (accepted) break;

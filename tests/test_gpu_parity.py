@@ -1120,3 +1120,65 @@ def test_gff_exact_sampler_matches_oracle(gpu_ops, orc, Mt, mass, B):
             assert_close(phi[b], want, tol=1e-12, scale=float(np.max(np.abs(want))), what=f"GFF exact draw {step} chain {b}")
     with pytest.raises(abi.MlmcpiError, match="only for the GFF"):
         gpu_ops.GFFExactSampler(abi.lattice_action(4, 8, 8, beta=1.0), 1)
+
+
+# ---- the device's angle samplers against the analytic law, with no oracle in between ---------------------------------
+# (oracle.cc::dev_vonmises_table was written in lockstep with device_common.hpp, so device == oracle is
+# close to a self-comparison there.  Here 2 10^5 DEVICE draws per case go straight against the quadrature CDF of
+# p(x) ~ exp(kappa cos(x - centre)) (expcosdistribution.cc:7-21) and the closed form <cos> = I1 / I0.)
+def _vonmises_cdf(kappa):
+    from scipy import integrate
+    grid = np.linspace(-np.pi, np.pi, 8001)
+    cdf = integrate.cumulative_trapezoid(np.exp(kappa * (np.cos(grid) - 1.0)), grid, initial=0.0)
+    cdf /= cdf[-1]
+    return lambda x: np.interp(x, grid, cdf)
+
+
+_VS_CASES = [(2.0, 0.0), (2.0, 0.45), (2.0, 0.85), (2.0, 1.25), (2.0, 1.65), (2.0, 2.05), (2.0, 2.45), (2.0, 2.8), (2.0, 3.1),
+             (4.0, 0.2), (4.0, 1.9), (4.0, 4.5), (0.6, 1.0), (3.0, -7.0), (0.0, 1.0)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scale,d", _VS_CASES)
+def test_device_step_envelope_draws_follow_the_von_mises_law(gpu_ops, scale, d):
+    """mlmcpi_test_vs_draw (the sweeps' sampler at 2 beta, 2 m0 / a <= 4) over all eight concentration classes
+    (class = floor(32 | |d / 4 pi| mod 1/2 - 1/4 |): d = 0 ... pi walks from class 7 down to class 0)."""
+    from scipy import stats
+    from scipy.special import i0e, i1e
+    from conftest import zcheck
+    n = 200000
+    x_p = torch.full((n,), 0.4, dtype=torch.float64, device="cuda")
+    x_m = x_p + d
+    draws = gpu_ops.test_vs_draw(20261004, 3, 11, scale, x_p, x_m).cpu().numpy()
+    assert (np.abs(draws) <= np.pi + 1e-12).all()
+    kappa = scale * abs(np.cos(0.5 * d))
+    centre = 0.4 + 0.5 * d + (np.pi if np.cos(0.5 * d) < 0 else 0.0)
+    rel = draws - centre
+    rel -= 2 * np.pi * np.round(rel / (2 * np.pi))
+    ks = stats.kstest(rel, _vonmises_cdf(kappa))
+    assert ks.pvalue > 1e-3, (scale, d, ks)
+    # symmetry about the centre (the sign bit) and the first trigonometric moment
+    zcheck(f"device vs_draw scale={scale} d={d}: <sin>", float(np.sin(rel).mean()), float(np.sin(rel).std() / np.sqrt(n)), 0.0, gate=4.5)
+    zcheck(f"device vs_draw scale={scale} d={d}: <cos>", float(np.cos(rel).mean()), float(np.cos(rel).std() / np.sqrt(n)),
+           float(i1e(kappa) / i0e(kappa)), gate=4.5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("beta,d", [(1.0, 0.7), (1.0, 2.9), (2.5, 0.3), (2.5, 2.2), (6.0, 1.5), (40.0, 0.1), (0.05, 1.0)])
+def test_device_expcos_draws_follow_the_von_mises_law(gpu_ops, beta, d):
+    """mlmcpi_test_expcos: the wrapped-Cauchy sampler the sweeps use beyond 2 beta = 4 (and the two-level fill-ins always)"""
+    from scipy import stats
+    from scipy.special import i0e, i1e
+    from conftest import zcheck
+    n = 200000
+    x_p = torch.full((n,), -0.3, dtype=torch.float64, device="cuda")
+    x_m = x_p + d
+    draws = gpu_ops.test_expcos(77, 1, 5, beta, x_p, x_m).cpu().numpy()
+    kappa = 2.0 * beta * abs(np.cos(0.5 * d))
+    centre = -0.3 + 0.5 * d + (np.pi if np.cos(0.5 * d) < 0 else 0.0)
+    rel = draws - centre
+    rel -= 2 * np.pi * np.round(rel / (2 * np.pi))
+    ks = stats.kstest(rel, _vonmises_cdf(kappa))
+    assert ks.pvalue > 1e-3, (beta, d, ks)
+    zcheck(f"device expcos beta={beta} d={d}: <cos>", float(np.cos(rel).mean()), float(np.cos(rel).std() / np.sqrt(n)),
+           float(i1e(kappa) / i0e(kappa)), gate=4.5)

@@ -38,7 +38,7 @@ out = {"_how": "tools/profile_all.sh: rocprofv3 --pmc <counters> --kernel-trace 
                "averages over every launch of the run.  FETCH_SIZE / WRITE_SIZE are KiB; FETCH_SIZE is doubled (gfx950 counts a "
                "128-byte request of a 16-byte-per-lane streaming read as 64 B, MI355X_MICROARCH.md HBM section); WRITE_SIZE is "
                "exact.  `build` = hash of the kernel sources (bench.py build_id()).  Raw summary: profiles/%s_profile_summary.json." % tag,
-       "entries": [], "valu": [], "kernels_valu_busy": []}
+       "entries": [], "valu": [], "kernels_valu_busy": [], "probes": []}
 # The kernels bench.py's TIMED region spends its time in, by workload (name substrings).  The profiled run also holds
 # what precedes the timed steps -- thermalisation with other kernels or other shapes (ho_hmc: 32 single-trajectory launches
 # at a sixth of the chain kernel's utilisation; quartic_mlmc_hier: direct HMC on every level) -- and a utilisation averaged
@@ -75,6 +75,13 @@ for w, e in S.items():
             fuse = int(short.split("<")[1].split(">")[0])
         if "or_heat_kernel<" in short:
             fuse = int(short.split("<")[1].split(">")[0].split(",")[0]) + 1   # <K> or <K, wide>
+        # bench.py's hbm_bound_probes (schwinger, --probes): single launches of the HBM-bound kernels of the path
+        if w == "schwinger" and "hbm_bytes_per_launch" in k and any(
+                t in short for t in ("schwinger_or_block_kernel<1>", "schwinger_reduce_band_kernel", "schwinger_force_kernel")):
+            out["probes"].append({"workload": w, "size": SIZES[w], "chains": CHAINS[w], "kernel": short,
+                                  "hbm_bytes_per_launch": k["hbm_bytes_per_launch"], "read_bytes": k["read_bytes_corrected"],
+                                  "write_bytes": k["write_bytes"], "launches": k.get("FETCH_SIZE_launches"), "build": build,
+                                  "source": f"profiles/{tag}_profile_summary.json"})
         if kind and w in ("schwinger", "gff", "rotor_sweep"):
             if "hbm_bytes_per_launch" in k:
                 out["entries"].append({"workload": w, "size": SIZES[w], "chains": CHAINS[w], "fuse": fuse, "kind": kind, "kernel": short,

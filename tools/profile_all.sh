@@ -14,6 +14,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for W in ${WORKLOADS:-schwinger gff rotor_hmc quartic_mlmc quartic_mlmc_hier rotor_sweep quartic_hmc ho_hmc}; do
   ARGS="--workload $W --steps 5 --warmup 2 --no-cpu-baseline --no-extra-points"
+  if [ $W = schwinger ]; then ARGS="$ARGS --probes"; fi   # + single launches of the HBM-bound kernels (bench.py hbm_bound_probes)
   mkdir -p $OUT/$W
   timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$W/stats -- python3 $ROOT/bench.py $ARGS > $OUT/$W/stats.log 2>&1 || { echo "$W: stats pass failed"; tail -3 $OUT/$W/stats.log; exit 1; }
   grep '^{' $OUT/$W/stats.log | tail -1 > $OUT/$W/bench_profiled.json

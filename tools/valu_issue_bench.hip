@@ -1,7 +1,7 @@
 // valu_issue_bench.hip -- issue cost of the vector instructions the heat-bath kernel is made of, relative to v_add_f32.
 // Every kernel runs the same loop of independent instructions (8 register chains) on every SIMD of the chip with 8
 // waves per SIMD; time / (instructions per wave x waves per SIMD) is the issue cost per wave-instruction.
-//   hipcc --offload-arch=gfx950 -O3 tools/valu_issue_bench.hip -o gpurun_out/valu_issue_bench && gpurun_out/valu_issue_bench
+//   hipcc --offload-arch=gfx950 -O3 tools/valu_issue_bench.hip -o tools/build/valu_issue_bench (build/ is git-ignored but travels to the GPU box)
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdint.h>
@@ -52,6 +52,31 @@
 #define B_FRACT64(i) asm volatile("v_fract_f64 %0, %0" : "+v"(a##i));
 #define B_RNDNE64(i) asm volatile("v_rndne_f64 %0, %0" : "+v"(a##i));
 
+#define B_BITOP3(i) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(a##i) : "v"(b), "v"((uint32_t)i + 3u));
+#define B_BITOP3S(i) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(a##i) : "v"(b), "s"(sk));
+#define B_XORS(i) asm volatile("v_xor_b32 %0, %1, %0" : "+v"(a##i) : "s"(sk));
+#define B_CVTF32U32(i) asm volatile("v_cvt_f32_u32 %0, %0" : "+v"(a##i));
+#define B_CVTUB0(i) asm volatile("v_cvt_f32_ubyte0 %0, %0" : "+v"(a##i));
+#define B_EXP32(i) asm volatile("v_exp_f32 %0, %0" : "+v"(a##i));
+#define B_LSHLADD(i) asm volatile("v_lshl_add_u32 %0, %0, 2, %1" : "+v"(a##i) : "v"(b));
+#define B_ADD3(i) asm volatile("v_add3_u32 %0, %0, %1, %1" : "+v"(a##i) : "v"(b));
+#define B_MINU(i) asm volatile("v_min_u32 %0, %0, %1" : "+v"(a##i) : "v"(b));
+#define B_FMAAK(i) asm volatile("v_fmaak_f32 %0, %0, %1, 0x3c088889" : "+v"(a##i) : "v"(b));
+#define B_CMPF32(i) asm volatile("v_cmp_lt_f32 vcc, %0, %1" :: "v"(a##i), "v"(c) : "vcc");
+#define B_CVTU32F64(i) { uint32_t t; asm volatile("v_cvt_u32_f64 %0, %1" : "=v"(t) : "v"(a##i)); asm volatile("" :: "v"(t)); }
+#define UDECLS UDECL uint32_t sk = __builtin_amdgcn_readfirstlane(blockIdx.x * 7u + 3u);
+KERNEL(k_bitop3, UDECL, B_BITOP3, USINK)
+KERNEL(k_bitop3_sgpr, UDECLS, B_BITOP3S, USINK)
+KERNEL(k_xor_sgpr, UDECLS, B_XORS, USINK)
+KERNEL(k_cvt_f32_u32, UDECL, B_CVTF32U32, USINK)
+KERNEL(k_cvt_f32_ubyte0, UDECL, B_CVTUB0, USINK)
+KERNEL(k_exp32, FDECL, B_EXP32, DSINK)
+KERNEL(k_lshl_add, UDECL, B_LSHLADD, USINK)
+KERNEL(k_add3, UDECL, B_ADD3, USINK)
+KERNEL(k_min_u32, UDECL, B_MINU, USINK)
+KERNEL(k_fmaak32, FDECL, B_FMAAK, DSINK)
+KERNEL(k_cmp32, FDECL, B_CMPF32, DSINK)
+KERNEL(k_cvt_u32_f64, DDECL, B_CVTU32F64, DSINK)
 KERNEL(k_fma64, DDECL, B_FMA64, DSINK)
 KERNEL(k_add64, DDECL, B_ADD64, DSINK)
 KERNEL(k_mul64, DDECL, B_MUL64, DSINK)
@@ -110,5 +135,7 @@ int main() {
   RUN(k_rsq64); RUN(k_floor64); RUN(k_fract64); RUN(k_rndne64); RUN(k_ldexp64); RUN(k_cmp64); RUN(k_cvt_f32_f64);
   RUN(k_cvt_f64_u32); RUN(k_xor); RUN(k_add_u32); RUN(k_lshr); RUN(k_and_or); RUN(k_bfe); RUN(k_alignbit); RUN(k_mullo);
   RUN(k_mulhi); RUN(k_mad_u64_u32); RUN(k_cndmask_sgpr);
+  RUN(k_bitop3); RUN(k_bitop3_sgpr); RUN(k_xor_sgpr); RUN(k_cvt_f32_u32); RUN(k_cvt_f32_ubyte0); RUN(k_exp32); RUN(k_lshl_add);
+  RUN(k_add3); RUN(k_min_u32); RUN(k_fmaak32); RUN(k_cmp32); RUN(k_cvt_u32_f64);
   return 0;
 }
