@@ -33,7 +33,9 @@ WORKLOADS = ["schwinger", "gff", "rotor_hmc", "quartic_hmc", "ho_hmc", "quartic_
 DEFAULT_SIZE = {"schwinger": 1024, "gff": 512, "rotor_hmc": 65536, "quartic_hmc": 32768, "ho_hmc": 128,
                 "quartic_mlmc": 32768, "quartic_mlmc_hier": 32768, "rotor_sweep": 65536}
 DEFAULT_CHAINS = {"schwinger": 32, "gff": 1024, "rotor_hmc": 1024, "quartic_hmc": 2048, "ho_hmc": 8192,
-                  "quartic_mlmc": 512, "quartic_mlmc_hier": 512, "rotor_sweep": 1024}
+                  # quartic_mlmc_hier: the plateau of tools/scan_hier_chains.sh (512: 1.04, 1024: 1.24, 2048: 1.35, 4096: 1.35 T
+                  # site-steps/s: the coarsest-level HMC kernel is one 256-thread workgroup per chain, 2048 chains = 8 waves per SIMD)
+                  "quartic_mlmc": 512, "quartic_mlmc_hier": 2048, "rotor_sweep": 1024}
 
 
 def parse():
@@ -225,6 +227,9 @@ def fast_path_cliff(torch, abi, ops, a, rank, headline_rate):
             ("1024 x 992 (64 x 32 tiles)", "schwinger", 1024, 992, 1.0, 32,
              "2 x 2 register-patch overrelaxation launches (4 sweeps each) + step-envelope heat bath on 64 x 32 tiles"),
             ("192 x 96", "schwinger", 192, 96, 1.0, 1024, "as 1024 x 992"),
+            ("64 x 64", "schwinger", 64, 64, 1.0, 4096,
+             "register-block overrelaxation launches + generic heat-bath kernel (one 64 x 64 tile is the lattice: the fused "
+             "launch's image would wrap around it twice)"),
             ("gff 96 x 96", "gff", 96, 96, None, 8192, "gff_sweep_kernel: generic tiles, 4 sweeps per launch")):
         act = abi.lattice_action(abi.SCHWINGER, Mt, Mx, beta=beta) if kind == "schwinger" else abi.lattice_action(abi.GFF, Mt, Mx, mass=10.0)
         sites = (2 if kind == "schwinger" else 1) * Mt * Mx
@@ -451,6 +456,14 @@ def main():
             rccl = {"ranks": chk["ranks"], "lib": comm.library_path(), "runtime": comm.runtime_path(),
                     "allreduce_check": chk["allreduce_check"], "expected": chk["expected"],
                     "rendezvous": "128-byte id broadcast with torch.distributed"}
+            # two RCCL communicators live in this process (torch's process group and the library's): say whether they
+            # run on one librccl file or two -- the pairing the first multi-GPU run exercises
+            mapped = comm.mapped_rccl_files()
+            rccl["mapped_librccl"] = mapped
+            rccl["one_runtime_for_both_communicators"] = len(mapped) == 1 and os.path.realpath(comm.runtime_path() or "") == mapped[0]
+            if not rccl["one_runtime_for_both_communicators"]:
+                rccl["note"] = ("torch.distributed and libmlmcpi_rccl.so bind different librccl files (or more than one is "
+                                "mapped): two RCCL runtimes in one process")
         else:
             exchange, chk = comm.establish(rank, world, dist, torch, lambda: TorchExchange(torch, dist))
             rccl = {"ranks": chk["ranks"], "lib": None, "runtime": None, "allreduce_check": chk["allreduce_check"],
@@ -718,6 +731,18 @@ def main():
                               "hierarchical_acceptance_rank0": {str(l): {str(k): round(v, 4) for k, v in lv.sampler.p_accept().items()}
                                                                 for l, lv in est.levels.items()},
                               "run_to_epsilon": hier_run}
+            # Levels whose two-level steps never accepted in this run: the chains of such a level do not move beyond their
+            # (untimed, direct-HMC) initial sample, so the estimate and its error bar rest on one effective sample per
+            # chain there and the throughput counts proposals that are never accepted.  Faithful to the reference's
+            # configuration (T_final = 4096, a = 0.125: the fine-level fill-in is too wide to be accepted) -- said in the line.
+            hacc = result["mlmc"]["hierarchical_acceptance_rank0"]
+            frozen = sorted({int(k) for acc in hacc.values() for k, v in acc.items() if v == 0.0})
+            result["mlmc"]["frozen_levels"] = frozen
+            if frozen:
+                result["mlmc"]["frozen_levels_note"] = (
+                    "two-level acceptance 0 on these levels: their chains stay at the untimed direct-HMC sample; the z-score "
+                    "against single-level HMC then checks that initialisation, not the hierarchical sampler, and 'epsilon "
+                    "reached' comes from independent frozen chains.  See the T_final = M_lat / 32 line for moving chains")
             launch_ms = ms(events) / a.steps
             floor = 16.0 * sum(lv.n_sub * lv.B * lv.sampler.acts[-1].M for lv in est.levels.values())  # coarsest states, once per trajectory
             result["roofline"] = register_resident_roofline(

@@ -60,6 +60,21 @@ def torch_rccl_path():
     return hits[0] if hits else None
 
 
+def mapped_rccl_files():
+    """every librccl file this process has mapped (/proc/self/maps): torch.distributed's RCCL and the one the library
+    opened are the same file when the list has one entry"""
+    seen = []
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                path = line.split(None, 5)[-1].strip() if len(line.split(None, 5)) == 6 else ""
+                if "librccl" in os.path.basename(path) and os.path.realpath(path) not in seen:
+                    seen.append(os.path.realpath(path))
+    except OSError:
+        pass
+    return seen
+
+
 def open_runtime(path=None):
     p = path or os.environ.get("MLMCPI_RCCL_LIB") or torch_rccl_path()
     _check(load().mlmcpi_comm_load(p.encode() if p else None), "mlmcpi_comm_load")

@@ -223,6 +223,48 @@ __device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c
   return U4{c0, c1, c2, c3};
 }
 
+// Round keys in VECTOR registers.  MI355X issues a 32-bit VALU instruction whose operands are all VGPRs (or literals) at
+// 2.4 - 2.8 cycles per wave, the same instruction with an SGPR operand at 4.1 (tools/valu_issue_bench.hip,
+// profiles/r04_valu_issue_cost.txt: v_xor_b32 2.4 / 4.1, v_bitop3_b32 2.8 / 4.1).  The compiler keeps wave-uniform values --
+// the round keys -- in SGPRs, where the scalar unit bumps them for free, and pays for that in every one of the 2 x 10
+// key xors of a call.  Here the keys of rounds 2 .. 9 sit in 16 VGPRs (an opaque v_mov, so that they stay there) and a
+// round's  hi ^ counter ^ key  is ONE three-input v_bitop3_b32: 16 instructions at 2.8 cycles instead of 32 at 2.4 / 4.1.
+// Rounds 0 and 1 stay as they are: half of their operands are uniform and fold away on the scalar side.  Same function.
+struct PhiloxVKeys { uint32_t k[16]; };
+__device__ __forceinline__ uint32_t to_vgpr(uint32_t s) {
+  uint32_t v;
+  asm("v_mov_b32 %0, %1" : "=v"(v) : "s"(s));
+  return v;
+}
+__device__ __forceinline__ PhiloxVKeys philox_vkeys(uint32_t k0, uint32_t k1) {
+  PhiloxVKeys vk;
+#pragma unroll
+  for (int r = 2; r < 10; ++r) {
+    vk.k[2 * (r - 2)] = to_vgpr(k0 + (uint32_t)r * 0x9E3779B9u);
+    vk.k[2 * (r - 2) + 1] = to_vgpr(k1 + (uint32_t)r * 0xBB67AE85u);
+  }
+  return vk;
+}
+__device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                            const PhiloxVKeys &vk) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    if (r < 2) {
+      c0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+      c2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    } else {
+      c0 = __builtin_amdgcn_bitop3_b32((uint32_t)(p1 >> 32), c1, vk.k[2 * (r - 2)], 0x96);       // a ^ b ^ c
+      c2 = __builtin_amdgcn_bitop3_b32((uint32_t)(p0 >> 32), c3, vk.k[2 * (r - 2) + 1], 0x96);
+    }
+    c1 = (uint32_t)p1;
+    c3 = (uint32_t)p0;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return U4{c0, c1, c2, c3};
+}
+
 __device__ __forceinline__ double u01(uint32_t lo, uint32_t hi) {
   uint64_t v = ((uint64_t)hi << 32) | lo;
   return (double)(v >> 11) * (1.0 / 9007199254740992.0);
@@ -240,6 +282,13 @@ __device__ __forceinline__ void rng_normals(const RngKey &k, uint32_t site, uint
   double u, v;
   rng_uniforms(k, site, purpose, sub, u, v);
   box_muller(u, v, n0, n1);
+}
+
+// the same with the round keys in vector registers (philox_vkeys: hot loops that draw once per cell)
+__device__ __forceinline__ void rng_normals(const RngKey &k, const PhiloxVKeys &vk, uint32_t site, uint32_t purpose, uint32_t sub,
+                                            double &n0, double &n1) {
+  const U4 r = philox4x32_10(site, k.chain, k.step, (purpose << 24) | (sub & 0xFFFFFFu), k.k0, k.k1, vk);
+  box_muller(u01(r.x, r.y), u01(r.z, r.w), n0, n1);
 }
 
 // cosine branch only (one normal per call)
@@ -350,10 +399,11 @@ __device__ __forceinline__ int vm_exact(uint32_t lo, double tail, double c) {
 
 // Attempts 2 pair and 2 pair + 1; returns true when one of them is accepted (or when the attempt bound is hit).
 // f = cos(theta).  sub0 separates streams that share (site, chain, step): 0 for sweeps, kVmFillin for two-level fill-ins.
-__device__ __forceinline__ bool vm_attempt_pair(const RngKey &k, uint32_t site, uint32_t pair, double kappa, double R,
-                                                double &f, bool &negative, uint32_t sub0 = 0) {
+template <class Keys>   // RngKey alone, or RngKey + PhiloxVKeys (hot loops)
+__device__ __forceinline__ bool vm_attempt_pair_impl(const RngKey &k, const Keys *vk, uint32_t site, uint32_t pair, double kappa, double R,
+                                                     double &f, bool &negative, uint32_t sub0) {
   const uint32_t w3 = (P_VONMISES << 24) | sub0 | pair;
-  const U4 q = philox4x32_10(site, k.chain, k.step, w3, k.k0, k.k1);
+  const U4 q = vk ? philox4x32_10(site, k.chain, k.step, w3, k.k0, k.k1, *vk) : philox4x32_10(site, k.chain, k.step, w3, k.k0, k.k1);
   double fa, ca, fb, cb;
   int sa = vm_try(q.x, q.y, kappa, R, fa, ca), sb = vm_try(q.z, q.w, kappa, R, fb, cb);
   if (sa < 0 || (sa == 0 && sb < 0)) {  // a decision that matters is open: fetch the tails
@@ -364,6 +414,14 @@ __device__ __forceinline__ bool vm_attempt_pair(const RngKey &k, uint32_t site, 
   f = sa == 1 ? fa : fb;
   negative = ((sa == 1 ? q.x : q.z) & 1u) != 0;
   return sa == 1 || sb == 1 || pair + 1 >= kMaxVmPairs;
+}
+__device__ __forceinline__ bool vm_attempt_pair(const RngKey &k, uint32_t site, uint32_t pair, double kappa, double R,
+                                                double &f, bool &negative, uint32_t sub0 = 0) {
+  return vm_attempt_pair_impl<PhiloxVKeys>(k, nullptr, site, pair, kappa, R, f, negative, sub0);
+}
+__device__ __forceinline__ bool vm_attempt_pair(const RngKey &k, const PhiloxVKeys *vk, uint32_t site, uint32_t pair, double kappa,
+                                                double R, double &f, bool &negative, uint32_t sub0 = 0) {
+  return vm_attempt_pair_impl<PhiloxVKeys>(k, vk, site, pair, kappa, R, f, negative, sub0);
 }
 
 __device__ __forceinline__ double vm_angle(double f, bool negative) {
@@ -443,8 +501,8 @@ __device__ __forceinline__ double two_pi_i0_scaled(double z) {
 // straight-line code; about 97 % of the cells are done then.  What is left is a geometric tail: a few cells per wave
 // that need one more call, a few per workgroup that need two.  Retrying them where they sit makes every wave run the
 // whole attempt code with one or two live lanes, several times over.  Instead the leftovers of the whole workgroup are
-// pushed into a small LDS pool (HbPool: concentration, centre, Philox site, LDS offset), and after a barrier ONE wave
-// finishes them, one entry per lane, and writes the angles straight to their cells.  Entries that do not fit (the pool
+// pushed into a small LDS pool (HbPool: concentration, centre, Philox site, LDS offset), and after a barrier the first
+// threads of the workgroup finish them, one entry each, and write the angles straight to their cells.  Entries that do not fit (the pool
 // holds `cap` of them; expected ~40 per 1280 cells at beta = 1) are retried by their own lane on the spot.  Cells
 // accepted at once are written back at once (cells of one colour phase are not in each other's stencils), so nothing
 // but the loop state lives across cells.  Which random numbers a cell consumes is fixed by (site, attempt), so the
@@ -466,8 +524,11 @@ struct HbPool {
   }
 };
 
-template <int NT, int S, class Setup, class Commit>
+template <int NT, int S, bool LEAN = false, class Setup, class Commit>   // LEAN: round keys on the scalar side (16 VGPRs less)
 __device__ __forceinline__ void heatbath_cells(uint32_t total, const RngKey &key, HbPool &pool, Setup setup, Commit commit) {
+  PhiloxVKeys vk_;
+  if (!LEAN) vk_ = philox_vkeys(key.k0, key.k1);
+  const PhiloxVKeys *const vk = LEAN ? nullptr : &vk_;
   for (uint32_t b0 = 0; b0 < total; b0 += S * NT) {  // uniform trip count: the barriers below need every thread
     uint32_t *cnt = pool.count() + (pool.use & 1u);
     // The other counter (the one of the previous and of the next use) is cleared HERE: after wave 0's read of it in the
@@ -483,7 +544,7 @@ __device__ __forceinline__ void heatbath_cells(uint32_t total, const RngKey &key
         bool neg = false;
         setup(idx, tau, cen, site, off);
         const double kap = vm_clamp(tau), env = vm_envelope(kap);
-        bool done = vm_attempt_pair(key, site, 0, kap, env, f, neg);
+        bool done = vm_attempt_pair(key, vk, site, 0, kap, env, f, neg);
         if (!done && pool.cap) {
           const uint32_t slot = atomicAdd(cnt, 1u);
           if (slot < pool.cap) {
@@ -492,20 +553,20 @@ __device__ __forceinline__ void heatbath_cells(uint32_t total, const RngKey &key
           }
         }
         // no pool, or pool full: retry here
-        for (uint32_t pair = 1; !done; ++pair) done = vm_attempt_pair(key, site, pair, kap, env, f, neg);
+        for (uint32_t pair = 1; !done; ++pair) done = vm_attempt_pair(key, vk, site, pair, kap, env, f, neg);
         commit(off, mod_2pi_fast(vm_angle(f, neg) + cen));
       }
     }
     if (pool.cap) {
       __syncthreads();
-      if (threadIdx.x < kWave) {  // wave 0 finishes the pooled cells, one per lane
+      {  // the first threads finish the pooled cells, one each (r03: wave 0 alone, 64 at a time)
         const uint32_t filled = min(*cnt, pool.cap);
-        for (uint32_t e = threadIdx.x; e < filled; e += kWave) {
+        for (uint32_t e = threadIdx.x; e < filled; e += NT) {
           const double k_ = pool.kap()[e], c_ = pool.cen()[e], r_ = vm_envelope(k_);
           const uint32_t s_ = pool.site()[e], o_ = pool.off()[e];
           double f = 1.0;
           bool ng = false;
-          for (uint32_t pair = 1; !vm_attempt_pair(key, s_, pair, k_, r_, f, ng); ++pair) {
+          for (uint32_t pair = 1; !vm_attempt_pair(key, vk, s_, pair, k_, r_, f, ng); ++pair) {
           }
           commit(o_, mod_2pi_fast(vm_angle(f, ng) + c_));
         }
@@ -582,9 +643,9 @@ struct VsTable {
   float s_acc, s_rej;
   __device__ static VsTable at(const void *image, const uint32_t *__restrict__ d_table) {
     VsTable t{(const uint8_t *)image, 0.f, 0.f};
-    if (d_table) {  // uniform address: scalar loads
-      t.s_acc = __uint_as_float(d_table[kVsConstOff / 4]);
-      t.s_rej = __uint_as_float(d_table[kVsConstOff / 4 + 1]);
+    if (d_table) {  // uniform address: scalar loads; then into vector registers, where a v_fma_f32 on them issues at full rate
+      t.s_acc = __uint_as_float(to_vgpr(d_table[kVsConstOff / 4]));
+      t.s_rej = __uint_as_float(to_vgpr(d_table[kVsConstOff / 4 + 1]));
     }
     return t;
   }
@@ -672,11 +733,13 @@ __device__ __attribute__((noinline)) uint32_t vs_exact_pair(uint32_t k0, uint32_
 // attempts 2 pair and 2 pair + 1 of `site`; kappa_exact() is evaluated only when a screening decision is open.
 // Returns true when one of them is accepted (or the attempt bound is hit); |x| and its sign come back either way.
 template <class KappaExact>
-__device__ __forceinline__ bool vs_attempt_pair(const RngKey &k, uint32_t site, uint32_t pair, float kp, uint32_t cls,
+__device__ __forceinline__ bool vs_attempt_pair(const RngKey &k, const PhiloxVKeys *vk, uint32_t site, uint32_t pair, float kp, uint32_t cls,
                                                 const VsTable &tab, KappaExact kappa_exact, double &theta, bool &negative,
                                                 uint32_t sub0 = 0) {
   const uint32_t w3 = (P_VONMISES << 24) | sub0 | pair;
-  const U4 q = philox4x32_10(site, k.chain, k.step, w3, k.k0, k.k1);
+  // vk == NULL (a compile-time fact at every call site): round keys on the scalar side -- 16 VGPRs less, for kernels that
+  // live on occupancy
+  const U4 q = vk ? philox4x32_10(site, k.chain, k.step, w3, k.k0, k.k1, *vk) : philox4x32_10(site, k.chain, k.step, w3, k.k0, k.k1);
   uint32_t ca, cb;
   const float pa = vs_accept_prob(q.y, kp, cls, tab, ca), pb = vs_accept_prob(q.w, kp, cls, tab, cb);
   const float la = (float)q.x, lb = (float)q.z;
@@ -699,155 +762,128 @@ __device__ __forceinline__ bool vs_attempt_pair(const RngKey &k, uint32_t site, 
   return acc_a || acc_b || pair + 1 >= kMaxVmPairs;
 }
 
-// Work distribution of a step-envelope colour phase.  After the first pair of attempts ~5 % of the cells are still open.
-// Until r03 every thread owned a fixed list of cells (t, t + NT, ...), the open ones went into an LDS pool, and the pool
-// was worked off in rounds behind barriers: one or two waves walking a dependent chain while the others waited -- measured
-// at 12-16 % of the whole sampling step for 4.4 % of the cells.  Now the cells of a phase are a QUEUE (one LDS counter):
-// a wave hands the next cells to exactly those of its lanes that have none (one returning atomic per wave and iteration),
-// and a lane whose pair of attempts failed simply keeps its cell for the next iteration, alongside the fresh cells of its
-// neighbours.  Retries cost their 5 % of lane-iterations and nothing else, and the waves of a workgroup finish within one
-// iteration of each other, whatever their share of retries.  Only the cells that are still open when the queue has run
-// dry (about three per wave) go through a list in LDS -- entry = LDS offset of the cell and the index of its next pair;
-// stencil, centre and kappa are recomputed from the tile image, which the phase does not change under the cell -- and
-// are finished in place behind ONE barrier, one entry per thread (wave 0 as a rule).  Which random numbers a cell
-// consumes is fixed by (site, attempt), and cells of one colour phase do not read each other, so the result does not
-// depend on which lane draws which cell, nor when.
+// Open cells of a step-envelope colour phase.  After the first pair of attempts ~5 % of the cells are still open.  Retrying
+// them where they sit makes every wave run the whole attempt code again and again with two or three live lanes.  Instead
+// they go on a list in LDS -- an entry is just the cell's LDS offset and the index of its next pair; stencil, centre and
+// kappa are recomputed from the tile image, which the phase does not change under the cell -- and behind ONE barrier the
+// first threads of the workgroup take one entry each and finish it where it is, however many pairs that takes.
+// (r03 worked the list off in rounds -- one pair per entry, what is still open onto a second list, a barrier, and so on
+// until a round fitted one wave: with ~110 entries per phase that was a barrier and a round more than this, and 7 % of
+// the fused launch.  Measured on one box, r04: 0.8175 ms with rounds down to 64 entries, 0.7863 down to 128, 0.7626 with
+// none, profiles/r04_ab_tail.txt.  Handing the cells of a phase out through a queue, so that retries ride along with
+// fresh cells and no list is needed until the queue runs dry, was built and measured too: 3 % slower than the rounds --
+// the returning atomic and the hand-out arithmetic per wave and iteration cost more than the rounds they replace.)
 template <class E>  // uint16_t: offset in 12 bits, next pair in 4 (compile-time 64 x 32 tiles); uint32_t: 16 + 16
 struct VsPool {
   static constexpr uint32_t kOffBits = sizeof(E) == 2 ? 12 : 16;
   static constexpr uint32_t kMaxPair = (1u << (8 * sizeof(E) - kOffBits)) - 1;
   E *buf;                // `cap` entries
-  uint32_t *ctr;         // [0], [1]: queue heads of even / odd uses; [2], [3]: list lengths of even / odd uses
-  uint32_t cap, use;     // capacity of the list (0: none, leftovers are finished where they are); uses so far (uniform)
+  uint32_t *count;       // [2]: list lengths of even / odd uses
+  uint32_t cap, use;     // capacity (0: no list, every cell is finished by its own lane); uses so far (uniform)
   VsTable tab;
   // LDS bytes: table | counters | list
   static __host__ __device__ constexpr size_t bytes(uint32_t cap) { return kVsTableBytes + 16 + ((size_t)cap * sizeof(E) + 7) / 8 * 8; }
-  // call from every thread; the counters are visible after the caller's next barrier.  d_table == NULL: a kernel
-  // instance that never draws from the step envelope -- nothing in LDS is touched.
+  // call from every thread; visible after the caller's next barrier.  d_table == NULL: a kernel instance that never draws
+  // from the step envelope -- nothing in LDS is touched.
   __device__ static VsPool carve(double *lds, uint32_t cap, const uint32_t *d_table) {
     VsPool p;
     p.tab = VsTable::stage(lds, d_table);
-    p.ctr = (uint32_t *)((uint8_t *)lds + kVsTableBytes);
-    p.buf = (E *)(p.ctr + 4);
+    p.count = (uint32_t *)((uint8_t *)lds + kVsTableBytes);
+    p.buf = (E *)(p.count + 4);
     p.cap = cap;
     p.use = 0;
-    if (d_table && threadIdx.x < 4) p.ctr[threadIdx.x] = 0;
+    if (d_table && threadIdx.x < 2) p.count[threadIdx.x] = 0;
     return p;
   }
 };
 
 // One colour phase.  off_of(idx) = LDS offset of cell idx of the phase; setup(off, cell) = centre, class, kappa', Philox
 // site from the tile image; kappa_exact(off) = the fp64 concentration (rare); commit(off, angle).  The caller puts a
-// barrier behind the call (every call site has one: the next phase reads what this one wrote).  One copy of the set-up
-// and of the attempt code serves fresh cells, retries and the leftover list (S is not used any more).
-template <int NT, int S, class E, class OffOf, class Setup, class KappaExact, class Commit>
+// barrier behind the call (every call site has one: the next phase reads what this one wrote).
+// Pass 0 walks the cells of the phase (thread t: cells t, t + NT, ...), pass 1 the list (the rare exact test is a function
+// call, vs_exact_pair, so that the two copies of the attempt code stay small).  S is not used any more.
+// LEAN (the 1-D rotor sweeps, whose 256-thread workgroups live on occupancy): one copy of the cell code with a run-time flag and
+// the round keys on the scalar side -- 59 instead of 97 VGPRs, 7 instead of 4 waves per SIMD (the fast form cost the rotor
+// sweeps 10 %; it gains the fused Schwinger launch, which LDS holds at 4 waves per SIMD anyway, 3 %).
+template <int NT, int S, class E, bool LEAN = false, class OffOf, class Setup, class KappaExact, class Commit>
 __device__ __forceinline__ void heatbath_cells_step(uint32_t total, const RngKey &key, VsPool<E> &pool, OffOf off_of, Setup setup,
                                                     KappaExact kappa_exact, Commit commit) {
   using P = VsPool<E>;
   constexpr uint32_t kOffMask = (1u << P::kOffBits) - 1;
-  const uint32_t u = pool.use & 1u;
-  uint32_t *const queue = pool.ctr + u, *const left = pool.ctr + 2 + u;
-  // the counters of the NEXT use: last touched in the previous use, which ended before the caller's barrier behind it
-  if (threadIdx.x == 0) pool.ctr[u ^ 1u] = pool.ctr[2 + (u ^ 1u)] = 0;
-  const uint32_t lane = threadIdx.x & (kWave - 1);
-  bool have = false, dry = false, tail = false;
-  uint32_t off = 0, pair = 0, tail_next = threadIdx.x, n_left = 0;
-  VsCell c;
-#ifdef MLMCPI_QUEUE_PREFETCH
-  // The wave reserves cells 64 at a time, one reservation ahead of its needs: the returning atomic of a reservation is
-  // issued an iteration before its result is used, so its LDS round trip runs under the attempt code instead of in
-  // front of the stencil reads.  [cb, cb + cn): the reservation being handed out; nb: the next one (64 cells).
-  uint32_t cb = 0, cn = 0, nb = 0;
-  {
-    uint32_t b0 = 0;
-    if (lane == 0) b0 = atomicAdd(queue, 2u * kWave);
-    cb = (uint32_t)__builtin_amdgcn_readfirstlane((int)b0);
-    cn = kWave;
-    nb = cb + kWave;
-  }
-  uint32_t pending = 0;       // lane 0: result of the reservation issued in the previous iteration
-  bool have_pending = false;  // (uniform)
-#endif
-  for (;;) {
-    bool fetched = false;
-    uint32_t f_off = 0, f_pair = 0;
-    if (!tail) {
-      if (!dry) {
-        const uint64_t need = __ballot(!have);
-        if (need) {  // wave-uniform
-          const uint32_t n = (uint32_t)__popcll(need);
-          const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
-#ifdef MLMCPI_QUEUE_PREFETCH
-          if (n >= cn && have_pending) {  // cells of the next reservation are needed now: its atomic was issued an iteration ago
-            nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)pending);
-            have_pending = false;
-          }
-          const uint32_t idx = rank < cn ? cb + rank : nb + (rank - cn);
-          if (n >= cn) {  // the current reservation is used up: the next one takes its place, and a new one is asked for
-            const uint32_t used = n - cn;
-            cb = nb + used;
-            cn = kWave - used;
-            nb = total;   // (placeholder until the reservation asked for below is read, at the top of a later iteration)
-            if (cb < total) {
-              if (lane == 0) pending = atomicAdd(queue, (uint32_t)kWave);
-              have_pending = true;
-            }
-          } else {
-            cb += n;
-            cn -= n;
-          }
-          dry = cb >= total;   // reservations only grow: nothing below `total` can come any more
-#else
-          uint32_t base = 0;
-          if (lane == 0) base = atomicAdd(queue, n);
-          base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-          dry = base + n >= total;
-          const uint32_t idx = base + rank;
-#endif
-          if (!have && idx < total) {
-            f_off = off_of(idx);
-            fetched = true;
-          }
-        }
-      }
-    } else if (!have && tail_next < n_left) {
-      const uint32_t e = pool.buf[tail_next];
-      tail_next += NT;
-      f_off = e & kOffMask;
-      f_pair = e >> P::kOffBits;
-      fetched = true;
-    }
-    if (fetched) {
-      off = f_off;
-      pair = f_pair;
-      setup(off, c);
-      have = true;
-    }
-    if (!__any(have)) {  // wave-uniform
-      if (tail) break;
-      __syncthreads();   // every wave gets here exactly once per call: the list of this phase is complete
-      tail = true;
-      n_left = min(*left, pool.cap);
-      continue;
-    }
-    if (have) {
-      double th = 0.0;
-      bool neg = false;
-      if (vs_attempt_pair(key, c.site, pair, c.kp, c.cls, pool.tab, [&] { return kappa_exact(off); }, th, neg)) {
+  uint32_t *const cnt = pool.count + (pool.use & 1u);
+  // the counter of the NEXT use: last read in the previous use, which ended before the caller's barrier behind it
+  if (pool.cap && threadIdx.x == 0) pool.count[(pool.use & 1u) ^ 1u] = 0;
+  PhiloxVKeys vk_;
+  if (!LEAN) vk_ = philox_vkeys(key.k0, key.k1);
+  const PhiloxVKeys *const vk = LEAN ? nullptr : &vk_;
+  // One cell: pairs of attempts until one is accepted -- or, with on_list, one pair and then onto the list.  Two copies of
+  // this (pass 0 and pass 1) on purpose: with one copy and run-time flags the hot loop of pass 0 carries the list's
+  // branches and loads (measured: +2.4 % on the fused launch).
+  auto cell = [&](uint32_t off, uint32_t pair, auto on_list) {
+    VsCell c;
+    setup(off, c);
+    double th = 0.0;
+    bool neg = false;
+    for (;;) {
+      if (vs_attempt_pair(key, vk, c.site, pair, c.kp, c.cls, pool.tab, [&] { return kappa_exact(off); }, th, neg)) {
         commit(off, mod_2pi_fast(c.centre + (neg ? -th : th)));
-        have = false;
-      } else {
-        ++pair;
-        // no fresh cells left to share the next iteration with: hand the cell over (a full list, or a pair index the
-        // entry cannot hold, keeps it here, where the loop goes on until it is done)
-        if (dry && !tail && pair <= P::kMaxPair) {
-          const uint32_t slot = atomicAdd(left, 1u);
-          if (slot < pool.cap) {
-            pool.buf[slot] = (E)(off | (pair << P::kOffBits));
-            have = false;
-          }
+        return;
+      }
+      ++pair;
+      if ((bool)on_list && pair == 1 && pool.cap) {   // (kMaxPair >= 1: the entry can hold it)
+        const uint32_t slot = atomicAdd(cnt, 1u);
+        if (slot < pool.cap) {
+          pool.buf[slot] = (E)(off | (pair << P::kOffBits));
+          return;
         }
       }
+    }
+  };
+  // Pass 0 takes whole rounds of NT cells only: the cells left over (130 of the 2178 of a phase of the fused kernel, NT =
+  // 512) would cost the first waves a fifth iteration with the others waiting at the barrier; they join the list instead,
+  // where threads are idle anyway.
+  const uint32_t n_main = pool.cap ? total / NT * NT : total;
+  if (LEAN) {   // one loop over both passes, one copy of the cell code
+    uint32_t n = n_main, n_list = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+      for (uint32_t i = threadIdx.x; i < n; i += NT) {
+        uint32_t off, pair = 0;
+        if (pass == 0) {
+          off = off_of(i);
+        } else if (i < n_list) {
+          const uint32_t e = pool.buf[i];
+          off = e & kOffMask;
+          pair = e >> P::kOffBits;
+        } else {
+          off = off_of(n_main + (i - n_list));
+        }
+        cell(off, pair, pass == 0);
+      }
+      if (!pool.cap) break;
+      if (pass == 0) {
+        __syncthreads();
+        n_list = min(*cnt, pool.cap);
+        n = n_list + (total - n_main);
+      }
+    }
+    ++pool.use;
+    return;
+  }
+  for (uint32_t i = threadIdx.x; i < n_main; i += NT) cell(off_of(i), 0u, std::true_type{});
+  if (pool.cap) {
+    __syncthreads();
+    const uint32_t n_list = min(*cnt, pool.cap);   // (the same value in every thread: nothing is pushed behind the barrier)
+    const uint32_t n = n_list + (total - n_main);
+    for (uint32_t i = threadIdx.x; i < n; i += NT) {
+      uint32_t off, pair = 0;
+      if (i < n_list) {
+        const uint32_t e = pool.buf[i];
+        off = e & kOffMask;
+        pair = e >> P::kOffBits;
+      } else {
+        off = off_of(n_main + (i - n_list));
+      }
+      cell(off, pair, std::false_type{});
     }
   }
   ++pool.use;
@@ -860,7 +896,7 @@ __device__ __forceinline__ double vs_draw(const RngKey &k, uint32_t site, double
   vs_cell(scale, x_p, x_m, c);
   double th = 0.0;
   bool neg = false;
-  for (uint32_t pair = 0; !vs_attempt_pair(k, site, pair, c.kp, c.cls, tab, [&] { return vs_kappa_exact(scale, x_p, x_m); }, th, neg); ++pair) {
+  for (uint32_t pair = 0; !vs_attempt_pair(k, (const PhiloxVKeys *)nullptr, site, pair, c.kp, c.cls, tab, [&] { return vs_kappa_exact(scale, x_p, x_m); }, th, neg); ++pair) {
   }
   return mod_2pi_fast(c.centre + (neg ? -th : th));
 }

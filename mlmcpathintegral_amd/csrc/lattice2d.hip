@@ -581,6 +581,20 @@ __global__ void __launch_bounds__(1024)
   }
 }
 
+// Experiment (-DMLMCPI_SKEW=n): the two workgroups a CU holds start together and stay in step -- both in their load / store
+// phases (HBM bound, issue slots idle), then both in their sweeps (issue bound, HBM idle).  Delaying the second workgroup
+// of every CU by n x 3.6 us at the start of the launch puts them half a period apart.
+#ifdef MLMCPI_SKEW
+#define MLMCPI_SKEW_START()                                                                      \
+  do {                                                                                           \
+    const uint32_t lin_ = blockIdx.y * gridDim.x + blockIdx.x;                                   \
+    if (lin_ >= kComputeUnits && lin_ < 2 * kComputeUnits)                                       \
+      for (int i_ = 0; i_ < MLMCPI_SKEW; ++i_) __builtin_amdgcn_s_sleep(127);                    \
+  } while (0)
+#else
+#define MLMCPI_SKEW_START() do { } while (0)
+#endif
+
 // ---- Schwinger overrelaxation, 4 x 4 register blocks on 64 x 64 tiles ------------------------------------------
 // The 2 x 2 kernel above recomputes (64 + 4K)(32 + 4K) / (64 * 32) = 1.875 x the owned updates at K = 4 and moves 24 B
 // through LDS per update.  Here a thread keeps a 4 x 4 block of vertices (32 link angles, 64 VGPRs) for all K sweeps and
@@ -771,6 +785,7 @@ __global__ void __launch_bounds__(OrBlockGeom<K>::NT)
   const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
   const uint32_t i0 = tx * TW, j0 = ty * TH;
   double t0[PH][PW], t1[PH][PW];
+  MLMCPI_SKEW_START();
   or_block_sweeps<G, K>(lds, in + (size_t)b * Mt * Mx, Mt, Mx, i0, j0, t0, t1);
 
   // Owned vertices: buffer columns [H, H + TW), rows [H, H + TH).  A thread holds PW consecutive vertices of a row
@@ -822,18 +837,22 @@ struct OrHeatGeom {
   using G = OrBlockGeom<K + 1>;
   static constexpr int NT = G::NT, HB = 2, IW = G::TW + 2 * HB, IH = G::TH + 2 * HB;
   static constexpr size_t image_bytes = (size_t)2 * IW * IH * sizeof(double);
-  // the retry pool behind the image: a colour phase leaves 4.4 % of its ~2200 cells for it at beta = 1 (about 100 entries; a
-  // pool that overflows sends cells back to their lanes, which was measured at +20 % on the launch with 64 entries);
-  // 296 entries is what the plane area of the deepest geometry leaves
-  static constexpr uint32_t pool_cap = 296;
-  static constexpr size_t hb_bytes = image_bytes + VsPool<uint32_t>::bytes(pool_cap);
+  // in front of the image: the sampler's tables and the list of open cells -- a colour phase leaves about 5 % of its ~2200
+  // cells on it at beta = 1 (110 entries on average; a list that overflows leaves cells to their own lanes, measured at
+  // +20 % on the launch with 64 entries)
+  static constexpr uint32_t pool_cap = 256, hb_pool_cap = 128;   // step-envelope list; wrapped-Cauchy pool (24 B per entry)
+  static constexpr size_t pool_bytes_of(size_t a, size_t b) { return ((a > b ? a : b) + 15) / 16 * 16; }
+  static constexpr size_t pool_bytes = pool_bytes_of(VsPool<uint32_t>::bytes(pool_cap), HbPool::bytes(hb_pool_cap));
+  static constexpr size_t hb_bytes = image_bytes + pool_bytes;
   static_assert(hb_bytes <= OrBlockGeom<6>::lds_bytes, "two workgroups per CU");
   static constexpr size_t lds_bytes = G::lds_bytes > hb_bytes ? G::lds_bytes : hb_bytes;
 };
 
 // WIDE: 1024 threads per workgroup, for launches with at most one workgroup per CU (few chains): the register-block part
 // runs on the first OrHeatGeom<K>::NT threads as before, the heat-bath part on all sixteen waves.
-template <int K, bool WIDE = false>
+// STEP = false (r04): the heat-bath part draws from the wrapped-Cauchy envelope (heatbath_region, as
+// schwinger_sweep_kernel<true, ., 64, 32, false> does): actions beyond 2 beta = 4 get the fused launch too.
+template <int K, bool WIDE = false, bool STEP = true>
 __global__ void __launch_bounds__(WIDE ? 1024 : OrHeatGeom<K>::NT, 4)
     schwinger_or_heat_kernel(uint32_t Mt, uint32_t Mx, double beta, const double2 *__restrict__ in, double2 *__restrict__ out,
                              uint32_t tiles_x, RngKey key0, int qoi_op, double *__restrict__ qoi_partial,
@@ -850,12 +869,16 @@ __global__ void __launch_bounds__(WIDE ? 1024 : OrHeatGeom<K>::NT, 4)
   double t0[PH][PW], t1[PH][PW];
   MLMCPI_STAMP(0);
   MLMCPI_STAMP_WHERE();
+  MLMCPI_SKEW_START();
   or_block_sweeps<G, K>(lds, in + (size_t)b * Mt * Mx, Mt, Mx, i0, j0, t0, t1);
   MLMCPI_STAMP(3);  // K sweeps done
 
-  // the image: theta_0 and theta_1 planes of IH x IW vertices; every block that reaches into it puts its part down
-  double *th0 = lds, *th1 = lds + IW * IH;
-  VsPool<uint32_t> vpool = VsPool<uint32_t>::carve(lds + 2 * IW * IH, OH::pool_cap, vs_table);
+  // The sampler's tables, round counters and retry pool at the START of the LDS (their addresses are then instruction
+  // offsets: a table look-up costs no address arithmetic beyond its index), the image behind them: theta_0 and theta_1
+  // planes of IH x IW vertices; every block that reaches into it puts its part down
+  VsPool<uint32_t> vpool = VsPool<uint32_t>::carve(lds, OH::pool_cap, STEP ? vs_table : nullptr);
+  HbPool hpool = HbPool::carve(lds, STEP ? 0u : OH::hb_pool_cap);
+  double *th0 = lds + OH::pool_bytes / sizeof(double), *th1 = th0 + IW * IH;
   if (tid < NP) {
     const int pj = (int)tid / NPX, pi = (int)tid - pj * NPX;
 #pragma unroll
@@ -889,6 +912,17 @@ __global__ void __launch_bounds__(WIDE ? 1024 : OrHeatGeom<K>::NT, 4)
   for (uint32_t par = 0; par < 2; ++par) {  // mu = 0: rows [HB, HB + TH] of one parity, columns [HB - 1, HB + TW]
     const uint32_t r_first = HB + par, nr = (HB + TH - r_first) / 2 + 1;
     constexpr uint32_t ncol = TW + 2;
+    if (!STEP)
+      heatbath_region<NT, 5, true>(
+          nr, ncol, skey, hpool,
+          [&](uint32_t ri, uint32_t ci, double &tau, double &centre, uint32_t &site, uint32_t &o) {
+            const uint32_t r = r_first + 2 * ri, c = HB - 1 + ci;
+            o = r * bw + c;
+            expcos_params(beta, th0[o + bw] + th1[o] - th1[o + 1], th0[o - bw] + th1[o - bw + 1] - th1[o - bw], tau, centre);
+            site = 2 * (wrap(sr, r, Mx) * Mt + wrap(sc, c, Mt));
+          },
+          [&](uint32_t o, double v) { th0[o] = v; });
+    else
     heatbath_region_step<NT, 5, true, uint32_t>(
         nr, ncol, r_first * bw + (HB - 1), 2 * bw, 1, skey, vpool,
         [&](uint32_t o, VsCell &cell) {
@@ -906,6 +940,17 @@ __global__ void __launch_bounds__(WIDE ? 1024 : OrHeatGeom<K>::NT, 4)
   for (uint32_t par = 0; par < 2; ++par) {  // mu = 1: rows [HB, HB + TH), even columns up to HB + TW, odd ones up to HB + TW - 1
     const uint32_t c_first = HB + par, c_hi1 = par ? HB + TW - 1 : HB + TW;
     const uint32_t nc = (c_hi1 - c_first) / 2 + 1;
+    if (!STEP)
+      heatbath_region<NT, 5, true>(
+          TH, nc, skey, hpool,
+          [&](uint32_t ri, uint32_t ci, double &tau, double &centre, uint32_t &site, uint32_t &o) {
+            const uint32_t r = HB + ri, c = c_first + 2 * ci;
+            o = r * bw + c;
+            expcos_params(beta, th0[o] + th1[o + 1] - th0[o + bw], th0[o + bw - 1] + th1[o - 1] - th0[o - 1], tau, centre);
+            site = 2 * (wrap(sr, r, Mx) * Mt + wrap(sc, c, Mt)) + 1;
+          },
+          [&](uint32_t o, double v) { th1[o] = v; });
+    else
     heatbath_region_step<NT, 5, true, uint32_t>(
         TH, nc, HB * bw + c_first, bw, 2, skey, vpool,
         [&](uint32_t o, VsCell &cell) {
@@ -974,6 +1019,7 @@ __global__ void __launch_bounds__(NT)
   RngKey key = key0;
   key.chain += b;
   const double inv_kappa = 1. / (4. + mu2), two_over_kappa = 2. / (4. + mu2), sigma = 1. / sqrt(4. + mu2);
+  const PhiloxVKeys vk = philox_vkeys(key.k0, key.k1);
 
   stage_region<NT, (NT >= 1024 ? 3 : 5), double>(
       bh, bw, [&](uint32_t r, uint32_t c) { return src[(size_t)wrap(sr, r, Mx) * Mt + wrap(sc, c, Mt)]; },
@@ -1003,7 +1049,7 @@ __global__ void __launch_bounds__(NT)
       auto draw_pair = [&](uint32_t r, uint32_t c, bool park) {  // returns this cell's normal
         const uint32_t ell = wrap(sr, r, Mx) * Mt + wrap(sc, c, Mt);
         double n0, n1;
-        rng_normals(skey, ell >> 1, P_GFF_NORMAL, 0, n0, n1);
+        rng_normals(skey, vk, ell >> 1, P_GFF_NORMAL, 0, n0, n1);
         if (park) nrm[r * bw + (c ^ 1u)] = (ell & 1u) ? n0 : n1;
         return (ell & 1u) ? n1 : n0;
       };
@@ -1426,6 +1472,7 @@ __global__ void __launch_bounds__(GffHeatGeom<K>::NT, 4)
   // colour 0: the tile plus one ring, (TH + 2) x (TW + 2) / 2 cells; cell idx = tid + k NT of the thread, k < CELLS
   constexpr uint32_t nrow = TH + 2, nhalf = (TW + 2) / 2, total = nrow * nhalf, CELLS = (total + NT - 1) / NT;
   double partner[CELLS];  // the normal of (r, c ^ 1), the colour-1 cell of the same Box-Muller pair
+  const PhiloxVKeys vk = philox_vkeys(skey.k0, skey.k1);
 #pragma unroll
   for (uint32_t k = 0; k < CELLS; ++k) {
     const uint32_t idx = tid + k * NT;
@@ -1436,7 +1483,7 @@ __global__ void __launch_bounds__(GffHeatGeom<K>::NT, 4)
     const uint32_t o = r * bw + c;
     const uint32_t ell = wrap(sr, r, Mx) * Mt + wrap(sc, c, Mt);
     double n0, n1;
-    rng_normals(skey, ell >> 1, P_GFF_NORMAL, 0, n0, n1);
+    rng_normals(skey, vk, ell >> 1, P_GFF_NORMAL, 0, n0, n1);
     partner[k] = (ell & 1u) ? n0 : n1;
     phi[o] = fma(stencil(o), inv_kappa, sigma * ((ell & 1u) ? n1 : n0));
   }
@@ -1618,22 +1665,62 @@ __global__ void __launch_bounds__(256) gff_force_kernel(uint32_t Mt, uint32_t Mx
 // Gather form of quenchedschwingeraction.cc:68-89: the reference scatters +-beta sin(theta_P) of
 // plaquette (i,j) onto its four links; link (i,j,0) therefore receives F(i,j) - F(i,j-1) and link
 // (i,j,1) receives F(i-1,j) - F(i,j) (each a two-term sum, so the value is order independent).
+//
+// One sine per plaquette.  (Until r03 every thread computed the three plaquettes its two links touch -- three sines per
+// site, 0.37 ms for 1024^2 x 32 = 0.36 of the HBM roofline for a kernel that reads and writes the state once.)  A WAVE
+// walks up a band of rows with 64 consecutive columns: lane l holds column (62 tile + l - 1) mod Mt, takes theta_1 of the
+// column to its right from lane l + 1 and F of the column to its left from lane l - 1 (DPP rotations: no LDS, no barrier),
+// and keeps F of the row below in a register.  Lanes 1 .. 62 emit; lane 0 only supplies F, lane 63 only theta_1: tiles step
+// by 62 columns, 3 % redundant loads and sines, and nothing at the edge of a wave is special.  Rows are loaded two ahead
+// of their use.  Same arithmetic per plaquette as before (same sum order): bit-identical forces.
+#ifndef MLMCPI_FORCE_ROWS
+#define MLMCPI_FORCE_ROWS 32
+#endif
+constexpr uint32_t kForceCols = 62, kForceRows = MLMCPI_FORCE_ROWS;
+__host__ __device__ inline uint32_t force_waves(uint32_t Mt, uint32_t Mx) {
+  return ((Mt + kForceCols - 1) / kForceCols) * ((Mx + kForceRows - 1) / kForceRows);
+}
+// emit(j, i, F_0, F_1): force on the two links of vertex (i, j)
+template <class Emit>
+__device__ __forceinline__ void schwinger_force_band(const double2 *__restrict__ t, uint32_t Mt, uint32_t Mx, double coupling,
+                                                     uint32_t wave_id, Emit emit) {
+  const uint32_t tiles = (Mt + kForceCols - 1) / kForceCols;
+  const uint32_t band = wave_id / tiles, tile = wave_id - band * tiles, lane = threadIdx.x & (kWave - 1);
+  const uint32_t col = tile * kForceCols + lane;                       // column + 1, not wrapped
+  const uint32_t i = (uint32_t)(((uint64_t)col + Mt - 1) % Mt);
+  const bool owner = lane >= 1 && lane <= kForceCols && col <= Mt;     // col - 1 < Mt: not a column of the next lap
+  const uint32_t jb = band * kForceRows, je = min(jb + kForceRows, Mx);
+  auto up_of = [&](uint32_t j) { return j + 1 == Mx ? 0u : j + 1; };
+  auto F_of = [&](const double2 &a, const double2 &above) {
+    // theta(i,j,0) + theta(i+1,j,1) - theta(i,j+1,0) - theta(i,j,1)   (quenchedschwingeraction.cc:14-17)
+    return coupling * sin_reduced(a.x + wave_rotate_down(a.y) - above.x - a.y);
+  };
+  const uint32_t jm = jb == 0 ? Mx - 1 : jb - 1;
+  uint32_t j1 = up_of(jb), j2 = up_of(j1);
+  const double2 below = t[(size_t)jm * Mt + i];
+  double2 here = t[(size_t)jb * Mt + i], above = t[(size_t)j1 * Mt + i], next = t[(size_t)j2 * Mt + i];
+  double F_below = F_of(below, here);
+  for (uint32_t j = jb; j < je; ++j) {
+    const double F = F_of(here, above);
+    const double F_left = wave_rotate_up(F);
+    if (owner) emit(j, i, F - F_below, F_left - F);
+    F_below = F;
+    here = above;
+    above = next;
+    j2 = up_of(j2);
+    next = t[(size_t)j2 * Mt + i];   // (two rows past the band at its end: a valid row, not used)
+  }
+}
+
+// grid (ceil(force_waves / 4), B)
 __global__ void __launch_bounds__(256) schwinger_force_kernel(uint32_t Mt, uint32_t Mx, double beta,
                                                               const double2 *__restrict__ t_all,
                                                               double2 *__restrict__ f_all) {
-  const uint32_t b = blockIdx.y;
-  const double2 *t = t_all + (size_t)b * Mt * Mx;
+  const uint32_t b = blockIdx.y, wave_id = blockIdx.x * 4 + threadIdx.x / kWave;
+  if (wave_id >= force_waves(Mt, Mx)) return;   // (a whole wave)
   double2 *f = f_all + (size_t)b * Mt * Mx;
-  for (uint32_t j = blockIdx.x; j < Mx; j += gridDim.x) {
-    const uint32_t jm = j == 0 ? Mx - 1 : j - 1;
-    for (uint32_t i = threadIdx.x; i < Mt; i += blockDim.x) {
-      const uint32_t im = i == 0 ? Mt - 1 : i - 1;
-      const double F = beta * sin_reduced(plaquette_angle(t, Mt, Mx, i, j));
-      const double Fd = beta * sin_reduced(plaquette_angle(t, Mt, Mx, i, jm));
-      const double Fl = beta * sin_reduced(plaquette_angle(t, Mt, Mx, im, j));
-      f[(size_t)j * Mt + i] = make_double2(F - Fd, Fl - F);
-    }
-  }
+  schwinger_force_band(t_all + (size_t)b * Mt * Mx, Mt, Mx, beta, wave_id,
+                       [&](uint32_t j, uint32_t i, double f0, double f1) { f[(size_t)j * Mt + i] = make_double2(f0, f1); });
 }
 
 __global__ void __launch_bounds__(256) lattice_init_kernel(int kind, uint32_t n, RngKey key0, double *__restrict__ x) {
@@ -1848,7 +1935,7 @@ static int launch_sweep_nt(const SweepGeom &g, dim3 grid, hipStream_t st, uint32
       if (int rc = vs_table_device(2. * coupling, &vs_table)) return rc;
     if (HEAT) {
       const size_t quarter = 40 * 1024 - 64;  // (the kernel's static LDS: the QoI reduction scratch)
-      const size_t entry = step ? 2 * (fixed ? sizeof(uint16_t) : sizeof(uint32_t)) : 24, fixed_part = step ? kVsTableBytes + 16 : 8;
+      const size_t entry = step ? (fixed ? sizeof(uint16_t) : sizeof(uint32_t)) : 24, fixed_part = step ? kVsTableBytes + 16 : 8;
       cap = 64;
       if (lds + fixed_part + entry * cap <= quarter) cap = (uint32_t)((quarter - lds - fixed_part) / entry) & ~7u;
       if (cap > (step ? 256u : 1024u)) cap = step ? 256u : 1024u;
@@ -1931,6 +2018,7 @@ static int init_sweep_kernels() {
 #define MLMCPI_OR_HEAT_ATTR(KK) \
   MLMCPI_HIP_TRY(hipFuncSetAttribute((const void *)schwinger_or_heat_kernel<KK, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)OrHeatGeom<KK>::lds_bytes)); \
   MLMCPI_HIP_TRY(hipFuncSetAttribute((const void *)schwinger_or_heat_kernel<KK, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)OrHeatGeom<KK>::lds_bytes)); \
+  MLMCPI_HIP_TRY(hipFuncSetAttribute((const void *)schwinger_or_heat_kernel<KK, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)OrHeatGeom<KK>::lds_bytes)); \
   MLMCPI_HIP_TRY(hipFuncSetAttribute((const void *)gff_or_heat_kernel<KK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GffHeatGeom<KK>::lds_bytes))
   MLMCPI_OR_HEAT_ATTR(1); MLMCPI_OR_HEAT_ATTR(2); MLMCPI_OR_HEAT_ATTR(3); MLMCPI_OR_HEAT_ATTR(4); MLMCPI_OR_HEAT_ATTR(5);
 #undef MLMCPI_OR_HEAT_ATTR
@@ -1971,8 +2059,8 @@ int mlmcpi_lattice_force(const mlmcpi_lattice_action *act, const double *d_phi, 
   if (act->kind == MLMCPI_GFF)
     hipLaunchKernelGGL(gff_force_kernel, grid, block, 0, as_stream(stream), act->Mt, act->Mx, gff_mu2(*act), d_phi, d_f);
   else
-    hipLaunchKernelGGL(schwinger_force_kernel, grid, block, 0, as_stream(stream), act->Mt, act->Mx, act->beta,
-                       (const double2 *)d_phi, (double2 *)d_f);
+    hipLaunchKernelGGL(schwinger_force_kernel, dim3((force_waves(act->Mt, act->Mx) + 3) / 4, B), block, 0, as_stream(stream),
+                       act->Mt, act->Mx, act->beta, (const double2 *)d_phi, (double2 *)d_f);
   MLMCPI_LAUNCH_CHECK("lattice force kernel");
   return MLMCPI_OK;
 }
@@ -2078,10 +2166,11 @@ static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, doub
         dim3 bgrid((act->Mt / 64) * (act->Mx / 64), B);
         // the last overrelaxation launch of the draw takes the heat-bath sweep behind it along (and the QoI, if that is
         // the draw's last sweep): schwinger_or_heat_kernel, bit-identical to the two launches (MLMCPI_OR_HEAT=split)
-        if (!tune.or_heat_split && s + n == n_overrelax && n_heatbath >= 1 && (n <= 5 || whole_draw) && 2. * act->beta <= kVsKappaMax &&
-            act->Mt >= 128 && act->Mx >= 128) {
+        if (!tune.or_heat_split && s + n == n_overrelax && n_heatbath >= 1 && (n <= 5 || whole_draw) && act->Mt >= 128 && act->Mx >= 128) {
+          const bool step = 2. * act->beta <= kVsKappaMax;   // which sampler: a property of the action (device_common.hpp)
           const uint32_t *vs_table = nullptr;
-          if (int rcv = vs_table_device(2. * act->beta, &vs_table)) return rcv;
+          if (step)
+            if (int rcv = vs_table_device(2. * act->beta, &vs_table)) return rcv;
           const bool with_qoi = qoi_kind && s + n + 1 == total;
           void *partial = nullptr;
           if (with_qoi)
@@ -2091,7 +2180,8 @@ static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, doub
           // at most one workgroup per CU: sixteen waves for the heat-bath part (bit-identical; MLMCPI_OR_HEAT=wide|narrow forces)
           const bool wide = tune.or_heat_wide ? tune.or_heat_wide > 0 : (uint64_t)bgrid.x * B <= kComputeUnits;
 #define MLMCPI_OR_HEAT_W(KK, WW) hipLaunchKernelGGL((schwinger_or_heat_kernel<KK, WW>), bgrid, dim3(WW ? 1024 : OrHeatGeom<KK>::NT), OrHeatGeom<KK>::lds_bytes, st, act->Mt, act->Mx, act->beta, in2, out2, act->Mt / 64, hkey, op, (double *)partial, vs_table)
-#define MLMCPI_OR_HEAT(KK) do { if (wide) MLMCPI_OR_HEAT_W(KK, true); else MLMCPI_OR_HEAT_W(KK, false); } while (0)
+#define MLMCPI_OR_HEAT_CAUCHY(KK) hipLaunchKernelGGL((schwinger_or_heat_kernel<KK, false, false>), bgrid, dim3(OrHeatGeom<KK>::NT), OrHeatGeom<KK>::lds_bytes, st, act->Mt, act->Mx, act->beta, in2, out2, act->Mt / 64, hkey, op, (double *)partial, vs_table)
+#define MLMCPI_OR_HEAT(KK) do { if (!step) MLMCPI_OR_HEAT_CAUCHY(KK); else if (wide) MLMCPI_OR_HEAT_W(KK, true); else MLMCPI_OR_HEAT_W(KK, false); } while (0)
           switch (n) {
             case 1: MLMCPI_OR_HEAT(1); break;
             case 2: MLMCPI_OR_HEAT(2); break;
@@ -2105,6 +2195,7 @@ static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, doub
             default: MLMCPI_OR_HEAT_W(10, true);
           }
 #undef MLMCPI_OR_HEAT
+#undef MLMCPI_OR_HEAT_CAUCHY
 #undef MLMCPI_OR_HEAT_W
           MLMCPI_LAUNCH_CHECK("schwinger_or_heat_kernel");
           if (with_qoi) {
@@ -2417,24 +2508,20 @@ __global__ void __launch_bounds__(256)
       }
     }
   } else {
+    // grid (ceil(force_waves / 4), B): one sine per plaquette (schwinger_force_band)
+    const uint32_t wave_id = blockIdx.x * 4 + threadIdx.x / kWave;
+    if (wave_id >= force_waves(Mt, Mx)) return;
     const double2 *t = (const double2 *)x_in + (size_t)b * Mt * Mx;
     double2 *out = (double2 *)x_out + (size_t)b * Mt * Mx, *p = (double2 *)p_all + (size_t)b * Mt * Mx;
-    for (uint32_t j = blockIdx.x; j < Mx; j += gridDim.x) {
-      const uint32_t jm = j == 0 ? Mx - 1 : j - 1;
-      for (uint32_t i = threadIdx.x; i < Mt; i += blockDim.x) {
-        const uint32_t im = i == 0 ? Mt - 1 : i - 1;
-        const size_t o = (size_t)j * Mt + i;
-        const double F = coupling * sin_reduced(plaquette_angle(t, Mt, Mx, i, j));
-        const double Fd = coupling * sin_reduced(plaquette_angle(t, Mt, Mx, i, jm));
-        const double Fl = coupling * sin_reduced(plaquette_angle(t, Mt, Mx, im, j));
-        double2 pn = p[o];
-        pn.x -= dtp * (F - Fd);
-        pn.y -= dtp * (Fl - F);
-        p[o] = pn;
-        const double2 xo = t[o];
-        out[o] = make_double2(xo.x + dtx * pn.x, xo.y + dtx * pn.y);
-      }
-    }
+    schwinger_force_band(t, Mt, Mx, coupling, wave_id, [&](uint32_t j, uint32_t i, double f0, double f1) {
+      const size_t o = (size_t)j * Mt + i;
+      double2 pn = p[o];
+      pn.x -= dtp * f0;
+      pn.y -= dtp * f1;
+      p[o] = pn;
+      const double2 xo = t[o];
+      out[o] = make_double2(xo.x + dtx * pn.x, xo.y + dtx * pn.y);
+    });
   }
 }
 
@@ -2536,7 +2623,7 @@ int mlmcpi_lattice_hmc_draw(const mlmcpi_lattice_action *act, double *d_phi, uin
         hipLaunchKernelGGL(lat_hmc_step_kernel<MLMCPI_GFF>, row_grid, block, 0, st, act->Mt, act->Mx, coupling,
                            (const double *)src, dst, p, done_in, dtp, dtx);
       else
-        hipLaunchKernelGGL(lat_hmc_step_kernel<MLMCPI_SCHWINGER>, row_grid, block, 0, st, act->Mt, act->Mx, coupling,
+        hipLaunchKernelGGL(lat_hmc_step_kernel<MLMCPI_SCHWINGER>, dim3((force_waves(act->Mt, act->Mx) + 3) / 4, B), block, 0, st, act->Mt, act->Mx, coupling,
                            (const double *)src, dst, p, done_in, dtp, dtx);
       MLMCPI_LAUNCH_CHECK("lat_hmc_step_kernel");
       double *tmp = src; src = dst; dst = tmp;

@@ -540,7 +540,7 @@ __global__ void __launch_bounds__(256)
           while (g >= M) g -= M;
           return g;
         };
-        heatbath_cells_step<256, 4, uint32_t>(
+        heatbath_cells_step<256, 4, uint32_t, true>(
             count, skey, vpool, [&](uint32_t idx) { return k0 + 2 * idx; },
             [&](uint32_t k, VsCell &cell) {
               vs_cell(sig_scale, buf[k + 1], buf[k - 1], cell);
@@ -549,7 +549,7 @@ __global__ void __launch_bounds__(256)
             [&](uint32_t k) { return vs_kappa_exact(sig_scale, buf[k + 1], buf[k - 1]); },
             [&](uint32_t k, double angle) { buf[k] = angle; });
       } else if (HEAT) {
-        heatbath_cells<256, 4>(
+        heatbath_cells<256, 4, true>(
             count, skey, pool,
             [&](uint32_t idx, double &tau, double &centre, uint32_t &site, uint32_t &off) {
               const uint32_t k = k0 + 2 * idx;

@@ -87,6 +87,10 @@ def test_config5_as_the_reference_runs_it_agrees_with_single_level_hmc():
     """quartic_mlmc_hier (sampler = 'hierarchical') and quartic_mlmc (direct samplers): both telescoping
     sums within 2 sigma of the single-level HMC estimate on the finest lattice taken in the hierarchical run."""
     h = json.load(open(os.path.join(ROOT, "profiles", f"{_tag()}_bench_quartic_mlmc_hier.json")))
+    # a level whose two-level steps never accept must be named in the line (ADVICE r03), from r04 on
+    hacc = h["mlmc"]["hierarchical_acceptance_rank0"]
+    if _tag() >= "r04":
+        assert h["mlmc"]["frozen_levels"] == sorted({int(k) for acc in hacc.values() for k, v in acc.items() if v == 0.0})
     ref = h["mlmc"]["run_to_epsilon"]["single_level_fine_hmc"]
     assert abs(ref["z"]) < 2.0 and h["mlmc"]["run_to_epsilon"]["reached"]
     d = json.load(open(os.path.join(ROOT, "profiles", f"{_tag()}_bench_quartic_mlmc.json")))

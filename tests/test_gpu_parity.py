@@ -539,6 +539,7 @@ SWEEP_CASES = [
     ("schwinger", 130, 70, dict(beta=1.0), 1),
     ("schwinger", 64, 64, dict(beta=2.0), 2),    # one 64 x 64 tile of the 4 x 4 register-block kernel: the buffer wraps onto itself
     ("schwinger", 192, 128, dict(beta=1.0), 1),  # 3 x 2 tiles of it
+    ("schwinger", 128, 128, dict(beta=3.0), 1),  # 2 beta > 4: the fused launch with the wrapped-Cauchy sampler (r04)
     ("schwinger", 16, 16, dict(beta=0.0), 2),    # flat conditionals: kappa is clamped, the draw is uniform
     ("schwinger", 16, 16, dict(beta=40.0), 2),   # sharply peaked conditionals (kappa up to 80)
     ("gff", 16, 16, dict(mass=0.0), 2),          # massless field: kappa = 4
@@ -570,7 +571,9 @@ def test_lattice_sweeps_match_oracle(gpu_ops, orc, kind, Mt, Mx, kw, B, fuse):
             assert_close(got, xo, tol=1e-11, what=f"sweeps ({n_or},{n_hb}) fuse={fuse}")
 
 
-@pytest.mark.parametrize("Mt,Mx,B,beta", [(128, 128, 3, 1.0), (192, 128, 2, 2.0), (256, 128, 2, 0.3), (1024, 1024, 2, 1.0)])
+@pytest.mark.parametrize("Mt,Mx,B,beta", [(128, 128, 3, 1.0), (192, 128, 2, 2.0), (256, 128, 2, 0.3), (1024, 1024, 2, 1.0),
+                                          # r04: beyond 2 beta = 4 the fused launch draws from the wrapped-Cauchy envelope
+                                          (128, 192, 2, 3.0), (256, 256, 2, 40.0)])
 def test_overrelaxation_and_heat_bath_in_one_launch_equal_two_launches(gpu_ops, Mt, Mx, B, beta):
     """schwinger_or_heat_kernel<K> (the last K <= 5 overrelaxation sweeps of a draw, the heat-bath sweep behind them and
     the QoI in one launch) against the same draw with the heat bath in a launch of its own (MLMCPI_OR_HEAT=split): states

@@ -32,7 +32,7 @@ def issue_model(k):
 
 
 SIZES = {"schwinger": 1024, "gff": 512, "rotor_hmc": 65536, "quartic_hmc": 32768, "ho_hmc": 128, "quartic_mlmc": 32768, "quartic_mlmc_hier": 32768, "rotor_sweep": 65536}
-CHAINS = {"schwinger": 32, "gff": 1024, "rotor_hmc": 1024, "quartic_hmc": 2048, "ho_hmc": 8192, "quartic_mlmc": 512, "quartic_mlmc_hier": 512, "rotor_sweep": 1024}
+CHAINS = {"schwinger": 32, "gff": 1024, "rotor_hmc": 1024, "quartic_hmc": 2048, "ho_hmc": 8192, "quartic_mlmc": 512, "quartic_mlmc_hier": 2048, "rotor_sweep": 1024}
 out = {"_how": "tools/profile_all.sh: rocprofv3 --pmc <counters> --kernel-trace on `python3 bench.py --workload W --steps 5 --warmup 2 "
                "--no-cpu-baseline --no-extra-points`, one pass per counter group (SQ group; FETCH_SIZE; WRITE_SIZE), per-launch "
                "averages over every launch of the run.  FETCH_SIZE / WRITE_SIZE are KiB; FETCH_SIZE is doubled (gfx950 counts a "

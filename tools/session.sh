@@ -25,6 +25,9 @@ for S in $STEPS; do
       ( cd /tmp && export TMPDIR=/tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d ${GRAFT_REPO_ROOT:?}/gpurun_out/prof_$TAG -- python3 ${GRAFT_REPO_ROOT:?}/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra-points > ${GRAFT_REPO_ROOT:?}/gpurun_out/prof_$TAG.log 2>&1 ); rc=$?
       echo "rocprof exit $rc"; find gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1 | xargs -r head -6 | cut -c1-200
       if [ $rc -ne 0 ]; then exit $rc; fi ;;
+    hierscan) bash tools/scan_hier_chains.sh $TAG || exit 1 ;;
+    benchall) bash tools/bench_all.sh $TAG || exit 1 ;;
+    stall) bash tools/pmc_stall.sh $TAG || exit 1 ;;
     ab) bash tools/ab.sh $TAG ${AB_VARIANTS:-"" pf r03} || exit 1 ;;
     *) echo "unknown step $S"; exit 64 ;;
   esac

@@ -65,6 +65,19 @@
 #define B_CMPF32(i) asm volatile("v_cmp_lt_f32 vcc, %0, %1" :: "v"(a##i), "v"(c) : "vcc");
 #define B_CVTU32F64(i) { uint32_t t; asm volatile("v_cvt_u32_f64 %0, %1" : "=v"(t) : "v"(a##i)); asm volatile("" :: "v"(t)); }
 #define UDECLS UDECL uint32_t sk = __builtin_amdgcn_readfirstlane(blockIdx.x * 7u + 3u);
+#define B_MAD64S(i) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "+v"(a##i) : "s"(sk), "v"((uint32_t)i + 3u) : "vcc");
+#define LDECLS LDECL uint32_t sk = __builtin_amdgcn_readfirstlane(blockIdx.x * 7u + 3u);
+KERNEL(k_mad_u64_u32_sgpr, LDECLS, B_MAD64S, USINK)
+#define B_ADDINL(i) asm volatile("v_add_u32 %0, 64, %0" : "+v"(a##i));
+KERNEL(k_add_u32_inline, UDECL, B_ADDINL, USINK)
+#define B_ADDLIT(i) asm volatile("v_add_u32 %0, 0x9E3779B9, %0" : "+v"(a##i));
+KERNEL(k_add_u32_literal, UDECL, B_ADDLIT, USINK)
+#define B_FMA32S(i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a##i) : "s"(sf), "v"(c));
+#define FDECLS FDECL float sf = __builtin_amdgcn_readfirstlane((int)blockIdx.x) * 1e-9f + 1.0f;
+KERNEL(k_fma32_sgpr, FDECLS, B_FMA32S, DSINK)
+#define B_ADD64S(i) asm volatile("v_add_f64 %0, %0, %1" : "+v"(a##i) : "s"(sd));
+#define DDECLS DDECL double sd = (double)__builtin_amdgcn_readfirstlane((int)blockIdx.x) * 1e-9;
+KERNEL(k_add64_sgpr, DDECLS, B_ADD64S, DSINK)
 KERNEL(k_bitop3, UDECL, B_BITOP3, USINK)
 KERNEL(k_bitop3_sgpr, UDECLS, B_BITOP3S, USINK)
 KERNEL(k_xor_sgpr, UDECLS, B_XORS, USINK)
@@ -136,6 +149,6 @@ int main() {
   RUN(k_cvt_f64_u32); RUN(k_xor); RUN(k_add_u32); RUN(k_lshr); RUN(k_and_or); RUN(k_bfe); RUN(k_alignbit); RUN(k_mullo);
   RUN(k_mulhi); RUN(k_mad_u64_u32); RUN(k_cndmask_sgpr);
   RUN(k_bitop3); RUN(k_bitop3_sgpr); RUN(k_xor_sgpr); RUN(k_cvt_f32_u32); RUN(k_cvt_f32_ubyte0); RUN(k_exp32); RUN(k_lshl_add);
-  RUN(k_add3); RUN(k_min_u32); RUN(k_fmaak32); RUN(k_cmp32); RUN(k_cvt_u32_f64);
+  RUN(k_mad_u64_u32_sgpr); RUN(k_add_u32_inline); RUN(k_add_u32_literal); RUN(k_fma32_sgpr); RUN(k_add64_sgpr); RUN(k_add3); RUN(k_min_u32); RUN(k_fmaak32); RUN(k_cmp32); RUN(k_cvt_u32_f64);
   return 0;
 }
