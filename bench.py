@@ -64,6 +64,8 @@ def parse():
                     help="schwinger: time the HBM-bound kernels of the path after the timed steps even with --no-extra-points")
     ap.add_argument("--cpu-draws", type=int, default=0)
     ap.add_argument("--epsilon", type=float, default=2e-3, help="quartic_mlmc_hier: tolerance of the untimed run to convergence")
+    ap.add_argument("--hier-sub-factor", type=float, default=1.0,
+                    help="quartic_mlmc_hier: draws between coarse samples = this x the reference's ceil(2 tau_int) (experiment)")
     ap.add_argument("--t-final", type=float, default=0.0, help="quartic_mlmc_hier: T_final (default size / 8, i.e. a = 0.125 on the finest level)")
     return ap.parse_args()
 
@@ -545,7 +547,7 @@ def main():
         est = mlmc.PathMLMC(abi.QUARTIC, size, T_hier, n_level, B, nt=a.nt, dt0=0.02, seed=a.seed, rank=rank, world=world,
                             params=dict(lam=1.0, x0=1.0), hierarchical=True, dt_coarse=a.dt or 0.095)
         est.exchange = exchange
-        est.thermalise(400)   # untimed: every chain starts from an equilibrium sample of its level (direct HMC, once)
+        est.thermalise(400, a.hier_sub_factor)   # untimed: every chain starts from an equilibrium sample of its level (direct HMC, once)
         sub = {l: lv.n_sub for l, lv in est.levels.items()}
         # site-steps per step of THIS rank's instances (HMC force evaluations on the coarsest level + two-level passes)
         units_rank = sum((lv.n_sub * lv.sampler.cost + (0 if lv.coarsest else lv.step.fine.M)) * lv.B for lv in est.levels.values())

@@ -805,7 +805,7 @@ struct VsPool {
 // LEAN (the 1-D rotor sweeps, whose 256-thread workgroups live on occupancy): one copy of the cell code with a run-time flag and
 // the round keys on the scalar side -- 59 instead of 97 VGPRs, 7 instead of 4 waves per SIMD (the fast form cost the rotor
 // sweeps 10 %; it gains the fused Schwinger launch, which LDS holds at 4 waves per SIMD anyway, 3 %).
-template <int NT, int S, class E, bool LEAN = false, class OffOf, class Setup, class KappaExact, class Commit>
+template <int NT, int S, class E, int LEAN = 0, class OffOf, class Setup, class KappaExact, class Commit>   // LEAN: 1 = scalar round keys, 2 = + one copy of the cell code
 __device__ __forceinline__ void heatbath_cells_step(uint32_t total, const RngKey &key, VsPool<E> &pool, OffOf off_of, Setup setup,
                                                     KappaExact kappa_exact, Commit commit) {
   using P = VsPool<E>;
@@ -843,7 +843,7 @@ __device__ __forceinline__ void heatbath_cells_step(uint32_t total, const RngKey
   // 512) would cost the first waves a fifth iteration with the others waiting at the barrier; they join the list instead,
   // where threads are idle anyway.
   const uint32_t n_main = pool.cap ? total / NT * NT : total;
-  if (LEAN) {   // one loop over both passes, one copy of the cell code
+  if (LEAN >= 2) {   // one loop over both passes, one copy of the cell code
     uint32_t n = n_main, n_list = 0;
     for (int pass = 0; pass < 2; ++pass) {
       for (uint32_t i = threadIdx.x; i < n; i += NT) {

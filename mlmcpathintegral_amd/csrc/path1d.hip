@@ -492,8 +492,14 @@ __global__ void __launch_bounds__(256) path_transfer_kernel(uint32_t Mc, double 
 // rotoraction.cc:20-56, rotoraction.hh:195-213.
 // HEAT = false: overrelaxation-only instantiation (no sampler code, few registers).  STEP: heat-bath draws from the step
 // envelope (2 m0 / a <= kVsKappaMax, device_common.hpp) instead of the wrapped-Cauchy one; pool_cap then counts VsPool entries.
+#ifndef MLMCPI_ROTOR_LEAN
+#define MLMCPI_ROTOR_LEAN 2
+#endif
+#ifndef MLMCPI_ROTOR_WAVES
+#define MLMCPI_ROTOR_WAVES 1
+#endif
 template <bool HEAT, bool STEP = false>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, HEAT && STEP ? MLMCPI_ROTOR_WAVES : 1)
     rotor_sweep_kernel(PathP P, const double *__restrict__ in, double *__restrict__ out, uint32_t owned_len,
                        uint32_t nsweeps, uint32_t kinds, RngKey key0, uint32_t pool_cap, const uint32_t *__restrict__ vs_table,
                        double *__restrict__ winding_partial = nullptr) {
@@ -540,7 +546,7 @@ __global__ void __launch_bounds__(256)
           while (g >= M) g -= M;
           return g;
         };
-        heatbath_cells_step<256, 4, uint32_t, true>(
+        heatbath_cells_step<256, 4, uint32_t, MLMCPI_ROTOR_LEAN>(
             count, skey, vpool, [&](uint32_t idx) { return k0 + 2 * idx; },
             [&](uint32_t k, VsCell &cell) {
               vs_cell(sig_scale, buf[k + 1], buf[k - 1], cell);

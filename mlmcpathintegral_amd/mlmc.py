@@ -169,6 +169,8 @@ class HierPathLevel(PathLevel):
         self.tau_coarse = max(1.0, tau)
         # ceil(2 tau_int), montecarlomultilevel.cc:173 (a stationary series cannot exceed 1 + 2 (window - 1))
         self.n_sub = min(max(1, int(-(-2.0 * self.tau_coarse // 1))), 2 * (1 + 2 * self.window))
+        # experiment knob (bench.py --hier-sub-factor): more draws between coarse samples than the reference's ceil(2 tau_int)
+        self.n_sub = max(1, int(round(self.n_sub * getattr(self, "sub_factor", 1.0))))
         if self.step is not None:
             # the level's own state: an equilibrium sample of its action by a direct HMC run (untimed, once)
             fine = self.step.fine
@@ -231,9 +233,10 @@ class PathMLMC:
     def state_entries(self):
         return sum(lv.B * lv.act_src.M for lv in self.levels.values())
 
-    def thermalise(self, n):
+    def thermalise(self, n, sub_factor=1.0):
         for lv in self.levels.values():
             if self.hierarchical:
+                lv.sub_factor = sub_factor
                 lv.thermalise(n, self.dts)
             else:
                 lv.thermalise(n, self.dts[lv.level])
