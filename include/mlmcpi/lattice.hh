@@ -61,7 +61,9 @@ protected:
 };
 
 /** Unrotated and rotated periodic 2-D lattices.  The coarse hierarchy (lattice2d.cc:12-82) is built
- *  on demand; the vertex lists used only by the 2-D multilevel glue are not reproduced. */
+ *  on demand.  The vertex lists of the 2-D multilevel glue (coarse / fine-only vertices, fine -> coarse map,
+ *  lattice2d.cc:82-134) live with the level objects of the library (mlmcpi_gff_level_tables, csrc/gff_levels.hip),
+ *  pinned bit for bit to the reference's own class (tests/test_gff_levels.py). */
 class Lattice2D : public Lattice {
 public:
   Lattice2D(const unsigned int Mt_lat_, const unsigned int Mx_lat_, const CoarseningType coarsening_type_,

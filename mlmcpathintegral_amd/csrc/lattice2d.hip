@@ -179,6 +179,12 @@ __device__ __forceinline__ uint32_t wrap_add(uint32_t base, uint32_t off, uint32
 // updates in the same order as the generic instantiation (TWC = THC = 0): bit-identical results.
 // STEP: the heat-bath phases draw from the step envelope (2 beta <= kVsKappaMax; device_common.hpp) instead of the
 // wrapped-Cauchy one; pool_cap then counts entries of VsPool.
+// LDS bytes in front of the tile image of a heat-bath launch of schwinger_sweep_kernel (kernel and host agree through this)
+__host__ __device__ inline size_t sweep_pool_bytes(bool step, bool fixed, uint32_t cap) {
+  const size_t b = step ? (fixed ? VsPool<uint16_t>::bytes(cap) : VsPool<uint32_t>::bytes(cap)) : HbPool::bytes(cap);
+  return (b + 15) / 16 * 16;
+}
+
 template <bool HEAT, int NT, int TWC = 0, int THC = 0, bool STEP = false>
 __global__ void __launch_bounds__(NT, HEAT ? (NT == 256 ? 4 : NT == 512 ? 2 : 1) : 1)
     schwinger_sweep_kernel(uint32_t Mt, uint32_t Mx, double beta, const double2 *__restrict__ in,
@@ -202,12 +208,13 @@ __global__ void __launch_bounds__(NT, HEAT ? (NT == 256 ? 4 : NT == 512 ? 2 : 1)
     }
     return wrap_add(base, off, n);
   };
-  double *th0 = lds, *th1 = lds + (size_t)bw * bh;
-  // retry pool of the heat-bath phases, behind the tile image (the host sizes the allocation for tg.TW x tg.TH tiles)
-  double *pool_lds = lds + (size_t)2 * ((FIXED ? TWC : tg.TW) + 2 * H) * ((FIXED ? THC : tg.TH) + 2 * H);
-  HbPool pool = HbPool::carve(pool_lds, HEAT && !STEP ? pool_cap : 0u);
+  // The sampler's tables and the list / pool of open cells of the heat-bath phases at the START of the LDS (table look-ups
+  // are then instruction offsets; r04), the tile image behind them (launch_sweep_nt sizes the allocation the same way)
   using PoolEntry = typename std::conditional<FIXED, uint16_t, uint32_t>::type;   // 68 x 36 cells: 12 bits of offset
+  double *pool_lds = lds;
+  HbPool pool = HbPool::carve(pool_lds, HEAT && !STEP ? pool_cap : 0u);
   VsPool<PoolEntry> vpool = VsPool<PoolEntry>::carve(pool_lds, HEAT && STEP ? pool_cap : 0u, STEP ? vs_table : nullptr);
+  double *th0 = lds + (HEAT ? sweep_pool_bytes(STEP, FIXED, pool_cap) / sizeof(double) : 0), *th1 = th0 + (size_t)bw * bh;
   const double beta2 = 2. * beta;
   const uint32_t sc = (uint32_t)(((uint64_t)i0 + Mt - (H % Mt)) % Mt);  // lattice column of buffer column 0
   const uint32_t sr = (uint32_t)(((uint64_t)j0 + Mx - (H % Mx)) % Mx);
@@ -1265,9 +1272,12 @@ __global__ void __launch_bounds__(1024)
 // the 8 neighbour values across the block's edges that belong to the other colour.  Redundancy (64 + 4K)^2 / 64^2
 // (1.72 at K = 5) instead of 1.875 at K = 4 on 64 x 32 tiles, 1.75 LDS accesses per update instead of 3, three
 // workgroups per CU.  Same sums in the same order as gff_or_patch_kernel: bit-identical.
-template <int K>
+// T: tile extent.  64 is the default; 32 x 32 tiles (r04) serve the lattices 64 x 64 tiles do not divide or that are too
+// small for the fused launch (96 x 96: 339 -> see DESIGN 7, fast_path_cliff) -- the halo recomputation is 2.6 x at K = 5
+// instead of 1.7 x, but the launches are bound by their passes over the state, not by the sweeps.
+template <int K, int T = 64>
 struct GffBlockGeom {
-  static constexpr int TW = 64, TH = 64, PW = 4, PH = 4, H = 2 * K;
+  static constexpr int TW = T, TH = T, PW = 4, PH = 4, H = 2 * K;
   static constexpr int BW = TW + 2 * H, BH = TH + 2 * H, NPX = BW / PW, NPY = BH / PH, NP = NPX * NPY;
   static constexpr int NT = (NP + 63) / 64 * 64;
   static constexpr int NPLANE = 2 * PW + 2 * (PH - 2);
@@ -1358,11 +1368,11 @@ __device__ __forceinline__ void gff_block_sweeps(double *lds, const double *__re
   }
 }
 
-template <int K>
-__global__ void __launch_bounds__(GffBlockGeom<K>::NT)
+template <int K, int T = 64>
+__global__ void __launch_bounds__((GffBlockGeom<K, T>::NT))
     gff_or_block_kernel(uint32_t Mt, uint32_t Mx, double mu2, const double *__restrict__ in, double *__restrict__ out,
                         uint32_t tiles_x) {
-  using G = GffBlockGeom<K>;
+  using G = GffBlockGeom<K, T>;
   constexpr int TW = G::TW, TH = G::TH, PW = G::PW, PH = G::PH, H = G::H, NPX = G::NPX, NP = G::NP;
   static_assert(PW == 4 && PH == 4, "the write-back moves 4 sites per block row");
   extern __shared__ double lds[];
@@ -1410,19 +1420,19 @@ __global__ void __launch_bounds__(GffBlockGeom<K>::NT)
 // not parked in LDS here: the thread that draws the pair for a colour-0 cell (r, c) also updates the colour-1 cell
 // (r, c ^ 1) and keeps its normal in a register (the two phases walk the same compile-time index space), so the image is
 // the field alone and three workgroups fit a CU.
-template <int K>
+template <int K, int T = 64>
 struct GffHeatGeom {
-  using G = GffBlockGeom<K + 1>;
+  using G = GffBlockGeom<K + 1, T>;
   static constexpr int NT = G::NT, HB = 2, IW = G::TW + 2 * HB, IH = G::TH + 2 * HB;
   static constexpr size_t image_bytes = (size_t)IW * IH * sizeof(double);
   static constexpr size_t lds_bytes = G::lds_bytes > image_bytes ? G::lds_bytes : image_bytes;
 };
 
-template <int K>
-__global__ void __launch_bounds__(GffHeatGeom<K>::NT, 4)
+template <int K, int T = 64>
+__global__ void __launch_bounds__((GffHeatGeom<K, T>::NT), 4)
     gff_or_heat_kernel(uint32_t Mt, uint32_t Mx, double mu2, const double *__restrict__ in, double *__restrict__ out,
                        uint32_t tiles_x, RngKey key0, int qoi_op, double *__restrict__ qoi_partial) {
-  using OH = GffHeatGeom<K>;
+  using OH = GffHeatGeom<K, T>;
   using G = typename OH::G;
   constexpr int NT = OH::NT, TW = G::TW, TH = G::TH, PW = G::PW, PH = G::PH, H = G::H, NPX = G::NPX, NP = G::NP;
   constexpr int HB = OH::HB, IW = OH::IW, IH = OH::IH, O = H - HB;  // image (0, 0) = buffer (O, O)
@@ -1674,7 +1684,7 @@ __global__ void __launch_bounds__(256) gff_force_kernel(uint32_t Mt, uint32_t Mx
 // by 62 columns, 3 % redundant loads and sines, and nothing at the edge of a wave is special.  Rows are loaded two ahead
 // of their use.  Same arithmetic per plaquette as before (same sum order): bit-identical forces.
 #ifndef MLMCPI_FORCE_ROWS
-#define MLMCPI_FORCE_ROWS 32
+#define MLMCPI_FORCE_ROWS 128
 #endif
 constexpr uint32_t kForceCols = 62, kForceRows = MLMCPI_FORCE_ROWS;
 __host__ __device__ inline uint32_t force_waves(uint32_t Mt, uint32_t Mx) {
@@ -1695,20 +1705,28 @@ __device__ __forceinline__ void schwinger_force_band(const double2 *__restrict__
     // theta(i,j,0) + theta(i+1,j,1) - theta(i,j+1,0) - theta(i,j,1)   (quenchedschwingeraction.cc:14-17)
     return coupling * sin_reduced(a.x + wave_rotate_down(a.y) - above.x - a.y);
   };
+  // Rows are loaded four ahead of their use, at the TOP of an iteration (vmcnt counts stores too and retires in order, so
+  // waiting for a row implies waiting for every store issued before its load).  Measured: 0.234 ms with two rows of
+  // lookahead as with four, bands of 32 rows; 0.228 ms with bands of 128 (fewer band edges); EXPERIMENTS 1.6.
   const uint32_t jm = jb == 0 ? Mx - 1 : jb - 1;
-  uint32_t j1 = up_of(jb), j2 = up_of(j1);
+  uint32_t jn = jb;
+  auto next_row = [&]() {   // (up to four rows past the band at its end: valid rows, not used -- guarding the load cost 5 %)
+    jn = up_of(jn);
+    return t[(size_t)jn * Mt + i];
+  };
   const double2 below = t[(size_t)jm * Mt + i];
-  double2 here = t[(size_t)jb * Mt + i], above = t[(size_t)j1 * Mt + i], next = t[(size_t)j2 * Mt + i];
+  double2 here = t[(size_t)jb * Mt + i], above = next_row(), ahead1 = next_row(), ahead2 = next_row();
   double F_below = F_of(below, here);
   for (uint32_t j = jb; j < je; ++j) {
+    const double2 ahead3 = next_row();
     const double F = F_of(here, above);
     const double F_left = wave_rotate_up(F);
     if (owner) emit(j, i, F - F_below, F_left - F);
     F_below = F;
     here = above;
-    above = next;
-    j2 = up_of(j2);
-    next = t[(size_t)j2 * Mt + i];   // (two rows past the band at its end: a valid row, not used)
+    above = ahead1;
+    ahead1 = ahead2;
+    ahead2 = ahead3;
   }
 }
 
@@ -1923,7 +1941,7 @@ static int launch_sweep_nt(const SweepGeom &g, dim3 grid, hipStream_t st, uint32
                             const double *src, double *dst, uint32_t n, uint32_t kinds, RngKey key, int qoi_op = 0,
                             double *qoi_partial = nullptr) {
   if (SCHW) {
-    // heat-bath launches: room for the retry pool behind the tile image, as many entries as still keep the workgroup's
+    // heat-bath launches: room for the tables and the list of open cells in front of the tile image, as many entries as still keep the workgroup's
     // LDS footprint within a quarter of the CU's 160 KiB (4 workgroups per CU), at least one wave's worth
     const bool fixed = HEAT && NT == 256 && n == 1 && !g.overridden && g.tg.TW == 64 && g.tg.TH == 32 && Mt % 64 == 0 &&
                        Mx % 32 == 0 && Mt >= 128 && Mx >= 64;  // compile-time tile geometry (bit-identical results)
@@ -1935,13 +1953,12 @@ static int launch_sweep_nt(const SweepGeom &g, dim3 grid, hipStream_t st, uint32
       if (int rc = vs_table_device(2. * coupling, &vs_table)) return rc;
     if (HEAT) {
       const size_t quarter = 40 * 1024 - 64;  // (the kernel's static LDS: the QoI reduction scratch)
-      const size_t entry = step ? (fixed ? sizeof(uint16_t) : sizeof(uint32_t)) : 24, fixed_part = step ? kVsTableBytes + 16 : 8;
+      const size_t entry = step ? (fixed ? sizeof(uint16_t) : sizeof(uint32_t)) : 24, fixed_part = (step ? kVsTableBytes + 16 : 8) + 16;
       cap = 64;
       if (lds + fixed_part + entry * cap <= quarter) cap = (uint32_t)((quarter - lds - fixed_part) / entry) & ~7u;
       if (cap > (step ? 256u : 1024u)) cap = step ? 256u : 1024u;
-      const size_t pool_bytes = step ? (fixed ? VsPool<uint16_t>::bytes(cap) : VsPool<uint32_t>::bytes(cap)) : HbPool::bytes(cap);
-      lds += pool_bytes;
-      if (lds > 160 * 1024 - 256) { cap = 0; lds = g.lds_bytes + (step ? VsPool<uint32_t>::bytes(0) : 0); }
+      lds = g.lds_bytes + sweep_pool_bytes(step, fixed && step, cap);
+      if (lds > 160 * 1024 - 256) { cap = 0; lds = g.lds_bytes + sweep_pool_bytes(step, fixed && step, 0); }
     }
     if (fixed && step)
       hipLaunchKernelGGL((schwinger_sweep_kernel<HEAT, NT, 64, 32, HEAT>), grid, dim3(NT), lds, st, Mt, Mx, coupling,
@@ -2107,13 +2124,17 @@ static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, doub
   const Tuning tune = tuning();  // ONE snapshot per draw: mlmcpi_set_option on another thread cannot split a launch plan
   const bool or_blocks = !tune.or_lds && !tune.or_patch && !tune.tile_w && act->Mt % 64 == 0 && act->Mx % 64 == 0;
   const bool schw = act->kind == MLMCPI_SCHWINGER;
+  // GFF lattices that 32 x 32 tiles divide and 64 x 64 ones do not (or that are below 128, where the 64-tile fused launch
+  // does not apply): the register-block kernels on 32 x 32 tiles, same launch plan
+  const bool gff_blocks32 = !schw && !tune.or_lds && !tune.or_patch && !tune.tile_w && act->Mt % 32 == 0 && act->Mx % 32 == 0 &&
+                            act->Mt >= 64 && act->Mx >= 64 && !(or_blocks && act->Mt >= 128 && act->Mx >= 128);
   // One chain (at most one workgroup of the fused launch per CU: nothing to overlap a second launch's load and store
   // phases with): the whole draw in ONE launch of schwinger_or_heat_kernel<n_overrelax, wide> while its halo fits a
   // workgroup (n_overrelax <= 10) -- the library default only; a caller's `fuse` is kept.
   const bool whole_draw = fuse == 0 && schw && or_blocks && !tune.or_heat_split && tune.or_heat_wide >= 0 && n_heatbath >= 1 &&
                           n_overrelax >= 6 && n_overrelax <= 10 && 2. * act->beta <= kVsKappaMax && act->Mt >= 128 && act->Mx >= 128 &&
                           (uint64_t)(act->Mt / 64) * (act->Mx / 64) * B <= kComputeUnits;
-  if (fuse == 0) fuse = whole_draw ? n_overrelax : or_blocks ? 6 : 4;
+  if (fuse == 0) fuse = whole_draw ? n_overrelax : (or_blocks || gff_blocks32) ? 6 : 4;
   if (fuse > kMaxFuse) fuse = kMaxFuse;
   hipStream_t st = as_stream(stream);
   const uint32_t total = n_overrelax + n_heatbath;
@@ -2134,7 +2155,7 @@ static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, doub
     if (s < n_overrelax) {
       const uint32_t rem = n_overrelax - s;
       n = rem < fuse ? rem : fuse;
-      if (or_blocks) {  // as few launches as `fuse` allows, of equal depth (10 sweeps, fuse 6: 5 + 5, not 6 + 4)
+      if (or_blocks || gff_blocks32) {  // as few launches as `fuse` allows, of equal depth (10 sweeps, fuse 6: 5 + 5, not 6 + 4)
         const uint32_t launches = (rem + fuse - 1) / fuse;
         n = (rem + launches - 1) / launches;
       }
@@ -2253,6 +2274,49 @@ static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, doub
 #undef MLMCPI_OR
       MLMCPI_LAUNCH_CHECK("schwinger_or_kernel");
       rc = MLMCPI_OK;
+    } else if (!schw && !kinds && !g.overridden && gff_blocks32 && n <= 6) {
+      const double mu2 = gff_mu2(*act);
+      dim3 bgrid((act->Mt / 32) * (act->Mx / 32), B);
+      if (!tune.or_heat_split && s + n == n_overrelax && n_heatbath >= 1 && n <= 5) {
+        const bool with_qoi = qoi_kind && s + n + 1 == total;
+        void *partial = nullptr;
+        if (with_qoi)
+          if (int rcs = scratch((size_t)B * bgrid.x * sizeof(double), &partial, st)) return rcs;
+        const int op = with_qoi ? (int)L_PHI2 : 0;
+        const RngKey hkey = make_key(seed, chain0, sweep0 + s + n);
+#define MLMCPI_GFF_HEAT32(KK) hipLaunchKernelGGL((gff_or_heat_kernel<KK, 32>), bgrid, dim3((GffHeatGeom<KK, 32>::NT)), (GffHeatGeom<KK, 32>::lds_bytes), st, act->Mt, act->Mx, mu2, (const double *)src, dst, act->Mt / 32, hkey, op, (double *)partial)
+        switch (n) {
+          case 1: MLMCPI_GFF_HEAT32(1); break;
+          case 2: MLMCPI_GFF_HEAT32(2); break;
+          case 3: MLMCPI_GFF_HEAT32(3); break;
+          case 4: MLMCPI_GFF_HEAT32(4); break;
+          default: MLMCPI_GFF_HEAT32(5);
+        }
+#undef MLMCPI_GFF_HEAT32
+        MLMCPI_LAUNCH_CHECK("gff_or_heat_kernel<., 32>");
+        if (with_qoi) {
+          hipLaunchKernelGGL(lattice_finish_kernel, dim3((B + 3) / 4), dim3(256), 0, st, (const double *)partial, bgrid.x, B, op,
+                             1.0 / ((double)act->Mx * act->Mt), d_qoi, d_acc);
+          MLMCPI_LAUNCH_CHECK("lattice_finish_kernel");
+        }
+        advance();
+        s += n + 1;
+        continue;
+      }
+#define MLMCPI_GFF_BLOCK32(KK) hipLaunchKernelGGL((gff_or_block_kernel<KK, 32>), bgrid, dim3((GffBlockGeom<KK, 32>::NT)), (GffBlockGeom<KK, 32>::lds_bytes), st, act->Mt, act->Mx, mu2, (const double *)src, dst, act->Mt / 32)
+      switch (n) {
+        case 1: MLMCPI_GFF_BLOCK32(1); break;
+        case 2: MLMCPI_GFF_BLOCK32(2); break;
+        case 3: MLMCPI_GFF_BLOCK32(3); break;
+        case 4: MLMCPI_GFF_BLOCK32(4); break;
+        case 5: MLMCPI_GFF_BLOCK32(5); break;
+        default: MLMCPI_GFF_BLOCK32(6);
+      }
+#undef MLMCPI_GFF_BLOCK32
+      MLMCPI_LAUNCH_CHECK("gff_or_block_kernel<., 32>");
+      advance();
+      s += n;
+      continue;
     } else if (!schw && !kinds && !g.overridden && act->Mt % 64 == 0 && act->Mx % 32 == 0 && n <= (or_blocks ? 6u : 4u)) {
       const size_t lds = (size_t)(32 + 4 * n) * (64 + 4 * n + 1) * sizeof(double);
       dim3 sgrid((act->Mt / 64) * (act->Mx / 32), B);

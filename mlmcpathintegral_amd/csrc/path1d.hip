@@ -503,13 +503,16 @@ __global__ void __launch_bounds__(256, HEAT && STEP ? MLMCPI_ROTOR_WAVES : 1)
     rotor_sweep_kernel(PathP P, const double *__restrict__ in, double *__restrict__ out, uint32_t owned_len,
                        uint32_t nsweeps, uint32_t kinds, RngKey key0, uint32_t pool_cap, const uint32_t *__restrict__ vs_table,
                        double *__restrict__ winding_partial = nullptr) {
-  extern __shared__ double buf[];
+  extern __shared__ double lds_all[];
   __shared__ double qoi_red[4];
   // winding_partial != NULL: the segment's share of sum_j mod_2pi(x_j - x_{j-1}) (qoi/qm/qoisusceptibility.cc:8-23) of the
   // NEW state goes out with it; the left neighbour of the first owned site has to be exact for that: one more pair of halo sites
   const uint32_t b = blockIdx.y, seg = blockIdx.x, M = P.M, halo = 2 * nsweeps + (winding_partial ? 2u : 0u);
-  HbPool pool = HbPool::carve(buf + owned_len + 2 * halo, HEAT && !STEP ? pool_cap : 0u);  // behind the segment image
-  VsPool<uint32_t> vpool = VsPool<uint32_t>::carve(buf + owned_len + 2 * halo, HEAT && STEP ? pool_cap : 0u, STEP ? vs_table : nullptr);
+  // the sampler's tables and the list of open cells at the START of the LDS (table look-ups are then instruction offsets, not
+  // additions of a wave-uniform base at half rate: r04, -4 % on the sweeps), the segment image behind them
+  HbPool pool = HbPool::carve(lds_all, HEAT && !STEP ? pool_cap : 0u);
+  VsPool<uint32_t> vpool = VsPool<uint32_t>::carve(lds_all, HEAT && STEP ? pool_cap : 0u, STEP ? vs_table : nullptr);
+  double *const buf = lds_all + (HEAT ? (STEP ? VsPool<uint32_t>::bytes(pool_cap) : HbPool::bytes(pool_cap)) / sizeof(double) : 0);
   const uint32_t o0 = seg * owned_len, olen = min(owned_len, M - o0);
   const uint32_t L = olen + 2 * halo;
   const uint32_t g0 = (uint32_t)(((uint64_t)o0 + M - (halo % M)) % M);

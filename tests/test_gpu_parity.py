@@ -529,6 +529,8 @@ SWEEP_CASES = [
     ("gff", 64, 64, dict(mass=10.0), 2),   # specialised overrelaxation kernel, 1 x 2 tiles
     ("gff", 128, 128, dict(mass=3.0), 1),  # 2 x 4 tiles
     ("gff", 130, 130, dict(mass=10.0), 1),
+    ("gff", 96, 96, dict(mass=10.0), 2),   # 3 x 3 tiles of 32 x 32: register-block kernels where 64 x 64 tiles do not divide (r04)
+    ("gff", 160, 160, dict(mass=3.0), 1),  # 5 x 5 tiles (the GFF action takes square lattices only, gffaction.hh:169-173)
     ("schwinger", 2, 2, dict(beta=1.0), 2),
     ("schwinger", 2, 8, dict(beta=0.7), 1),
     ("schwinger", 4, 4, dict(beta=1.0), 2),
@@ -625,9 +627,11 @@ def test_wide_workgroups_of_the_fused_launch_change_nothing(gpu_ops, Mt, Mx, B):
         assert_close(res["wide"][1].cpu().numpy(), res["narrow"][1].cpu().numpy(), tol=1e-13, what="QoI")
 
 
-@pytest.mark.parametrize("M,B,mass", [(128, 3, 3.0), (192, 2, 10.0), (512, 2, 10.0)])
+@pytest.mark.parametrize("M,B,mass", [(128, 3, 3.0), (192, 2, 10.0), (512, 2, 10.0),
+                                      (96, 3, 10.0), (64, 2, 3.0), (160, 2, 10.0)])   # r04: 32 x 32 tiles
 def test_gff_overrelaxation_and_heat_bath_in_one_launch_equal_two_launches(gpu_ops, M, B, mass):
-    """gff_or_heat_kernel<K> against the two launches it replaces (MLMCPI_OR_HEAT=split): field bit for bit, phi^2 to rounding."""
+    """gff_or_heat_kernel<K> against the two launches it replaces (MLMCPI_OR_HEAT=split): field bit for bit, phi^2 to rounding.
+    (Lattices of 96, 64, 160 sites: the register-block kernels on 32 x 32 tiles, gff_or_heat_kernel<K, 32>.)"""
     from mlmcpathintegral_amd import abi
     act = abi.lattice_action(abi.GFF, M, M, mass=mass)
     x0 = gpu_ops.lattice_initialise(act, B, SEED, 2)
@@ -1063,7 +1067,7 @@ def test_draw_qoi_record_in_one_call_equals_the_three_steps(gpu_ops, kind, M, B)
         gpu_ops.lattice_sweep_draw_qoi(act, x0, torch.empty_like(x0), x0.clone(), 2, 0, SEED, 6, 0, qk, acc=torch.zeros((B, 5), dtype=torch.float64, device="cuda"))
 
 
-@pytest.mark.parametrize("M,B,n_or,n_hb", [(512, 3, 5, 1), (64, 2, 0, 1), (20, 2, 3, 2), (192, 2, 1, 1)])
+@pytest.mark.parametrize("M,B,n_or,n_hb", [(512, 3, 5, 1), (64, 2, 0, 1), (20, 2, 3, 2), (192, 2, 1, 1), (96, 2, 10, 1)])
 def test_fused_gff_qoi_equals_separate_evaluation(gpu_ops, M, B, n_or, n_hb):
     """The same for the GFF action: QoI2DPhiSquared (qoi kind 3) summed inside the heat-bath launch."""
     from mlmcpathintegral_amd import abi
