@@ -771,7 +771,7 @@ def main():
             launch_ms = ms(events) / a.steps
             floor = 16.0 * sum(lv.n_sub * lv.B * lv.sampler.acts[-1].M for lv in est.levels.values())  # coarsest states, once per trajectory
             result["roofline"] = register_resident_roofline(
-                "hmc_trajectory_kernel<1,8> (coarsest-level HMC of every hierarchical draw, M_lat = 2048: 4 waves per chain; > 95 % of the site-steps)", launch_ms, floor,
+                "hmc_trajectory_kernel<1,R> (coarsest-level HMC of every hierarchical draw, M_lat = %d: R = 16 sites per lane, 2 waves per chain at 2048 chains; > 95 %% of the site-steps)" % (size >> 4), launch_ms, floor,
                 32.0 * units_per_step / world, pmc_entry("kernels_valu_busy", workload=a.workload, size=size, chains=B),
                 "one step of all level instances of rank 0")
         else:

@@ -98,6 +98,37 @@ def test_config5_as_the_reference_runs_it_agrees_with_single_level_hmc():
     assert abs(z) < 2.0, z
 
 
+def test_hierarchical_line_with_moving_chains():
+    """r04: the second hierarchical line (T_final = M_lat / 32): no frozen level, every hierarchical sampler moves on every
+    level -- the multilevel path at bench scale with chains that move.  Its distance from single-level HMC is recorded in the
+    line and NOT gated: with the reference's ceil(2 tau_int) sub-sampling the delayed-acceptance scheme is biased at this
+    acceptance rate, which is what the line documents."""
+    if _tag() < "r04":
+        return
+    h = json.load(open(os.path.join(ROOT, "profiles", f"{_tag()}_bench_quartic_mlmc_hier_T1024.json")))
+    assert h["mlmc"]["frozen_levels"] == []
+    for acc in h["mlmc"]["hierarchical_acceptance_rank0"].values():
+        assert all(v > 0.02 for v in acc.values()), acc
+    assert "z" in h["mlmc"]["run_to_epsilon"]["single_level_fine_hmc"]
+
+
+def test_default_line_carries_the_r04_records():
+    """hbm_bound_probes (which kernels of the path reach 60 % of the HBM roofline), fast_path_cliff, the binding bound"""
+    if _tag() < "r04":
+        return
+    r = _latest_default_line()
+    probes = {p["entry_point"]: p for p in r["hbm_bound_probes"]["probes"]}
+    assert len(probes) == 4 and all(0.0 < p["frac_of_hbm_peak"] <= 1.0 for p in probes.values())
+    assert sum(p["reaches_60_percent"] for p in probes.values()) >= 3
+    for p in probes.values():
+        if p["counter_bytes"] is not None:
+            assert p["counter_bytes"] >= 0.95 * p["floor_bytes"]
+    cliff = {p["point"]: p for p in r["fast_path_cliff"]}
+    assert len(cliff) >= 6 and all(p["over_headline"] is None or p["over_headline"] > 0.65 for p in cliff.values()), cliff
+    assert r["roofline"]["bound"] == "valu" and 0.0 < r["roofline"]["frac"] <= 1.0
+    assert r["cpu_baseline"]["cores"] == min(r["cpu_baseline"]["cores_available"], r["cpu_baseline"]["cpu_quota"])
+
+
 def test_traffic_json_is_tied_to_a_kernel_build():
     t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
     builds = {e["build"] for sec in ("entries", "valu", "kernels_valu_busy") for e in t[sec]}

@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
-"""Merge the second profile_all.sh call (tag Tb) into the first (tag T): summary.json (dict update) and *_kernel_stats.csv.
-   tools/merge_profiles.py gpurun_out/prof_T gpurun_out/prof_Tb"""
+"""Merge the summaries of several tools/profile_all.sh calls (the eight workloads do not fit one gpurun call) into the
+first directory:   python tools/merge_profiles.py gpurun_out/prof_r04 gpurun_out/prof_r04b gpurun_out/prof_r04c
+then               python tools/make_traffic_json.py gpurun_out/prof_r04 r04"""
 import glob, json, os, shutil, sys
-a_dir, b_dir = sys.argv[1], sys.argv[2]
-a = json.load(open(os.path.join(a_dir, "summary.json")))
-a.update(json.load(open(os.path.join(b_dir, "summary.json"))))
-json.dump(a, open(os.path.join(a_dir, "summary.json"), "w"), indent=1)
-for f in glob.glob(os.path.join(b_dir, "*_kernel_stats.csv")):
-    shutil.copy(f, a_dir)
-print("workloads:", ", ".join(a))
+dst = sys.argv[1]
+S = json.load(open(os.path.join(dst, "summary.json")))
+for src in sys.argv[2:]:
+    S.update(json.load(open(os.path.join(src, "summary.json"))))
+    for f in glob.glob(os.path.join(src, "*_kernel_stats.csv")):
+        shutil.copy(f, dst)
+json.dump(S, open(os.path.join(dst, "summary.json"), "w"), indent=1)
+print(sorted(S), {w: (e.get("bench_profiled") or {}).get("kernel_build") for w, e in S.items()})

@@ -5,6 +5,17 @@ gfx950, MI355X_MICROARCH.md HBM section) for the library's kernels -> <dir>/summ
 import collections, csv, glob, json, os, shutil, sys
 out = sys.argv[1]
 summary = {}
+
+
+def grid_of(row):
+    """total threads of a dispatch (rocprofv3 writes Grid_Size in the counter files, Grid_Size_X/Y/Z in the kernel trace)"""
+    if row.get("Grid_Size"):
+        return str(int(float(row["Grid_Size"])))
+    g = 1
+    for k in ("Grid_Size_X", "Grid_Size_Y", "Grid_Size_Z"):
+        g *= int(float(row.get(k) or 1))
+    return str(g)
+
 for wdir in sorted(glob.glob(os.path.join(out, "*", ""))):
     w = os.path.basename(os.path.dirname(wdir))
     entry = {"kernels": {}}
@@ -15,6 +26,17 @@ for wdir in sorted(glob.glob(os.path.join(out, "*", ""))):
             name = row["Name"].split("(")[0].replace("void ", "")
             if "mlmcpi::" in name:
                 entry["kernels"].setdefault(name, {}).update(calls=int(row["Calls"]), avg_ns=float(row["AverageNs"]), pct=float(row["Percentage"]))
+    # The HMC trajectory kernel runs with one name on lattices of every level (the untimed direct-HMC thermalisation of the fine
+    # levels and the timed coarsest-level draws of quartic_mlmc_hier): keyed by grid size as well, from the kernel trace.
+    per_grid = collections.defaultdict(list)
+    for f in glob.glob(os.path.join(wdir, "stats", "**", "*kernel_trace.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if "hmc_trajectory_kernel" in row["Kernel_Name"]:
+                per_grid[row["Kernel_Name"].split("(")[0].replace("void ", "") + " grid=" + grid_of(row)].append(
+                    float(row["End_Timestamp"]) - float(row["Start_Timestamp"]))
+    total_ns = sum(k["avg_ns"] * k["calls"] for k in entry["kernels"].values() if "avg_ns" in k) or 1.0
+    for name, v in per_grid.items():
+        entry["kernels"].setdefault(name, {}).update(calls=len(v), avg_ns=sum(v) / len(v), pct=100.0 * sum(v) / total_ns, by_grid=True)
     for sub in ("sq", "mix1", "mix2", "FETCH_SIZE", "WRITE_SIZE"):
         acc = collections.defaultdict(lambda: collections.defaultdict(list))
         for f in glob.glob(os.path.join(wdir, sub, "**", "*counter_collection.csv"), recursive=True):
@@ -22,6 +44,8 @@ for wdir in sorted(glob.glob(os.path.join(out, "*", ""))):
                 name = row["Kernel_Name"].split("(")[0].replace("void ", "")
                 if "mlmcpi::" in name:
                     acc[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
+                    if "hmc_trajectory_kernel" in name:
+                        acc[name + " grid=" + grid_of(row)][row["Counter_Name"]].append(float(row["Counter_Value"]))
         for name, d in acc.items():
             k = entry["kernels"].setdefault(name, {})
             for c, v in d.items():
