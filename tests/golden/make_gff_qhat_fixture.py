@@ -18,6 +18,14 @@ What is imported and how:
     low-mode projection, so the acceptance recorded here is the same Metropolis test WITHOUT the projection, written
     with the class's own draw_* / evaluate_* calls (see independence_acceptance below).
 
+  * /root/reference/python/gff_twolevel.py -- class GFFAction (:7-165): evaluate (the plain fine action), evaluate_fillin
+    (the Gaussian fill-in action of the odd vertices = GFFConditionedFineAction::evaluate, gffconditionedfineaction.cc:7-49),
+    class TwoLevelSampler.step (:206-229: the three action differences of TwoLevelMetropolisStep::draw), class
+    QoISquaredField.exact_value (:186-193 = gff_phi_squared_analytical, auxilliary.cc:197-209).  Importing it runs the
+    author's 32 x 32 demonstration and writes covariance.pdf into the working directory: it is imported from a temporary
+    directory.  Recorded: S_fine, S_fillin, S_coarse (the smoothed coarse action, Lattice2D sweep order) of two
+    deterministic fields and the step's Delta S for the pair (current, proposal).
+
 Index order.  The Gibbs iteration matrix G depends on the ORDER of the sweep, so for nsmooth > 0 Q_prec_iter depends on
 the linear numbering of the rotated vertices.  The Python class numbers them (i outer, j inner, i + j even); the C++
 Lattice2D numbers them even-even vertices first, then odd-odd (lattice/lattice2d.hh:230-241), and GFFAction sweeps in
@@ -112,6 +120,65 @@ def independence_acceptance(tl, Mlat, mass, nsamples, seed):
     return accepted / nsamples, expected / nsamples
 
 
+def twolevel_terms(gs, tw, Lattice2DOrder):
+    """The terms of one two-level step between two deterministic fields, by the reference author's own methods."""
+    out = []
+    for Mlat, mass, nsmooth in ((8, 10.0, 2), (16, 10.0, 2), (16, 3.0, 1), (16, 10.0, 0)):
+        action = tw.GFFAction(Mlat, mass)
+        sm = Lattice2DOrder(action, nsmooth=nsmooth)
+        cur, prop = fields(Mlat)[0], fields(Mlat)[2]
+        terms = {}
+        for name, phi in (("current", cur), ("proposal", prop)):
+            terms[name] = {"S_fine": float(action.evaluate(phi)), "S_fillin": float(action.evaluate_fillin(phi)),
+                           "S_coarse": float(sm.evaluate(phi))}
+        # TwoLevelSampler.step, gff_twolevel.py:213-218
+        dS = (terms["proposal"]["S_fine"] - terms["current"]["S_fine"]) + (terms["current"]["S_coarse"] - terms["proposal"]["S_coarse"]) \
+            + (terms["current"]["S_fillin"] - terms["proposal"]["S_fillin"])
+        out.append({"Mlat": Mlat, "mass": mass, "nsmooth": nsmooth, "fields": ["fields()[0]", "fields()[2]"], "terms": terms, "DeltaS": dS})
+    exact = [{"Mlat": M, "mass": m, "phi_squared": float(tw.QoISquaredField(M, m).exact_value())} for M, m in ((16, 10.0), (64, 10.0), (32, 1.0))]
+    return out, exact
+
+
+def expected_acceptance(cls, Mlat, mass, nsmooth, n, seed):
+    """Stationary acceptance probability of the two-level step 16 x 16 <- rotated level, from the reference author's matrices
+    (numpy, vectorised restatement of TwoLevelSampler.step: current state ~ the fine action, coarse proposal ~ Sigma_iter,
+    Gaussian fill-in of the odd vertices): E[min(1, exp(-Delta S))].  cls fixes the order of the Gibbs sweep."""
+    act = types.SimpleNamespace(Mlat=Mlat, alat=1.0 / Mlat, mass=mass)
+    mu2, N = (mass / Mlat) ** 2, Mlat * Mlat
+    idx = lambda i, j: (i % Mlat) + Mlat * (j % Mlat)
+    Q = np.zeros((N, N))
+    for i in range(Mlat):
+        for j in range(Mlat):
+            Q[idx(i, j), idx(i, j)] = 4 + mu2
+            for di, dj in ((1, 0), (-1, 0), (0, 1), (0, -1)):
+                Q[idx(i, j), idx(i + di, j + dj)] = -1
+    Lf = np.linalg.cholesky(np.linalg.inv(Q))
+    sm = cls(act, nsmooth=nsmooth)
+    c_lin = np.zeros(sm.ndof, dtype=int)
+    for (i, j), l in sm.cart2lin_idx.items():
+        c_lin[l] = idx(i, j)
+    Lc, Qh, kap = np.linalg.cholesky(sm.Sigma_iter), sm.Q_prec_iter, 4 + mu2
+    odd = [(i, j) for i in range(Mlat) for j in range(Mlat) if (i + j) % 2 == 1]
+    nbr = np.array([[idx(i + 1, j), idx(i - 1, j), idx(i, j + 1), idx(i, j - 1)] for i, j in odd])
+    oddl = np.array([idx(i, j) for i, j in odd])
+
+    def terms(phi):
+        pc = phi[c_lin]
+        return 0.5 * phi @ Q @ phi, 0.5 * pc @ Qh @ pc, 0.5 * kap * np.sum((phi[oddl] - phi[nbr].sum(1) / kap) ** 2)
+
+    rng = np.random.default_rng(seed)
+    acc = []
+    for _ in range(n):
+        th = Lf @ rng.standard_normal(N)
+        pr = np.zeros(N)
+        pr[c_lin] = Lc @ rng.standard_normal(sm.ndof)
+        pr[oddl] = pr[nbr].sum(1) / kap + rng.standard_normal(len(oddl)) / np.sqrt(kap)
+        a, b, c = terms(th)
+        d, e, f = terms(pr)
+        acc.append(min(1.0, float(np.exp(-((d - a) + (b - e) + (c - f))))))
+    return float(np.mean(acc)), float(np.std(acc) / np.sqrt(n))
+
+
 def main():
     gs = load_gibbs_smoother()
     out = {"generated_by": "tests/golden/make_gff_qhat_fixture.py",
@@ -130,9 +197,45 @@ def main():
         acc.append({"Mlat": Mlat, "ndof": Mlat * Mlat, "mu2_fine": 0.390625, "nsamples": 4000, "accepted_fraction": rate,
                     "mean_acceptance_probability": mean_p})
     out["independence_acceptance_5pt_vs_9pt"] = acc
+    # gff_twolevel.py: imported from a scratch directory (it saves a plot where it runs)
+    import tempfile
+
+    class Lattice2DOrder(gs.CoarseGibbsSmoother):
+        def _build_index_maps(self):
+            self.cart2lin_idx, self.lin2cart_idx = {}, {}
+            for i in range(self.Mlat):
+                for j in range(self.Mlat):
+                    if (i + j) % 2 == 0:
+                        ell = lattice2d_rotated_index(self.Mlat, i, j)
+                        self.cart2lin_idx[(i, j)] = ell
+                        self.lin2cart_idx[ell] = (i, j)
+
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.chdir(tmp)
+        try:
+            import gff_twolevel as tw   # runs the author's 32 x 32 demonstration on import
+        finally:
+            os.chdir(cwd)
+    out["source"].append("/root/reference/python/gff_twolevel.py:7-229 (GFFAction, QoISquaredField, TwoLevelSampler.step)")
+    out["twolevel_terms"], out["phi_squared_exact"] = twolevel_terms(gs, tw, Lattice2DOrder)
+    # the author's TwoLevelSampler as it is (gff_twolevel.py:195-232), at the shape of the product's two-level chain test
+    # (16 x 16 <- rotated 16 x 16, mass 10, two Gibbs sweeps): its acceptance rate, for comparison with the device chain's
+    rho = []
+    for Mlat, mass, nsmooth, n in ((16, 10.0, 2, 4000), (16, 10.0, 0, 4000)):
+        np.random.seed(4242 + nsmooth)
+        sampler = tw.TwoLevelSampler(tw.GFFAction(Mlat, mass), tw.QoISquaredField(Mlat, mass), nsmooth=nsmooth)
+        for _ in range(n):
+            sampler.step()
+        rho.append({"Mlat": Mlat, "mass": mass, "nsmooth": nsmooth, "nsamples": n, "rho_accept": sampler.rho_accept()})
+    out["twolevel_rho_accept"] = rho
+    out["twolevel_expected_acceptance"] = []
+    for order, cls in (("python", gs.CoarseGibbsSmoother), ("lattice2d", Lattice2DOrder)):
+        m, e = expected_acceptance(cls, 16, 10.0, 2, 20000, 1)
+        out["twolevel_expected_acceptance"].append({"Mlat": 16, "mass": 10.0, "nsmooth": 2, "order": order, "mean": m, "error": e, "n": 20000})
     with open(os.path.join(HERE, "gff_qhat.json"), "w") as f:
         json.dump(out, f, indent=1)
-    print("wrote gff_qhat.json:", len(out["qhat"]), "Q-hat cases;", acc)
+    print("wrote gff_qhat.json:", len(out["qhat"]), "Q-hat cases;", acc, out["twolevel_rho_accept"])
 
 
 if __name__ == "__main__":

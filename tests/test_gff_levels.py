@@ -216,6 +216,39 @@ def test_gibbs_sweep_order_matters_for_qhat():
         assert not np.allclose(a["energies"], b["energies"], rtol=1e-6)
 
 
+@pytest.mark.parametrize("case", _qhat_fixture()["twolevel_terms"], ids=lambda c: f"M{c['Mlat']}-m{c['mass']}-n{c['nsmooth']}")
+def test_two_level_terms_match_the_reference_authors_python(orc, case):
+    """The three actions of TwoLevelMetropolisStep::draw for the GFF (twolevelmetropolisstep.cc:35-89 with GFFAction::evaluate,
+    gffaction.cc:8-30, the smoothed coarse action, :133-166, and GFFConditionedFineAction::evaluate,
+    gffconditionedfineaction.cc:7-49), against /root/reference/python/gff_twolevel.py (GFFAction.evaluate, evaluate_fillin,
+    CoarseGibbsSmoother.evaluate, TwoLevelSampler.step), run by the fixture generator on two deterministic fields: the
+    oracle reproduces S_fine, S_fillin, S_coarse of each field and Delta S of the pair to 1e-10 -- the vertex maps, the
+    restriction to the rotated level, the fill-in's neighbour sums and variance included."""
+    L = orc.lib()
+    Mlat, mass, n = case["Mlat"], case["mass"], case["nsmooth"]
+    F, Cl = OLevel(orc, Mlat, ROTATE, 0, mass, 0), OLevel(orc, Mlat, ROTATE, 1, mass, n)
+    f = _fixture_fields(Mlat)
+    got = {}
+    for name, field in (("current", f[0]), ("proposal", f[2])):
+        phi = np.array([field[l % Mlat, l // Mlat] for l in range(Mlat * Mlat)])   # vertex l = Mt j + i
+        coarse = np.zeros(Cl.N)
+        L.orc_gff_copy(F.h, phi, coarse, 1)
+        got[name] = {"S_fine": L.orc_gff_level_evaluate(F.h, phi), "S_fillin": L.orc_gff_cfa_evaluate(F.h, phi),
+                     "S_coarse": L.orc_gff_level_evaluate(Cl.h, coarse)}
+        for k, v in case["terms"][name].items():
+            assert abs(got[name][k] - v) < 1e-10 * max(1.0, abs(v)), (name, k, got[name][k], v)
+    dS = (got["proposal"]["S_fine"] - got["current"]["S_fine"]) + (got["current"]["S_coarse"] - got["proposal"]["S_coarse"]) \
+        + (got["current"]["S_fillin"] - got["proposal"]["S_fillin"])
+    assert abs(dS - case["DeltaS"]) < 1e-9
+
+
+def test_phi_squared_closed_form_matches_the_reference_authors_python(orc):
+    """gff_phi_squared_analytical (auxilliary.cc:197-209) against QoISquaredField.exact_value of gff_twolevel.py:186-193"""
+    for c in _qhat_fixture()["phi_squared_exact"]:
+        got = orc.lib().orc_gff_phi_squared_analytical(c["mass"], c["Mlat"], c["Mlat"])
+        assert abs(got - c["phi_squared"]) < 1e-12 * c["phi_squared"], (c, got)
+
+
 def test_three_level_acceptance_is_the_plain_vs_marginal_mismatch():
     """with three GFF levels (16 x 16 -> rotated -> 8 x 8) the lower two-level step accepts about 8 %.  The
     reading: the fill-in of the rotated level (gffconditionedfineaction.cc:7-25) is exact for the PLAIN stencil there, so
@@ -356,4 +389,9 @@ def test_gff_two_level_chain_samples_the_fine_distribution(gpu_ops, orc):
     p_acc = n_acc / (n * B)
     print(f"GFF two-level chain 16^2: <phi^2> = {m:.6f} +- {e:.6f} (exact {exact:.6f}), acceptance {p_acc:.3f}")
     zcheck("GFF two-level chain 16^2: <phi^2> vs closed form", m, e, exact)
+    # the acceptance rate expected from the reference author's matrices with Lattice2D's order of the Gibbs sweep
+    # (tests/golden/gff_qhat.json: 0.9863 +- 0.0001; the Python class's own sweep order would give 0.9910)
+    want = next(a for a in _qhat_fixture()["twolevel_expected_acceptance"] if a["order"] == "lattice2d")
+    zcheck("GFF two-level chain 16^2: acceptance vs the reference author's matrices", p_acc,
+           math.sqrt(p_acc * (1.0 - p_acc) / (n * B)) * 3.0, want["mean"], want["error"])   # (x 3: successive steps of a chain are correlated)
     assert p_acc > 0.5
