@@ -626,11 +626,12 @@ def main():
 
     elapsed = time_steps(torch, dist, world, step, a.steps, a.warmup)
 
-    if a.workload == "schwinger" and (a.probes or (not a.no_extra_points and a.chains == 0)):
+    # (side measurements on one rank only: at N > 1 they would only stagger the ranks in front of the statistics all-reduce)
+    if a.workload == "schwinger" and world == 1 and (a.probes or (not a.no_extra_points and a.chains == 0)):
         extra["hbm_bound_probes"] = hbm_bound_probes(torch, ops, W, a)
 
     # side measurements of the default workload (same kernels, other batch sizes), after the timed region
-    if a.workload == "schwinger" and not a.no_extra_points and a.chains == 0:
+    if a.workload == "schwinger" and world == 1 and not a.no_extra_points and a.chains == 0:
         # (a single-chain step is ~0.06 ms: 200 of them, so that the figure does not hang on a handful of launches)
         for name, b_extra, k_extra in (("single_chain", 1, max(10 * a.steps, 200)), ("chains_128", 128, max(2, a.steps // 4))):
             Wx = SweepWorkload(a, torch, abi, ops, "schwinger", size, b_extra, rank * b_extra)

@@ -101,3 +101,16 @@ def test_bench_has_no_fallback_or_silent_exit():
     for banned in ("os._exit", "daemon=True", "threading", "fallback;"):
         assert banned not in src, banned
     assert "comm.establish(" in src and '"rccl": rccl' in src
+
+
+def test_mapped_rccl_files_names_torchs_runtime():
+    """bench.py's rccl record says whether torch.distributed and the library communicator run on ONE librccl file
+    (comm.mapped_rccl_files, /proc/self/maps): a process that has imported torch.distributed maps torch's own librccl,
+    which is also the file comm.open_runtime() hands to the library by default."""
+    import os
+    import torch.distributed  # noqa: F401  (maps torch's librccl)
+    from mlmcpathintegral_amd import comm
+    mapped = comm.mapped_rccl_files()
+    want = comm.torch_rccl_path()
+    assert want is not None and os.path.realpath(want) in mapped, (want, mapped)
+    assert all("librccl" in os.path.basename(p) for p in mapped)
