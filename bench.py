@@ -198,7 +198,7 @@ def hbm_bound_probes(torch, ops, W, a, launches=20):
         x, w = ops.lattice_sweep_draw_pingpong(W.act, x, w, 1, 0, a.seed, W.chain0, sweep[0], 1)
         sweep[0] += 1
 
-    probes = [("schwinger_or_block_kernel<1>", "mlmcpi_lattice_sweep_draw (1 overrelaxation sweep, one launch)",
+    probes = [("schwinger_perm_kernel" if W.perm else "schwinger_or_block_kernel<1>", "mlmcpi_lattice_sweep_draw (1 overrelaxation sweep, one launch)",
                "quenchedschwingeraction.cc:57-65", or1, 2.0 * state_bytes),
               ("schwinger_reduce_band_kernel", "mlmcpi_lattice_evaluate", "quenchedschwingeraction.cc:7-22",
                lambda: ops.lattice_evaluate(W.act, x), state_bytes),
@@ -239,13 +239,13 @@ def fast_path_cliff(torch, abi, ops, a, rank, headline_rate):
     pts = []
     for name, kind, Mt, Mx, beta, B, path in (
             ("beta = 4 (2 beta = 8 > 4)", "schwinger", 1024, 1024, 4.0, 32,
-             "register-block overrelaxation launches + wrapped-Cauchy heat bath"),
-            ("960 x 960", "schwinger", 960, 960, 1.0, 32, "the fused fast path (64 x 64 tiles divide the lattice)"),
+             "the one-launch draw with the wrapped-Cauchy heat bath (schwinger_perm_heat_kernel<512, false>)"),
+            ("960 x 960", "schwinger", 960, 960, 1.0, 32, "the one-launch draw (64 x 64 tiles divide the lattice)"),
             ("1024 x 992 (64 x 32 tiles)", "schwinger", 1024, 992, 1.0, 32,
              "2 x 2 register-patch overrelaxation launches (4 sweeps each) + step-envelope heat bath on 64 x 32 tiles"),
             ("192 x 96", "schwinger", 192, 96, 1.0, 1024, "as 1024 x 992"),
             ("64 x 64", "schwinger", 64, 64, 1.0, 4096,
-             "register-block overrelaxation launches + generic heat-bath kernel (one 64 x 64 tile is the lattice: the fused "
+             "closed-form overrelaxation launch + generic heat-bath kernel (one 64 x 64 tile is the lattice: the fused "
              "launch's image would wrap around it twice)"),
             ("gff 96 x 96", "gff", 96, 96, None, 8192,
              "gff_or_block_kernel<5, 32> + gff_or_heat_kernel<5, 32>: register blocks on 32 x 32 tiles (r04; generic tiles before: 339 G/s)")):
@@ -299,21 +299,24 @@ class SweepWorkload:
         # the library's launch plan for the overrelaxation sweeps (lattice2d.hip, sweep_draw_impl): where the 4 x 4
         # register-block kernel applies, up to 6 sweeps per launch in launches of equal depth (10 -> 5 + 5); otherwise
         # launches of 4 and a remainder (10 -> 4 + 4 + 2)
-        self.blocks = (size % 64 == 0 and os.environ.get("MLMCPI_OR_KERNEL", "") in ("", "block")
+        self.blocks = (size % 64 == 0 and os.environ.get("MLMCPI_OR_KERNEL", "") in ("", "block", "perm")
                        and not os.environ.get("MLMCPI_SWEEP_TILE"))
-        self.fuse = a.fuse or (6 if self.blocks else 4)
+        # Schwinger, 64 x 64 tiles: overrelaxation in closed form (schwinger_perm_kernel / schwinger_perm_heat_kernel), up to
+        # 10 sweeps per launch, launches of equal depth; the last one takes the heat-bath sweep and the QoI along
+        self.perm = kind == "schwinger" and self.blocks and os.environ.get("MLMCPI_OR_KERNEL", "") in ("", "perm")
+        self.fuse = (min(a.fuse, 10) if a.fuse else 10) if self.perm else a.fuse or (6 if self.blocks else 4)
         self.plan = or_plan(a.n_overrelax, self.fuse, self.blocks)   # [(depth, launches), ...], at most two entries
         # The last overrelaxation launch of a draw takes the heat-bath sweep (and the QoI) along -- one launch of
         # schwinger_or_heat_kernel<depth> / gff_or_heat_kernel<depth> (lattice2d.hip, sweep_draw_impl): 4 x 4 register-block
         # geometry, depth <= 5, lattices >= 128, for the Schwinger action the step-envelope sampler (2 beta <= 4; beta = 1
         # here), not switched off by MLMCPI_OR_HEAT=split.
-        self.or_heat = (self.blocks and a.n_heatbath == 1 and bool(self.plan) and self.plan[-1][0] <= 5
+        self.or_heat = (self.blocks and a.n_heatbath == 1 and bool(self.plan) and (self.plan[-1][0] <= 5 or self.perm)
                         and size >= 128 and os.environ.get("MLMCPI_OR_HEAT", "") != "split" and not a.no_fused_qoi)
         self.or_heat_depth = self.plan[-1][0] if self.or_heat else 0
         # ... and with at most one workgroup of that launch per CU (one chain) the library puts the WHOLE draw into it
         # (6 <= n_overrelax <= 10, default fuse; sweep_draw_impl: whole_draw)
-        whole = (self.or_heat and kind == "schwinger" and not a.fuse and 6 <= a.n_overrelax <= 10 and (size // 64) ** 2 * B <= 256
-                 and os.environ.get("MLMCPI_OR_HEAT", "") != "narrow")
+        whole = (self.or_heat and kind == "schwinger" and not self.perm and not a.fuse and 6 <= a.n_overrelax <= 10
+                 and (size // 64) ** 2 * B <= 256 and os.environ.get("MLMCPI_OR_HEAT", "") != "narrow")
         self.whole = whole
         if whole:
             self.plan, self.or_heat_depth = [], a.n_overrelax
@@ -864,6 +867,8 @@ def report_sweeps(result, a, W, size, B, world, step_ms, ms):
 
     def or_name(depth):
         if a.workload == "schwinger":
+            if W.perm:
+                return f"schwinger_perm_kernel (K = {depth})"
             if not special:
                 return "schwinger_sweep_kernel<false,256>"
             if W.blocks:
@@ -927,7 +932,10 @@ def report_sweeps(result, a, W, size, B, world, step_ms, ms):
     fused = getattr(W, "fused", False)
     if W.or_heat:
         d = W.or_heat_depth
-        record(f"{a.workload}_or_heat_kernel<{d}>", f"{d} fused overrelaxation sweeps + heat-bath sweep + qoi->evaluate in one launch "
+        record(f"schwinger_perm_heat_kernel<{1024 if (size // 64) ** 2 * B <= 256 else 512}, true> (K = {d})" if W.perm
+               else f"{a.workload}_or_heat_kernel<{d}>",
+               (f"{d} overrelaxation sweeps in closed form (one fixed permutation of the plaquettes)" if W.perm
+                else f"{d} fused overrelaxation sweeps") + " + heat-bath sweep + qoi->evaluate in one launch "
                "(QoI summed while the tile is in LDS)", W.ev["hb"], 1, d + 1, state_rw,
                pmc_entry("entries", chains=B, fuse=d + 1, kind="or_heat", **wl), pmc_entry("valu", kind="or_heat", fuse=d + 1, **wl))
     elif a.n_heatbath:

@@ -47,6 +47,7 @@ struct Tuning {
   uint32_t tile_w = 0, tile_h = 0, tile_nt = 0;  // MLMCPI_SWEEP_TILE=TWxTHxNT (0: default geometry)
   bool or_lds = false;                           // MLMCPI_OR_KERNEL=lds: LDS-resident instead of register-tiled overrelaxation
   bool or_patch = false;                         // MLMCPI_OR_KERNEL=patch: 2 x 2 register blocks on 64 x 32 tiles instead of 4 x 4 on 64 x 64
+  bool or_block = false;                         // MLMCPI_OR_KERNEL=block: 4 x 4 register blocks sweep by sweep instead of the closed form (Schwinger)
   uint32_t or_threads = 0;                       // MLMCPI_OR_THREADS (LDS-resident kernel's workgroup size; 0: default)
   bool or_heat_split = false;                    // MLMCPI_OR_HEAT=split: the heat-bath sweep behind the last overrelaxation launch gets a launch of its own
   int or_heat_wide = 0;                          // MLMCPI_OR_HEAT=wide|narrow: 1024-thread workgroups for the fused launch (+1 / -1; 0: by the number of tiles)

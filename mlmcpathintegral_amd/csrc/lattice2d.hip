@@ -828,83 +828,14 @@ __global__ void __launch_bounds__(OrBlockGeom<K>::NT)
   }
 }
 
-// ---- Schwinger: K overrelaxation sweeps and the heat-bath sweep behind them in one launch ------------------------------
-// A draw ends "... K overrelaxation sweeps, heat bath, QoI".  As two launches the state makes two round trips through HBM,
-// and the two kernels leave opposite halves of the CU idle: the overrelaxation launch is bound by its load / store phases
-// and the latencies of its colour phases (vector issue 0.44), the heat bath by vector issue (0.88) with its memory
-// traffic hidden.  Here the workgroup that has just swept a tile K times in registers (or_block_sweeps on the geometry
-// with halo 2K + 2, i.e. OrBlockGeom<K + 1>) lays the tile and the two rings the heat bath reads down as an LDS image (the
-// plane area is dead by then, and large enough), runs the heat-bath sweep of schwinger_sweep_kernel<true, ., 64, 32, true>
-// on it -- same regions (the pruned last-sweep form), same cells, same Philox words, same arithmetic: bit-identical
-// results -- sums the QoI and writes the tile out.  One round trip instead of two, and the two workgroups of a CU are in
-// different phases most of the time: the loads of one run under the sampler arithmetic of the other.
-// Step-envelope sampler only (2 beta <= kVsKappaMax); lattices of at least 128 x 128 that 64 x 64 tiles divide.
-template <int K>
-struct OrHeatGeom {
-  using G = OrBlockGeom<K + 1>;
-  static constexpr int NT = G::NT, HB = 2, IW = G::TW + 2 * HB, IH = G::TH + 2 * HB;
-  static constexpr size_t image_bytes = (size_t)2 * IW * IH * sizeof(double);
-  // in front of the image: the sampler's tables and the list of open cells -- a colour phase leaves about 5 % of its ~2200
-  // cells on it at beta = 1 (110 entries on average; a list that overflows leaves cells to their own lanes, measured at
-  // +20 % on the launch with 64 entries)
-  static constexpr uint32_t pool_cap = 256, hb_pool_cap = 128;   // step-envelope list; wrapped-Cauchy pool (24 B per entry)
-  static constexpr size_t pool_bytes_of(size_t a, size_t b) { return ((a > b ? a : b) + 15) / 16 * 16; }
-  static constexpr size_t pool_bytes = pool_bytes_of(VsPool<uint32_t>::bytes(pool_cap), HbPool::bytes(hb_pool_cap));
-  static constexpr size_t hb_bytes = image_bytes + pool_bytes;
-  static_assert(hb_bytes <= OrBlockGeom<6>::lds_bytes, "two workgroups per CU");
-  static constexpr size_t lds_bytes = G::lds_bytes > hb_bytes ? G::lds_bytes : hb_bytes;
-};
-
-// WIDE: 1024 threads per workgroup, for launches with at most one workgroup per CU (few chains): the register-block part
-// runs on the first OrHeatGeom<K>::NT threads as before, the heat-bath part on all sixteen waves.
-// STEP = false (r04): the heat-bath part draws from the wrapped-Cauchy envelope (heatbath_region, as
-// schwinger_sweep_kernel<true, ., 64, 32, false> does): actions beyond 2 beta = 4 get the fused launch too.
-template <int K, bool WIDE = false, bool STEP = true>
-__global__ void __launch_bounds__(WIDE ? 1024 : OrHeatGeom<K>::NT, 4)
-    schwinger_or_heat_kernel(uint32_t Mt, uint32_t Mx, double beta, const double2 *__restrict__ in, double2 *__restrict__ out,
-                             uint32_t tiles_x, RngKey key0, int qoi_op, double *__restrict__ qoi_partial,
-                             const uint32_t *__restrict__ vs_table) {
-  using OH = OrHeatGeom<K>;
-  using G = typename OH::G;
-  constexpr int NT = WIDE ? 1024 : OH::NT, TW = G::TW, TH = G::TH, PW = G::PW, PH = G::PH, H = G::H, NPX = G::NPX, NP = G::NP;
-  constexpr int HB = OH::HB, IW = OH::IW, IH = OH::IH, O = H - HB;  // image (0, 0) = buffer (O, O)
-  extern __shared__ double lds[];
-  __shared__ double qoi_red[NT / kWave];
-  const uint32_t tile = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-  const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
-  const uint32_t i0 = tx * TW, j0 = ty * TH;
-  double t0[PH][PW], t1[PH][PW];
-  MLMCPI_STAMP(0);
-  MLMCPI_STAMP_WHERE();
-  MLMCPI_SKEW_START();
-  or_block_sweeps<G, K>(lds, in + (size_t)b * Mt * Mx, Mt, Mx, i0, j0, t0, t1);
-  MLMCPI_STAMP(3);  // K sweeps done
-
-  // The sampler's tables, round counters and retry pool at the START of the LDS (their addresses are then instruction
-  // offsets: a table look-up costs no address arithmetic beyond its index), the image behind them: theta_0 and theta_1
-  // planes of IH x IW vertices; every block that reaches into it puts its part down
-  VsPool<uint32_t> vpool = VsPool<uint32_t>::carve(lds, OH::pool_cap, STEP ? vs_table : nullptr);
-  HbPool hpool = HbPool::carve(lds, STEP ? 0u : OH::hb_pool_cap);
-  double *th0 = lds + OH::pool_bytes / sizeof(double), *th1 = th0 + IW * IH;
-  if (tid < NP) {
-    const int pj = (int)tid / NPX, pi = (int)tid - pj * NPX;
-#pragma unroll
-    for (int c = 0; c < PH; ++c) {
-      const int r = PH * pj + c - O;
-      if (r < 0 || r >= IH) continue;
-#pragma unroll
-      for (int a = 0; a < PW; ++a) {
-        const int q = PW * pi + a - O;
-        if (q >= 0 && q < IW) {
-          th0[r * IW + q] = t0[c][a];
-          th1[r * IW + q] = t1[c][a];
-        }
-      }
-    }
-  }
-  __syncthreads();
-  MLMCPI_STAMP(4);  // image down
-
+// The tail shared by schwinger_or_heat_kernel and schwinger_perm_heat_kernel: the heat-bath sweep on the LDS image of a
+// 64 x 64 tile and its two rings (theta_0 plane th0, theta_1 plane th1, IW = IH = 68), the optional QoI, the write-out.
+template <int NT, bool STEP>
+__device__ __forceinline__ void schwinger_image_heat(double *th0, double *th1, VsPool<uint32_t> &vpool, HbPool &hpool, uint32_t Mt,
+                                                     uint32_t Mx, double beta, double2 *__restrict__ out, uint32_t i0, uint32_t j0,
+                                                     uint32_t b, uint32_t tile, RngKey key0, int qoi_op,
+                                                     double *__restrict__ qoi_partial, double *qoi_red) {
+  constexpr int TW = 64, TH = 64, HB = 2, IW = TW + 2 * HB;
   // the heat-bath sweep: the last-sweep regions of schwinger_sweep_kernel with H = HB, bw = IW, oh = TH, ow = TW
   constexpr uint32_t bw = IW;
   const uint32_t sc = i0 >= (uint32_t)HB ? i0 - HB : i0 + Mt - HB;  // lattice column of image column 0
@@ -986,9 +917,475 @@ __global__ void __launch_bounds__(WIDE ? 1024 : OrHeatGeom<K>::NT, 4)
   });
   if (qoi_op) {
     block_sum<1>(acc, qoi_red);
-    if (threadIdx.x == 0) qoi_partial[(size_t)b * gridDim.x + blockIdx.x] = acc[0];
+    if (threadIdx.x == 0) qoi_partial[(size_t)b * gridDim.x + tile] = acc[0];
   }
   MLMCPI_STAMP(9);
+}
+
+// ---- Schwinger: K overrelaxation sweeps and the heat-bath sweep behind them in one launch ------------------------------
+// A draw ends "... K overrelaxation sweeps, heat bath, QoI".  As two launches the state makes two round trips through HBM,
+// and the two kernels leave opposite halves of the CU idle: the overrelaxation launch is bound by its load / store phases
+// and the latencies of its colour phases (vector issue 0.44), the heat bath by vector issue (0.88) with its memory
+// traffic hidden.  Here the workgroup that has just swept a tile K times in registers (or_block_sweeps on the geometry
+// with halo 2K + 2, i.e. OrBlockGeom<K + 1>) lays the tile and the two rings the heat bath reads down as an LDS image (the
+// plane area is dead by then, and large enough), runs the heat-bath sweep of schwinger_sweep_kernel<true, ., 64, 32, true>
+// on it -- same regions (the pruned last-sweep form), same cells, same Philox words, same arithmetic: bit-identical
+// results -- sums the QoI and writes the tile out.  One round trip instead of two, and the two workgroups of a CU are in
+// different phases most of the time: the loads of one run under the sampler arithmetic of the other.
+// Step-envelope sampler only (2 beta <= kVsKappaMax); lattices of at least 128 x 128 that 64 x 64 tiles divide.
+template <int K>
+struct OrHeatGeom {
+  using G = OrBlockGeom<K + 1>;
+  static constexpr int NT = G::NT, HB = 2, IW = G::TW + 2 * HB, IH = G::TH + 2 * HB;
+  static constexpr size_t image_bytes = (size_t)2 * IW * IH * sizeof(double);
+  // in front of the image: the sampler's tables and the list of open cells -- a colour phase leaves about 5 % of its ~2200
+  // cells on it at beta = 1 (110 entries on average; a list that overflows leaves cells to their own lanes, measured at
+  // +20 % on the launch with 64 entries)
+  static constexpr uint32_t pool_cap = 256, hb_pool_cap = 128;   // step-envelope list; wrapped-Cauchy pool (24 B per entry)
+  static constexpr size_t pool_bytes_of(size_t a, size_t b) { return ((a > b ? a : b) + 15) / 16 * 16; }
+  static constexpr size_t pool_bytes = pool_bytes_of(VsPool<uint32_t>::bytes(pool_cap), HbPool::bytes(hb_pool_cap));
+  static constexpr size_t hb_bytes = image_bytes + pool_bytes;
+  static_assert(hb_bytes <= OrBlockGeom<6>::lds_bytes, "two workgroups per CU");
+  static constexpr size_t lds_bytes = G::lds_bytes > hb_bytes ? G::lds_bytes : hb_bytes;
+};
+
+// WIDE: 1024 threads per workgroup, for launches with at most one workgroup per CU (few chains): the register-block part
+// runs on the first OrHeatGeom<K>::NT threads as before, the heat-bath part on all sixteen waves.
+// STEP = false (r04): the heat-bath part draws from the wrapped-Cauchy envelope (heatbath_region, as
+// schwinger_sweep_kernel<true, ., 64, 32, false> does): actions beyond 2 beta = 4 get the fused launch too.
+template <int K, bool WIDE = false, bool STEP = true>
+__global__ void __launch_bounds__(WIDE ? 1024 : OrHeatGeom<K>::NT, 4)
+    schwinger_or_heat_kernel(uint32_t Mt, uint32_t Mx, double beta, const double2 *__restrict__ in, double2 *__restrict__ out,
+                             uint32_t tiles_x, RngKey key0, int qoi_op, double *__restrict__ qoi_partial,
+                             const uint32_t *__restrict__ vs_table) {
+  using OH = OrHeatGeom<K>;
+  using G = typename OH::G;
+  constexpr int NT = WIDE ? 1024 : OH::NT, TW = G::TW, TH = G::TH, PW = G::PW, PH = G::PH, H = G::H, NPX = G::NPX, NP = G::NP;
+  constexpr int HB = OH::HB, IW = OH::IW, IH = OH::IH, O = H - HB;  // image (0, 0) = buffer (O, O)
+  extern __shared__ double lds[];
+  __shared__ double qoi_red[NT / kWave];
+  const uint32_t tile = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
+  const uint32_t i0 = tx * TW, j0 = ty * TH;
+  double t0[PH][PW], t1[PH][PW];
+  MLMCPI_STAMP(0);
+  MLMCPI_STAMP_WHERE();
+  MLMCPI_SKEW_START();
+  or_block_sweeps<G, K>(lds, in + (size_t)b * Mt * Mx, Mt, Mx, i0, j0, t0, t1);
+  MLMCPI_STAMP(3);  // K sweeps done
+
+  // The sampler's tables, round counters and retry pool at the START of the LDS (their addresses are then instruction
+  // offsets: a table look-up costs no address arithmetic beyond its index), the image behind them: theta_0 and theta_1
+  // planes of IH x IW vertices; every block that reaches into it puts its part down
+  VsPool<uint32_t> vpool = VsPool<uint32_t>::carve(lds, OH::pool_cap, STEP ? vs_table : nullptr);
+  HbPool hpool = HbPool::carve(lds, STEP ? 0u : OH::hb_pool_cap);
+  double *th0 = lds + OH::pool_bytes / sizeof(double), *th1 = th0 + IW * IH;
+  if (tid < NP) {
+    const int pj = (int)tid / NPX, pi = (int)tid - pj * NPX;
+#pragma unroll
+    for (int c = 0; c < PH; ++c) {
+      const int r = PH * pj + c - O;
+      if (r < 0 || r >= IH) continue;
+#pragma unroll
+      for (int a = 0; a < PW; ++a) {
+        const int q = PW * pi + a - O;
+        if (q >= 0 && q < IW) {
+          th0[r * IW + q] = t0[c][a];
+          th1[r * IW + q] = t1[c][a];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  MLMCPI_STAMP(4);  // image down
+
+  schwinger_image_heat<NT, STEP>(th0, th1, vpool, hpool, Mt, Mx, beta, out, i0, j0, b, tile, key0, qoi_op, qoi_partial, qoi_red);
+}
+
+// ---- Schwinger overrelaxation in closed form: K sweeps are a fixed permutation of the plaquettes -----------------------
+// With P(i, j) = theta_0(i, j) + theta_1(i+1, j) - theta_0(i, j+1) - theta_1(i, j) the two staple sums of the mu = 0 link at
+// (i, j) are theta - P(i, j) and theta + P(i, j-1) (quenchedschwingeraction.cc:25-43), so its overrelaxation update
+// (quenchedschwingeraction.cc:57-65) is
+//     theta <- theta + P(i, j-1) - P(i, j)   (mod 2 pi),
+// after which P(i, j) and P(i, j-1) have changed places; likewise theta_1(i, j) <- theta_1 + P(i, j) - P(i-1, j) swaps
+// P(i, j) and P(i-1, j).  In the multicolour order of the sweeps here -- (mu = 0, j even), (mu = 0, j odd), (mu = 1, i even),
+// (mu = 1, i odd) -- a colour phase therefore swaps whole rows (columns) of plaquettes pairwise, and one sweep moves the
+// plaquette at an even row (column) index two rows (columns) down and the one at an odd index two up: after s sweeps
+//     P_s(i, j) = P_0(i + 2 s e_i, j + 2 s e_j),   e_x = +1 for even x, -1 for odd x,
+// whatever the field is.  Summing the increments of a link over K sweeps gives (s = 0 .. K - 1)
+//     theta_0(i, j)  +=  sum_s  P_0(i + 2 s e_i, j - 1 - p_j - 2 s)  -  P_0(i + 2 s e_i, j + p_j + 2 s),        p_x = x mod 2,
+//     theta_1(i, j)  +=  sum_s  P_0(i + p_i + 2 s, j + 2 (s + 1) e_j)  -  P_0(i - 1 - p_i - 2 s, j + 2 (s + 1) e_j),
+// the same map as K sweeps of any other overrelaxation kernel here up to the rounding of 4 K additions (measured against
+// them and against the oracle's sweeps: <= 3e-14 at K = 10).  A link costs 2 K LDS reads and 2 K additions instead of
+// 9.3 K fp64 instructions, there is no halo recomputation (only the links that are wanted are computed), no colour
+// phases and no barriers between sweeps; what remains is the halo of 2 K in the plaquettes a workgroup needs.
+// Pairs: the two mu = 0 links of a column at rows (j, j + 1), j even, share their first stream (p_j cancels in it), and so
+// do the two mu = 1 links of a row at columns (i, i + 1), i even, their second: a task is such a pair -- three streams of K
+// plaquettes, two links.  With S, X, X' the sums over the shared stream and the two others (each in the order s = 0, 1, ...),
+//     mu = 0:  theta_0(i, j) += S - X,  theta_0(i, j+1) += S - X';        mu = 1:  theta_1(i, j) += X - S,  theta_1(i+1, j) += X' - S.
+// That order of operations is the definition: a result depends on the field and K only -- not on the tile, the batch, the
+// workgroup size or the kernel (schwinger_perm_kernel == the first part of schwinger_perm_heat_kernel, bit for bit) -- but
+// K sweeps in one launch and the same sweeps in two differ in the last bits.
+//
+// The plane: P_0 over `rows` x W vertices in LDS.  A wave takes 63 columns of a group of rows and walks up: lane l loads
+// the double2 of column 63 cw + l, row by row -- the load of the next row is the theta_0(i, j+1) of this one, and
+// theta_1(i+1, j) comes from lane l + 1 by DPP (lane 63 only serves lane 62): ONE coalesced 16-byte load per plaquette,
+// U + 1 rows in flight per thread.  W + 1 <= Mt and rows + 1 <= Mx are not required: columns and rows wrap as often as
+// needed (a 64 x 64 lattice is its own halo).
+constexpr uint32_t kPermMaxK = 10;  // sweeps per launch
+
+// Workgroups are handed to the 8 XCDs round robin by their linear index; each XCD has its own L2.  Experiment
+// (-DMLMCPI_XCD_MAP): XCD x takes the x-th eighth of the (chain, tile) list instead, so that the workgroups resident on an
+// XCD at any time are neighbouring tiles of one or two chains, whose halos -- 65 % of what a workgroup of the 10-sweep
+// launch loads -- could be L2 hits.
+__device__ __forceinline__ void perm_tile_of_workgroup(uint32_t &tile, uint32_t &b) {
+  tile = blockIdx.x;
+  b = blockIdx.y;
+#ifdef MLMCPI_XCD_MAP   // measured (r04, same-box A/B at 1024 x 1024 x 32 and x 128): no difference
+  const uint32_t total = gridDim.x * gridDim.y;
+  if (total % 8 == 0) {
+    const uint32_t lin = blockIdx.y * gridDim.x + blockIdx.x, id = (lin % 8) * (total / 8) + lin / 8;
+    b = id / gridDim.x;
+    tile = id - b * gridDim.x;
+  }
+#endif
+}
+// where a thread stands in a build: its theta column, its rows [r, rend) of the `rows`, whether it owns a plaquette column
+struct PermBuildPos {
+  uint32_t c, r, rend, row_off, gj;   // row_off = gj Mt: the lattice row of plane row r, in vertices (< 2^32: check_lattice_dims)
+  const double2 *p;                   // src + the lattice column
+  bool active, owns;
+};
+template <int NT>
+__device__ __forceinline__ PermBuildPos perm_build_pos(const double2 *__restrict__ src, uint32_t Mt, uint32_t Mx, uint32_t gi0, uint32_t gj0,
+                                                       uint32_t W, uint32_t rows) {
+  PermBuildPos q;
+  // (the wave index on the scalar side: rows, row offsets and the loop conditions of the build are then scalar too)
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave), lane = threadIdx.x % kWave;
+  const uint32_t nwc = (W + 62) / 63, groups = (NT / kWave) / nwc;   // column waves per row group (W <= 108: at most 2), row groups
+  const uint32_t g = wave / nwc, cw = wave - g * nwc;
+  const uint32_t rpg = (rows + groups - 1) / groups;
+  q.c = 63 * cw + lane;                                                // theta column; the plaquette column of lanes 0 .. 62
+  q.r = g * rpg;
+  q.rend = g < groups ? min(rows, q.r + rpg) : 0;
+  q.active = q.r < q.rend && q.c <= W;   // (not: whole waves, or the lanes beyond theta column W, which nobody reads)
+  q.owns = lane < 63 && q.c < W;
+  q.p = src + wrap_add(gi0, q.c, Mt);
+  q.gj = wrap_add(gj0, q.r, Mx);
+  q.row_off = q.gj * Mt;
+  return q;
+}
+// rows (q.r, min(q.r + U, q.rend)] of the thread's column into nxt[0 .. U); first: row q.r itself into cur
+template <int U>
+__device__ __forceinline__ void perm_rows_load(PermBuildPos &q, uint32_t Mt, uint32_t Mx, bool first, double2 &cur, double2 (&nxt)[U]) {
+  if (!q.active) return;
+  if (first) cur = q.p[q.row_off];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    q.gj = q.gj + 1 == Mx ? 0 : q.gj + 1;
+    q.row_off = q.gj == 0 ? 0 : q.row_off + Mt;
+    if (q.r + u < q.rend) nxt[u] = q.p[q.row_off];
+  }
+}
+// their plaquettes into dst (row 0 of dst = plane row 0 of this build); cur <- the last row, for the next chunk
+template <int U>
+__device__ __forceinline__ void perm_rows_store(PermBuildPos &q, double *dst, uint32_t W, double2 &cur, const double2 (&nxt)[U]) {
+  if (!q.active) return;
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+    if (q.r + u < q.rend) {
+      const double right = wave_rotate_down(cur.y);   // theta_1 of the next column
+      if (q.owns) dst[(q.r + u) * W + q.c] = ((cur.x + right) - nxt[u].x) - cur.y;
+      cur = nxt[u];
+    }
+  q.r += U;
+}
+template <int NT, int U>
+__device__ __forceinline__ void perm_build_rows(double *dst, const double2 *__restrict__ src, uint32_t Mt, uint32_t Mx, uint32_t gi0,
+                                                uint32_t gj0, uint32_t W, uint32_t rows) {
+  PermBuildPos q = perm_build_pos<NT>(src, Mt, Mx, gi0, gj0, W, rows);
+  double2 cur = make_double2(0., 0.);
+  bool first = true;
+  while (__builtin_amdgcn_readfirstlane(q.r) < __builtin_amdgcn_readfirstlane(q.rend)) {   // (uniform per wave)
+    double2 nxt[U];
+    perm_rows_load<U>(q, Mt, Mx, first, cur, nxt);
+    perm_rows_store<U>(q, dst, W, cur, nxt);
+    first = false;
+  }
+}
+
+// K sweeps for the (64 + 2 RING) x (TH + 2 RING) vertices around a 64 x TH tile (RING = 0: the tile; RING = 2: what the heat
+// bath behind the sweeps reads; TH = 32: lattices that 64 x 32 tiles divide and 64 x 64 ones do not), in two halves of
+// HR = TH / 2 + RING rows.  NB = 1: one plane of 2 HR + 4 K rows serves both; NB = 2 (K
+// sweeps reach 2 K rows up and down: beyond K = 7 the whole plane does not fit beside a second workgroup): a plane of
+// HR + 4 K rows; for the second half its upper HR + 4 K - HR rows move down and HR new rows are built on top.
+// Tasks of a half: (HR / 2) x OW column pairs (mu = 0), then HR x (OW / 2) row pairs (mu = 1); thread t takes t, t + NT, ...
+template <int NT, int RING, int TH = 64>
+struct PermGeom {
+  static constexpr int OW = 64 + 2 * RING, HR = TH / 2 + RING, NTASK = HR * OW, NV = (NTASK + NT - 1) / NT;
+  static __host__ __device__ constexpr uint32_t width(uint32_t K) { return OW + 4 * K; }
+  static __host__ __device__ constexpr uint32_t rows(uint32_t K, uint32_t NB) { return (NB == 2 ? HR : 2 * HR) + 4 * K; }
+  static __host__ __device__ constexpr size_t plane_bytes(uint32_t K, uint32_t NB) { return (size_t)width(K) * rows(K, NB) * sizeof(double); }
+};
+
+// Task k of a thread, t = threadIdx.x + k NT: a column pair (mu = 0: rows r, r + 1 of column c; t < NT0) or a row pair
+// (mu = 1: columns c, c + 1 of row r), coordinates inside the half.  Two divisions per thread (PermTasks), then constants.
+template <int NT, int RING, int TH = 64>
+struct PermTasks {
+  using PG = PermGeom<NT, RING, TH>;
+  static constexpr int OW = PG::OW, HR = PG::HR, NT0 = (HR / 2) * OW, OW2 = OW / 2;
+  uint32_t q0, c0, q1, c1;   // threadIdx.x = q0 OW + c0 = q1 OW2 + c1
+  __device__ PermTasks() {
+    q0 = threadIdx.x / OW;
+    c0 = threadIdx.x - q0 * OW;
+    q1 = threadIdx.x / OW2;
+    c1 = threadIdx.x - q1 * OW2;
+  }
+  __device__ __forceinline__ bool valid(int k) const { return threadIdx.x + k * NT < (uint32_t)PG::NTASK; }
+  __device__ __forceinline__ bool is_mu1(int k) const { return threadIdx.x + k * NT >= (uint32_t)NT0; }
+  __device__ __forceinline__ void coords(int k, uint32_t &r, uint32_t &c) const {
+    if (!is_mu1(k)) {   // t = (q0 + dq) OW + c0 + dc
+      const uint32_t dq = (k * NT) / OW, dc = (k * NT) % OW;
+      uint32_t q = q0 + dq, cc = c0 + dc;
+      if (cc >= (uint32_t)OW) { cc -= OW; ++q; }
+      r = 2 * q;
+      c = cc;
+    } else {            // t - NT0 = (q1 + dq) OW2 + c1 + dc, dq possibly negative
+      const int off = k * NT - NT0, dq = off >= 0 ? off / OW2 : -((-off + OW2 - 1) / OW2), dc = off - dq * OW2;   // 0 <= dc < OW2
+      uint32_t q = q1 + (uint32_t)dq, cc = c1 + (uint32_t)dc;
+      if (cc >= (uint32_t)OW2) { cc -= OW2; ++q; }
+      r = q;
+      c = 2 * cc;
+    }
+  }
+};
+
+// res[h][k] = the new angles of the two links of task k of half h
+template <int NT, int RING, int TH = 64>
+__device__ __forceinline__ void perm_sweeps(double *plane, const double2 *__restrict__ src, uint32_t Mt, uint32_t Mx, uint32_t i0,
+                                            uint32_t j0, uint32_t K, uint32_t NB, double2 (&res)[2][PermGeom<NT, RING, TH>::NV]) {
+  using PG = PermGeom<NT, RING, TH>;
+  constexpr int HR = PG::HR, NV = PG::NV;
+  constexpr int U = 10, UB = 9;   // rows in flight per thread: first build (nothing else is live yet), new rows of the second
+  const uint32_t W = PG::width(K), rows = PG::rows(K, NB), H = RING + 2 * K;
+  // lattice coordinates of plane (0, 0) of the first build, and of output vertex (0, 0)
+  const uint32_t gi0 = (i0 + Mt - H % Mt) % Mt, gj0 = (j0 + Mx - H % Mx) % Mx;
+  const uint32_t oi0 = (i0 + Mt - RING) % Mt, oj0 = (j0 + Mx - RING) % Mx;
+  const int wb = 8 * (int)W;   // a plane row in bytes
+  const PermTasks<NT, RING, TH> tasks;
+  // the links of a half as they are now (HR, RING and the tile origins are even: output parity = lattice parity)
+  auto load_theta = [&](int h, double2 (&th)[NV]) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      if (!tasks.valid(k)) continue;
+      uint32_t r, c;
+      tasks.coords(k, r, c);
+      const uint32_t gr = wrap_add(oj0, r + h * HR, Mx), gc = wrap_add(oi0, c, Mt);
+      const double2 *v = src + ((size_t)gr * Mt + gc);
+      if (!tasks.is_mu1(k))
+        th[k] = make_double2(v->x, (gr + 1 == Mx ? v - (size_t)gr * Mt : v + Mt)->x);
+      else
+        th[k] = make_double2(v->y, (gc + 1 == Mt ? v - gc : v + 1)->y);
+    }
+  };
+  // what K sweeps add to them
+  auto gather = [&](int h, double2 (&d)[NV]) {
+    const uint32_t row_off = 2 * K + (NB == 2 ? 0 : h * HR);  // plane row of output row 0 of this half
+    const char *const pb = reinterpret_cast<const char *>(plane);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      if (!tasks.valid(k)) continue;
+      uint32_t r, c;
+      tasks.coords(k, r, c);
+      // byte offsets of the shared stream, of the first of the two others and of the second at s = 0, and their steps per s:
+      //   mu = 0: A_s = P(c + 2 s e_c, r - 1 - 2 s), B_s = P(c + 2 s e_c, r + 2 s), B'_s two rows above;
+      //   mu = 1: D_s = P(c - 1 - 2 s, J_s), J_s = r + 2 (s + 1) e_r, C_s = P(c + 2 s, J_s), C'_s two columns on
+      const int at = ((int)(r + row_off) * (int)W + (int)(c + 2 * K)) * 8;   // the vertex itself
+      int a, x, x2, da, dx;
+      if (!tasks.is_mu1(k)) {
+        const int ec16 = 16 - 32 * (int)(c & 1u);
+        a = at - wb;
+        x = at;
+        x2 = at + 2 * wb;
+        da = ec16 - 2 * wb;
+        dx = ec16 + 2 * wb;
+      } else {
+        const int er2w = 2 * wb - 4 * wb * (int)(r & 1u);
+        a = at + er2w - 8;
+        x = at + er2w;
+        x2 = x + 16;
+        da = er2w - 16;
+        dx = er2w + 16;
+      }
+      double S = 0.0, X = 0.0, X2 = 0.0;
+#pragma unroll 5
+      for (uint32_t s = 0; s < K; ++s) {
+        S += *reinterpret_cast<const double *>(pb + a);
+        X += *reinterpret_cast<const double *>(pb + x);
+        X2 += *reinterpret_cast<const double *>(pb + x2);
+        a += da;
+        x += dx;
+        x2 += dx;
+      }
+      d[k] = tasks.is_mu1(k) ? make_double2(X - S, X2 - S) : make_double2(S - X, S - X2);
+    }
+  };
+  auto finish = [&](const double2 (&th)[NV], double2 (&d)[NV]) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+      if (tasks.valid(k)) d[k] = make_double2(mod_2pi_fast(th[k].x + d[k].x), mod_2pi_fast(th[k].y + d[k].y));
+  };
+
+  perm_build_rows<NT, U>(plane, src, Mt, Mx, gi0, gj0, W, rows);
+  double2 th[NV];
+  if (NB == 1) {
+    // one plane: first half (its angles are in flight across the barrier and the first reads of the plane), second half
+    load_theta(0, th);
+    __syncthreads();
+    MLMCPI_STAMP(1);  // plane built
+    gather(0, res[0]);
+    finish(th, res[0]);
+    MLMCPI_STAMP(2);  // first half gathered
+    load_theta(1, th);
+    gather(1, res[1]);
+    finish(th, res[1]);
+    return;
+  }
+  // NB = 2: the HR new rows of the second plane are loaded while the first half is gathered (at most UB rows per thread:
+  // HR / 4 row groups); the angles of the first half only after it, so that the gather has the registers
+  PermBuildPos qb = perm_build_pos<NT>(src, Mt, Mx, gi0, wrap_add(gj0, rows, Mx), W, HR);
+  double2 curb = make_double2(0., 0.), vb[UB];
+  __syncthreads();
+  MLMCPI_STAMP(1);  // plane built
+  perm_rows_load<UB>(qb, Mt, Mx, true, curb, vb);
+  gather(0, res[0]);
+  MLMCPI_STAMP(2);  // first half gathered
+  // rows [HR, rows) of the plane become rows [0, rows - HR); the HR new rows on top
+  constexpr int NC = (4 * (int)kPermMaxK * (PG::OW + 4 * (int)kPermMaxK) + NT - 1) / NT;   // (rows - HR) W = 4 K W values
+  const uint32_t nkeep = (rows - HR) * W;
+  {
+    double keep[NC];
+    __syncthreads();  // the first half has read its plane
+#pragma unroll
+    for (int q = 0; q < NC; ++q) {
+      const uint32_t idx = threadIdx.x + q * NT;
+      if (idx < nkeep) keep[q] = plane[idx + HR * W];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NC; ++q) {
+      const uint32_t idx = threadIdx.x + q * NT;
+      if (idx < nkeep) plane[idx] = keep[q];
+    }
+  }
+  perm_rows_store<UB>(qb, plane + nkeep, W, curb, vb);
+  load_theta(0, th);
+  double2 th1[NV];
+  load_theta(1, th1);
+  __syncthreads();
+  MLMCPI_STAMP(10);  // second plane built
+  finish(th, res[0]);
+  gather(1, res[1]);
+  finish(th1, res[1]);
+}
+
+// the angles of perm_sweeps into the planes th0, th1 of an OW x 2 HR image (the caller puts barriers around it)
+template <int NT, int RING, int TH = 64>
+__device__ __forceinline__ void perm_store_image(double *th0, double *th1, const double2 (&res)[2][PermGeom<NT, RING, TH>::NV]) {
+  using PG = PermGeom<NT, RING, TH>;
+  constexpr int OW = PG::OW, HR = PG::HR, NV = PG::NV;
+  const PermTasks<NT, RING, TH> tasks;
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      if (!tasks.valid(k)) continue;
+      uint32_t r, c;
+      tasks.coords(k, r, c);
+      const uint32_t o = (r + h * HR) * OW + c;
+      if (!tasks.is_mu1(k)) {
+        th0[o] = res[h][k].x;
+        th0[o + OW] = res[h][k].y;
+      } else {
+        th1[o] = res[h][k].x;
+        th1[o + 1] = res[h][k].y;
+      }
+    }
+}
+
+// K <= kPermMaxK overrelaxation sweeps of a 64 x TH tile per workgroup; lds = perm_lds_bytes<TH>(K, NB)
+constexpr size_t kPermPlaneMax = 80 * 1024;  // two workgroups per CU
+template <int TH>
+__host__ __device__ constexpr size_t perm_lds_bytes(uint32_t K, uint32_t NB) {   // the plane; then the tile's image in its place
+  return PermGeom<512, 0, TH>::plane_bytes(K, NB) > 2 * 64 * TH * sizeof(double) ? PermGeom<512, 0, TH>::plane_bytes(K, NB)
+                                                                                   : 2 * 64 * TH * sizeof(double);
+}
+template <int TH>
+__global__ void __launch_bounds__(512, 4)
+    schwinger_perm_kernel(uint32_t Mt, uint32_t Mx, const double2 *__restrict__ in, double2 *__restrict__ out, uint32_t tiles_x,
+                          uint32_t K, uint32_t NB) {
+  constexpr int NT = 512;
+  using PG = PermGeom<NT, 0, TH>;
+  extern __shared__ double lds[];
+  uint32_t tile, b;
+  perm_tile_of_workgroup(tile, b);
+  const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
+  const uint32_t i0 = tx * 64, j0 = ty * TH;
+  double2 res[2][PG::NV];
+  perm_sweeps<NT, 0, TH>(lds, in + (size_t)b * Mt * Mx, Mt, Mx, i0, j0, K, NB, res);
+  double *th0 = lds, *th1 = lds + 64 * TH;
+  __syncthreads();  // the plane is dead: the image takes its place
+  perm_store_image<NT, 0, TH>(th0, th1, res);
+  __syncthreads();
+  double2 *dst = out + (size_t)b * Mt * Mx;
+#pragma unroll
+  for (int k = 0; k < 64 * TH / NT; ++k) {  // a wave writes a row of the tile
+    const uint32_t v = threadIdx.x + k * NT, r = v / 64, c = v % 64;
+    dst[(size_t)(j0 + r) * Mt + (i0 + c)] = make_double2(th0[v], th1[v]);
+  }
+}
+
+// K overrelaxation sweeps in closed form, then the heat-bath sweep, the QoI and the write-out of schwinger_or_heat_kernel
+// (the same tail, schwinger_image_heat): the whole draw of the reference's sampler (10 + 1 sweeps) is ONE launch with one
+// round trip of the state through HBM.  LDS: tables + list | the plane, then the image in the same place.
+template <int NT, bool STEP>
+struct PermHeatGeom {
+  using PG = PermGeom<NT, 2>;
+  using OH = OrHeatGeom<1>;  // (pool and image sizes do not depend on K)
+  static constexpr size_t lds_bytes(uint32_t K, uint32_t NB) {
+    return OH::pool_bytes + (PG::plane_bytes(K, NB) > OH::image_bytes ? PG::plane_bytes(K, NB) : OH::image_bytes);
+  }
+};
+
+template <int NT, bool STEP>
+__global__ void __launch_bounds__(NT, 4)
+    schwinger_perm_heat_kernel(uint32_t Mt, uint32_t Mx, double beta, const double2 *__restrict__ in, double2 *__restrict__ out,
+                               uint32_t tiles_x, uint32_t K, uint32_t NB, RngKey key0, int qoi_op, double *__restrict__ qoi_partial,
+                               const uint32_t *__restrict__ vs_table) {
+  using PH = PermHeatGeom<NT, STEP>;
+  using PG = typename PH::PG;
+  using OH = typename PH::OH;
+  constexpr int IW = OH::IW, IH = OH::IH;
+  static_assert(PG::OW == IW && 2 * PG::HR == IH, "the closed-form stage fills the heat bath's image");
+  extern __shared__ double lds[];
+  __shared__ double qoi_red[NT / kWave];
+  uint32_t tile, b;
+  perm_tile_of_workgroup(tile, b);
+  const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
+  const uint32_t i0 = tx * 64, j0 = ty * 64;
+  MLMCPI_STAMP(0);
+  MLMCPI_STAMP_WHERE();
+  VsPool<uint32_t> vpool = VsPool<uint32_t>::carve(lds, OH::pool_cap, STEP ? vs_table : nullptr);
+  HbPool hpool = HbPool::carve(lds, STEP ? 0u : OH::hb_pool_cap);
+  double *th0 = lds + OH::pool_bytes / sizeof(double), *th1 = th0 + IW * IH;
+  double2 res[2][PG::NV];
+  perm_sweeps<NT, 2>(th0, in + (size_t)b * Mt * Mx, Mt, Mx, i0, j0, K, NB, res);
+  MLMCPI_STAMP(3);  // K sweeps done
+  __syncthreads();  // the plane is dead: the image takes its place
+  perm_store_image<NT, 2>(th0, th1, res);
+  __syncthreads();
+  MLMCPI_STAMP(4);  // image down
+  schwinger_image_heat<NT, STEP>(th0, th1, vpool, hpool, Mt, Mx, beta, out, i0, j0, b, tile, key0, qoi_op, qoi_partial, qoi_red);
 }
 
 // ---- GFF sweeps --------------------------------------------------------------------------------------
@@ -2042,6 +2439,11 @@ static int init_sweep_kernels() {
 #define MLMCPI_OR_HEAT_ATTR_W(KK) MLMCPI_HIP_TRY(hipFuncSetAttribute((const void *)schwinger_or_heat_kernel<KK, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)OrHeatGeom<KK>::lds_bytes))
   MLMCPI_OR_HEAT_ATTR_W(6); MLMCPI_OR_HEAT_ATTR_W(7); MLMCPI_OR_HEAT_ATTR_W(8); MLMCPI_OR_HEAT_ATTR_W(9); MLMCPI_OR_HEAT_ATTR_W(10);
 #undef MLMCPI_OR_HEAT_ATTR_W
+  MLMCPI_HIP_TRY(hipFuncSetAttribute((const void *)schwinger_perm_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPermPlaneMax));
+  MLMCPI_HIP_TRY(hipFuncSetAttribute((const void *)schwinger_perm_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPermPlaneMax));
+#define MLMCPI_PERM_HEAT_ATTR(NN, SS) MLMCPI_HIP_TRY(hipFuncSetAttribute((const void *)schwinger_perm_heat_kernel<NN, SS>, hipFuncAttributeMaxDynamicSharedMemorySize, NN == 1024 ? 156 * 1024 : (int)OrHeatGeom<1>::hb_bytes))
+  MLMCPI_PERM_HEAT_ATTR(512, true); MLMCPI_PERM_HEAT_ATTR(512, false); MLMCPI_PERM_HEAT_ATTR(1024, true); MLMCPI_PERM_HEAT_ATTR(1024, false);
+#undef MLMCPI_PERM_HEAT_ATTR
   g_lds_attr_set[dev] = true;
   return MLMCPI_OK;
 }
@@ -2134,6 +2536,11 @@ static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, doub
   const bool whole_draw = fuse == 0 && schw && or_blocks && !tune.or_heat_split && tune.or_heat_wide >= 0 && n_heatbath >= 1 &&
                           n_overrelax >= 6 && n_overrelax <= 10 && 2. * act->beta <= kVsKappaMax && act->Mt >= 128 && act->Mx >= 128 &&
                           (uint64_t)(act->Mt / 64) * (act->Mx / 64) * B <= kComputeUnits;
+  // Schwinger overrelaxation in closed form (schwinger_perm_kernel, schwinger_perm_heat_kernel): the default where 64 x 64
+  // tiles divide the lattice; MLMCPI_OR_KERNEL=block|patch|lds select the sweep-by-sweep kernels
+  const bool perm = schw && !tune.or_block && !tune.or_lds && !tune.or_patch && !tune.tile_w && act->Mt % 64 == 0 && act->Mx % 32 == 0;
+  const bool perm64 = perm && act->Mx % 64 == 0;   // 64 x 64 tiles (else 64 x 32: the heat bath is a launch of its own)
+  const uint32_t fuse_arg = fuse;
   if (fuse == 0) fuse = whole_draw ? n_overrelax : (or_blocks || gff_blocks32) ? 6 : 4;
   if (fuse > kMaxFuse) fuse = kMaxFuse;
   hipStream_t st = as_stream(stream);
@@ -2159,6 +2566,61 @@ static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, doub
         const uint32_t launches = (rem + fuse - 1) / fuse;
         n = (rem + launches - 1) / launches;
       }
+    }
+    if (perm && s < n_overrelax) {
+      // as few launches as kPermMaxK (or the caller's `fuse`) allows, of equal depth
+      const uint32_t rem = n_overrelax - s, kmax = fuse_arg ? std::min(fuse_arg, kPermMaxK) : kPermMaxK;
+      const uint32_t launches = (rem + kmax - 1) / kmax, K = (rem + launches - 1) / launches;
+      const dim3 bgrid((act->Mt / 64) * (act->Mx / (perm64 ? 64 : 32)), B);
+      const double2 *in2 = (const double2 *)src;
+      double2 *out2 = (double2 *)dst;
+      if (perm64 && !tune.or_heat_split && s + K == n_overrelax && n_heatbath >= 1 && act->Mt >= 128 && act->Mx >= 128) {
+        // the last overrelaxation launch takes the heat-bath sweep behind it along, and the QoI if that ends the draw
+        const bool step = 2. * act->beta <= kVsKappaMax;   // which sampler: a property of the action (device_common.hpp)
+        const uint32_t *vs_table = nullptr;
+        if (step)
+          if (int rcv = vs_table_device(2. * act->beta, &vs_table)) return rcv;
+        const bool with_qoi = qoi_kind && s + K + 1 == total;
+        void *partial = nullptr;
+        if (with_qoi)
+          if (int rcs = scratch((size_t)B * bgrid.x * sizeof(double), &partial, st)) return rcs;
+        const int op = !with_qoi ? 0 : qoi_kind == 1 ? (int)L_PLAQ : (int)L_CHARGE;
+        const RngKey hkey = make_key(seed, chain0, sweep0 + s + K);
+        // at most one workgroup per CU: sixteen waves (MLMCPI_OR_HEAT=wide|narrow forces)
+        const bool wide = tune.or_heat_wide ? tune.or_heat_wide > 0 : (uint64_t)bgrid.x * B <= kComputeUnits;
+        using PHG = PermHeatGeom<512, true>;
+        // one plane for all 68 rows where it fits: beside a second workgroup (narrow) or in the whole LDS (wide)
+        const size_t lds_max = wide ? (size_t)156 * 1024 : OrHeatGeom<1>::hb_bytes;
+        const uint32_t NB = PHG::lds_bytes(K, 1) <= lds_max ? 1 : 2;
+        const size_t lds = PHG::lds_bytes(K, NB);
+        if (lds > lds_max) return fail(MLMCPI_ERR_INVALID, "closed-form plane of %u sweeps does not fit", K);
+#define MLMCPI_PERM_HEAT(NN, SS) hipLaunchKernelGGL((schwinger_perm_heat_kernel<NN, SS>), bgrid, dim3(NN), lds, st, act->Mt, act->Mx, act->beta, in2, out2, act->Mt / 64, K, NB, hkey, op, (double *)partial, vs_table)
+        if (wide) { if (step) MLMCPI_PERM_HEAT(1024, true); else MLMCPI_PERM_HEAT(1024, false); }
+        else { if (step) MLMCPI_PERM_HEAT(512, true); else MLMCPI_PERM_HEAT(512, false); }
+#undef MLMCPI_PERM_HEAT
+        MLMCPI_LAUNCH_CHECK("schwinger_perm_heat_kernel");
+        if (with_qoi) {
+          hipLaunchKernelGGL(lattice_finish_kernel, dim3((B + 3) / 4), dim3(256), 0, st, (const double *)partial, bgrid.x, B, op,
+                             1.0 / ((double)act->Mx * act->Mt), d_qoi, d_acc);
+          MLMCPI_LAUNCH_CHECK("lattice_finish_kernel");
+        }
+        advance();
+        s += K + 1;
+        continue;
+      }
+      if (perm64) {
+        using PG0 = PermGeom<512, 0, 64>;
+        const uint32_t NB = PG0::plane_bytes(K, 1) <= kPermPlaneMax ? 1 : 2;
+        hipLaunchKernelGGL(schwinger_perm_kernel<64>, bgrid, dim3(512), perm_lds_bytes<64>(K, NB), st, act->Mt, act->Mx, in2, out2, act->Mt / 64, K, NB);
+      } else {
+        using PG0 = PermGeom<512, 0, 32>;
+        const uint32_t NB = PG0::plane_bytes(K, 1) <= kPermPlaneMax ? 1 : 2;
+        hipLaunchKernelGGL(schwinger_perm_kernel<32>, bgrid, dim3(512), perm_lds_bytes<32>(K, NB), st, act->Mt, act->Mx, in2, out2, act->Mt / 64, K, NB);
+      }
+      MLMCPI_LAUNCH_CHECK("schwinger_perm_kernel");
+      advance();
+      s += K;
+      continue;
     }
     SweepGeom g;
     uint32_t kinds = 0;

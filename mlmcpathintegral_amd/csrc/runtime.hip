@@ -91,7 +91,8 @@ bool apply_option(Tuning &t, const char *name, const char *value) {
   if (n == "MLMCPI_OR_KERNEL") {
     t.or_lds = v == "lds";
     t.or_patch = v == "patch";
-    return v.empty() || v == "lds" || v == "patch" || v == "block";
+    t.or_block = v == "block";
+    return v.empty() || v == "lds" || v == "patch" || v == "block" || v == "perm";
   }
   if (n == "MLMCPI_OR_HEAT") {
     t.or_heat_split = v == "split";

@@ -314,7 +314,7 @@ def test_tuning_options_are_checked_by_name_and_value():
     accepted, anything else is MLMCPI_ERR_INVALID with a message -- a typo in a benchmark's environment must not be a
     silent no-op at run time."""
     from mlmcpathintegral_amd import abi
-    good = {"MLMCPI_SWEEP_TILE": ["64x32x256", "128x64x512", ""], "MLMCPI_OR_KERNEL": ["block", "patch", "lds", ""],
+    good = {"MLMCPI_SWEEP_TILE": ["64x32x256", "128x64x512", ""], "MLMCPI_OR_KERNEL": ["block", "patch", "lds", "perm", ""],
             "MLMCPI_OR_THREADS": ["256", "512", "1024", ""], "MLMCPI_OR_HEAT": ["fused", "split", "wide", "narrow", ""]}
     for name, values in good.items():
         for v in values:

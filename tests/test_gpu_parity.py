@@ -573,6 +573,44 @@ def test_lattice_sweeps_match_oracle(gpu_ops, orc, kind, Mt, Mx, kw, B, fuse):
             assert_close(got, xo, tol=1e-11, what=f"sweeps ({n_or},{n_hb}) fuse={fuse}")
 
 
+@pytest.mark.parametrize("Mt,Mx,B,beta", [(64, 64, 2, 1.0), (128, 128, 2, 1.0), (192, 128, 1, 2.0), (128, 256, 2, 3.0),
+                                          (64, 32, 2, 1.0), (192, 96, 1, 1.0)])   # the last two: 64 x 32 tiles
+def test_closed_form_overrelaxation_matches_oracle(gpu_ops, orc, Mt, Mx, B, beta):
+    """schwinger_perm_kernel / schwinger_perm_heat_kernel (K <= 10 overrelaxation sweeps per launch as ONE fixed permutation
+    of the plaquettes; the default where 64 x 64 tiles divide the lattice) at every depth the register-block kernels do not
+    reach -- one plane (K <= 7), two planes (K >= 8), several launches (n_or > 10), with and without the heat bath behind --
+    against the oracle's sweeps, against the closed form in numpy (tests/closed_form.py), and the same draw with the
+    heat bath in a launch of its own, bit for bit."""
+    from mlmcpathintegral_amd import abi
+    from closed_form import angle_diff, schwinger_overrelax_closed_form
+    act, A = make_lattice(orc, "schwinger", Mt, Mx, beta=beta)
+    rng = np.random.default_rng(Mt + Mx)
+    x0 = rng.uniform(-np.pi, np.pi, (B, A.size))
+    sweep = 40
+    for n_or, n_hb in ((7, 0), (8, 0), (9, 0), (10, 0), (10, 1), (8, 1), (13, 1), (23, 0)):
+        xd = dev(x0)
+        gpu_ops.lattice_sweep_draw(act, xd, torch.empty_like(xd), n_or, n_hb, SEED, 3, sweep)
+        got = xd.cpu().numpy()
+        xo = x0.copy()
+        for b in range(B):
+            for s in range(n_or + n_hb):
+                A.dev_sweep(xo[b], s >= n_or, SEED, 3 + b, sweep + s)
+        assert_angles_close(got, xo, tol=HB_TOL[min(n_hb, 2)], what=f"closed form ({n_or},{n_hb})")
+        if n_hb == 0 and n_or <= 10:   # one launch: the numpy statement of the same sums
+            for b in range(B):
+                err = angle_diff(got[b], schwinger_overrelax_closed_form(x0[b], Mt, Mx, n_or)).max()
+                assert err <= 1e-13, f"({n_or},0): device vs numpy closed form {err:.3e}"
+        if n_hb and Mt >= 128 and Mx >= 128:
+            abi.set_option("MLMCPI_OR_HEAT", "split")
+            try:
+                xs = dev(x0)
+                gpu_ops.lattice_sweep_draw(act, xs, torch.empty_like(xs), n_or, n_hb, SEED, 3, sweep)
+            finally:
+                abi.set_option("MLMCPI_OR_HEAT", "")
+            assert torch.equal(xs, xd), f"({n_or},{n_hb}): closed form + heat bath in one launch != two launches"
+        sweep += n_or + n_hb
+
+
 @pytest.mark.parametrize("Mt,Mx,B,beta", [(128, 128, 3, 1.0), (192, 128, 2, 2.0), (256, 128, 2, 0.3), (1024, 1024, 2, 1.0),
                                           # r04: beyond 2 beta = 4 the fused launch draws from the wrapped-Cauchy envelope
                                           (128, 192, 2, 3.0), (256, 256, 2, 40.0)])
@@ -663,7 +701,11 @@ def test_heatbath_retry_pool_with_several_passes_per_phase(gpu_ops, tile):
         act = abi.lattice_action(4, Mt, Mt, beta=beta)
         x = gpu_ops.lattice_initialise(act, 3, SEED, chain0=0)
         want, scratch = x.clone(), torch.empty_like(x)
-        gpu_ops.lattice_sweep_draw(act, want, scratch, 1, 3, SEED, 0, 7, fuse=1)
+        abi.set_option("MLMCPI_OR_KERNEL", "block")   # (the sweep-by-sweep family: the tile option below selects its generic kernels)
+        try:
+            gpu_ops.lattice_sweep_draw(act, want, scratch, 1, 3, SEED, 0, 7, fuse=1)
+        finally:
+            abi.set_option("MLMCPI_OR_KERNEL", "")
         abi.set_option("MLMCPI_SWEEP_TILE", tile)
         try:
             got = x.clone()
@@ -867,9 +909,27 @@ def test_schwinger_1024_properties(gpu_ops, orc, golden):
     S0 = gpu_ops.lattice_evaluate(act, x).cpu().numpy()
     a, b1 = x.clone(), x.clone()
     scratch = torch.empty_like(x)
-    gpu_ops.lattice_sweep_draw(act, a, scratch, 4, 2, SEED, 0, 0, fuse=1)
-    gpu_ops.lattice_sweep_draw(act, b1, scratch, 4, 2, SEED, 0, 0, fuse=3)
-    assert torch.equal(a, b1), "fused and unfused sweeps must agree bit for bit"
+    # The sweep-by-sweep kernels first (MLMCPI_OR_KERNEL=block and the others below): one arithmetic, bit-identical results
+    # whatever the launch plan.  The default -- overrelaxation in closed form -- is compared with them further down.
+    abi.set_option("MLMCPI_OR_KERNEL", "block")
+    try:
+        gpu_ops.lattice_sweep_draw(act, a, scratch, 4, 2, SEED, 0, 0, fuse=1)
+        gpu_ops.lattice_sweep_draw(act, b1, scratch, 4, 2, SEED, 0, 0, fuse=3)
+        assert torch.equal(a, b1), "fused and unfused sweeps must agree bit for bit"
+        # library default of that family (up to 6 overrelaxation sweeps per launch, 4 x 4 register-block kernel)
+        d4 = x.clone()
+        gpu_ops.lattice_sweep_draw(act, d4, scratch, 4, 2, SEED, 0, 0, fuse=0)
+        assert torch.equal(a, d4), "the default fusion depth must not change the result"
+        for n in (5, 6, 10):  # every depth of the 4 x 4 kernel (10 sweeps: 5 + 5) against single-sweep launches
+            u, v = x.clone(), x.clone()
+            gpu_ops.lattice_sweep_draw(act, u, scratch, n, 0, SEED, 0, 0, fuse=1)
+            gpu_ops.lattice_sweep_draw(act, v, scratch, n, 0, SEED, 0, 0, fuse=0)
+            assert torch.equal(u, v), f"{n} overrelaxation sweeps: default launch plan differs from single sweeps"
+        single = x[1:2].clone()
+        gpu_ops.lattice_sweep_draw(act, single, torch.empty_like(single), 4, 2, SEED, 1, 0, fuse=2)
+        assert torch.equal(single[0], a[1]), "a chain's result must not depend on the batch it runs in"
+    finally:
+        abi.set_option("MLMCPI_OR_KERNEL", "")
     # the specialised overrelaxation kernel (compile-time tile geometry) against the generic one
     abi.set_option("MLMCPI_SWEEP_TILE", "64x32x256")
     try:
@@ -878,10 +938,7 @@ def test_schwinger_1024_properties(gpu_ops, orc, golden):
     finally:
         abi.set_option("MLMCPI_SWEEP_TILE", "")
     assert torch.equal(a, gen), "specialised and generic sweep kernels must agree bit for bit"
-    # library default (up to 6 overrelaxation sweeps per launch, 4 x 4 register-block kernel) and the LDS-resident kernel
-    d4 = x.clone()
-    gpu_ops.lattice_sweep_draw(act, d4, scratch, 4, 2, SEED, 0, 0, fuse=0)
-    assert torch.equal(a, d4), "the default fusion depth must not change the result"
+    # the LDS-resident kernel
     abi.set_option("MLMCPI_OR_KERNEL", "lds")
     try:
         lds4 = x.clone()
@@ -896,14 +953,26 @@ def test_schwinger_1024_properties(gpu_ops, orc, golden):
     finally:
         abi.set_option("MLMCPI_OR_KERNEL", "")
     assert torch.equal(a, p4), "4 x 4 and 2 x 2 register-block overrelaxation kernels must agree bit for bit"
-    for n in (5, 6, 10):  # every depth of the 4 x 4 kernel (10 sweeps: 5 + 5) against single-sweep launches
+    # The default: K overrelaxation sweeps in closed form (schwinger_perm_kernel / schwinger_perm_heat_kernel).  The same map
+    # up to the rounding of 4 K additions: to 1e-12 against the sweep-by-sweep kernels for every launch plan (the two
+    # heat-bath sweeps behind take the same decisions); bit for bit among launches of the same depth.
+    plans = {}
+    for fuse in (1, 2, 3, 0):
+        plans[fuse] = x.clone()
+        gpu_ops.lattice_sweep_draw(act, plans[fuse], scratch, 4, 2, SEED, 0, 0, fuse=fuse)
+        assert_angles_close(plans[fuse].cpu().numpy(), a.cpu().numpy(), tol=HB_TOL[0], what=f"closed form, fuse={fuse}")
+    for n in (5, 6, 10, 13):  # one launch (13: 7 + 6) against single-sweep launches of the register-block kernel
         u, v = x.clone(), x.clone()
-        gpu_ops.lattice_sweep_draw(act, u, scratch, n, 0, SEED, 0, 0, fuse=1)
+        abi.set_option("MLMCPI_OR_KERNEL", "block")
+        try:
+            gpu_ops.lattice_sweep_draw(act, u, scratch, n, 0, SEED, 0, 0, fuse=1)
+        finally:
+            abi.set_option("MLMCPI_OR_KERNEL", "")
         gpu_ops.lattice_sweep_draw(act, v, scratch, n, 0, SEED, 0, 0, fuse=0)
-        assert torch.equal(u, v), f"{n} overrelaxation sweeps: default launch plan differs from single sweeps"
+        assert_angles_close(v.cpu().numpy(), u.cpu().numpy(), tol=HB_TOL[0], what=f"closed form, {n} sweeps")
     single = x[1:2].clone()
     gpu_ops.lattice_sweep_draw(act, single, torch.empty_like(single), 4, 2, SEED, 1, 0, fuse=2)
-    assert torch.equal(single[0], a[1]), "a chain's result must not depend on the batch it runs in"
+    assert torch.equal(single[0], plans[2][1]), "a chain's result must not depend on the batch it runs in"
     c = x.clone()
     gpu_ops.lattice_sweep_draw(act, c, scratch, 5, 0, SEED, 0, 0, fuse=2)
     S1 = gpu_ops.lattice_evaluate(act, c).cpu().numpy()

@@ -75,9 +75,9 @@ for w, e in S.items():
             tot_cycles += (im["issue_cycles"] if im else 4.0 * k["SQ_INSTS_VALU"]) * k["calls"]
         short = name.replace("mlmcpi::", "")
         kind = None
-        if "or_heat_kernel" in short:
+        if "or_heat_kernel" in short or "perm_heat_kernel" in short:
             kind = "or_heat"   # K overrelaxation sweeps + the heat-bath sweep in one launch: fuse = K + 1 sweeps
-        elif "or_patch_kernel" in short or "or_block_kernel" in short or "or_kernel" in short or "sweep_kernel<false" in short:
+        elif "or_patch_kernel" in short or "or_block_kernel" in short or "or_kernel" in short or "sweep_kernel<false" in short or "schwinger_perm_kernel" in short:
             kind = "overrelax"
         elif "sweep_kernel<true" in short:
             kind = "heatbath"
@@ -86,9 +86,11 @@ for w, e in S.items():
             fuse = int(short.split("<")[1].split(">")[0].split(",")[0])   # <K> or <K, tile>
         if "or_heat_kernel<" in short:
             fuse = int(short.split("<")[1].split(">")[0].split(",")[0]) + 1   # <K> or <K, wide>
+        if "perm_heat_kernel" in short:
+            fuse = 11   # K is a launch argument: the profiled run is the reference's draw, 10 + 1 sweeps in one launch
         # bench.py's hbm_bound_probes (schwinger, --probes): single launches of the HBM-bound kernels of the path
         if w == "schwinger" and "hbm_bytes_per_launch" in k and any(
-                t in short for t in ("schwinger_or_block_kernel<1>", "schwinger_reduce_band_kernel", "schwinger_force_kernel")):
+                t in short for t in ("schwinger_or_block_kernel<1>", "schwinger_perm_kernel", "schwinger_reduce_band_kernel", "schwinger_force_kernel")):
             out["probes"].append({"workload": w, "size": SIZES[w], "chains": CHAINS[w], "kernel": short,
                                   "hbm_bytes_per_launch": k["hbm_bytes_per_launch"], "read_bytes": k["read_bytes_corrected"],
                                   "write_bytes": k["write_bytes"], "launches": k.get("FETCH_SIZE_launches"), "build": build,
