@@ -18,7 +18,9 @@
  *       Schwinger      theta[b*2*Mt*Mx + 2*Mt*j + 2*i + mu]  (lattice/lattice2d.hh:348-354)
  *   - randomness is counter based: Philox4x32-10 keyed by `seed`, counter =
  *     (site, chain0 + b, step, purpose<<24 | sub).  Results do not depend on grid shape, tile
- *     size, number of fused sweeps or number of GPUs.  The contract is spelled out in DESIGN.md.
+ *     size or number of GPUs, nor on the number of sweeps fused into a launch -- to the last bit,
+ *     except for the Schwinger overrelaxation sweeps, which a launch evaluates as one closed form:
+ *     there the fused depth shows in the last bits (<= 4e-14).  The contract is spelled out in DESIGN.md.
  */
 #ifndef MLMCPI_HIP_H
 #define MLMCPI_HIP_H
@@ -77,10 +79,14 @@ int mlmcpi_copy_h2d(void *d_dst, const void *src, size_t bytes, void *stream);
 int mlmcpi_copy_d2h(void *dst, const void *d_src, size_t bytes, void *stream);
 int mlmcpi_copy_d2d(void *d_dst, const void *d_src, size_t bytes, void *stream);
 int mlmcpi_stream_synchronize(void *stream);
-/* Tuning knobs -- they never change results.  Read from the environment once, at the first use in the process; this call
- * changes one afterwards (value "" or NULL resets it): MLMCPI_SWEEP_TILE=TWxTHxNT (tile and workgroup size of the generic
- * sweep kernels; also forces them), MLMCPI_OR_KERNEL=lds|patch (LDS-resident or register-tiled overrelaxation kernels),
- * MLMCPI_OR_THREADS=256|512|1024 (workgroup size of the LDS-resident kernel). */
+/* Tuning knobs -- they change no result beyond the last bits.  Read from the environment once, at the first use in the
+ * process; this call changes one afterwards (value "" or NULL resets it): MLMCPI_SWEEP_TILE=TWxTHxNT (tile and workgroup
+ * size of the generic sweep kernels; also forces them), MLMCPI_OR_KERNEL=perm|block|lds|patch (Schwinger overrelaxation in
+ * closed form -- the default where 64 x 64 or 64 x 32 tiles divide the lattice -- or sweep by sweep on 4 x 4 register
+ * blocks, LDS resident, 2 x 2 register patches; the sweep-by-sweep kernels agree with each other bit for bit and with the
+ * closed form to 4e-14), MLMCPI_OR_THREADS=256|512|1024 (workgroup size of the LDS-resident kernel), MLMCPI_OR_HEAT=
+ * fused|split|wide|narrow (the heat-bath sweep behind the last overrelaxation launch: in it or in a launch of its own;
+ * workgroup size of the fused launch). */
 int mlmcpi_set_option(const char *name, const char *value);
 
 /* ---- index maps (host, integer, bit-exact) --------------------------------------------------
@@ -224,10 +230,10 @@ int mlmcpi_lattice_initialise(const mlmcpi_lattice_action *act, double *d_phi, u
  * distribution/expcosdistribution.hh:51-65), multicolour order (GFF: (i+j) even, odd; Schwinger:
  * mu=0 & j even, mu=0 & j odd, mu=1 & i even, mu=1 & i odd).  Mt and Mx must be even.  Sweep s
  * uses Philox step sweep0 + s.  d_phi is updated in place; d_scratch has the same size.
- * `fuse` = max number of consecutive overrelaxation sweeps fused into one launch (0 = library default: 6, in launches
- * of equal depth, on lattices that 64 x 64 tiles divide, 4 otherwise; heat-bath
- *   sweeps always get a launch of their own);
- * results do not depend on it. */
+ * `fuse` = max number of consecutive overrelaxation sweeps fused into one launch (0 = library default: Schwinger closed
+ * form 10; register-block kernels 6, in launches of equal depth, on lattices that 64 x 64 tiles divide; 4 otherwise.  The
+ * heat-bath sweep behind the last overrelaxation launch rides in it where the fused kernels apply, else it gets a launch
+ * of its own); results do not depend on it beyond the last bits of the Schwinger closed form (see the contract above). */
 int mlmcpi_lattice_sweep_draw(const mlmcpi_lattice_action *act, double *d_phi, double *d_scratch, uint32_t B,
                               uint32_t n_overrelax, uint32_t n_heatbath, uint64_t seed, uint32_t chain0,
                               uint32_t sweep0, uint32_t fuse, void *stream);

@@ -118,13 +118,15 @@ def test_default_line_carries_the_r04_records():
         return
     r = _latest_default_line()
     probes = {p["entry_point"]: p for p in r["hbm_bound_probes"]["probes"]}
-    assert len(probes) == 4 and all(0.0 < p["frac_of_hbm_peak"] <= 1.0 for p in probes.values())
+    # (five since the closed form: the single overrelaxation sweep both ways -- the default launch and the register-block one)
+    assert len(probes) == 5 and all(0.0 < p["frac_of_hbm_peak"] <= 1.0 for p in probes.values())
     assert sum(p["reaches_60_percent"] for p in probes.values()) >= 3
     for p in probes.values():
         if p["counter_bytes"] is not None:
             assert p["counter_bytes"] >= 0.95 * p["floor_bytes"]
     cliff = {p["point"]: p for p in r["fast_path_cliff"]}
-    assert len(cliff) >= 6 and all(p["over_headline"] is None or p["over_headline"] > 0.65 for p in cliff.values()), cliff
+    # (0.6: beta = 4 draws from the wrapped-Cauchy envelope, 0.66-0.68 of the headline since the overrelaxation got cheap)
+    assert len(cliff) >= 6 and all(p["over_headline"] is None or p["over_headline"] > 0.6 for p in cliff.values()), cliff
     assert r["roofline"]["bound"] == "valu" and 0.0 < r["roofline"]["frac"] <= 1.0
     assert r["cpu_baseline"]["cores"] == min(r["cpu_baseline"]["cores_available"], r["cpu_baseline"]["cpu_quota"])
 
@@ -157,6 +159,10 @@ def test_overrelaxation_launch_plan_mirrors_the_library():
     assert bench.or_plan(10, 4, False) == [(4, 2), (2, 1)]
     assert bench.or_plan(3, 4, False) == [(3, 1)]
     assert bench.or_plan(0, 6, True) == []
+    # Schwinger overrelaxation in closed form: up to 10 sweeps per launch, launches of equal depth
+    assert bench.or_plan(10, 10, True) == [(10, 1)]
+    assert bench.or_plan(13, 10, True) == [(7, 1), (6, 1)]
+    assert bench.or_plan(23, 10, True) == [(8, 2), (7, 1)]
     for n in range(0, 40):
         for fuse in (1, 2, 4, 6):
             for blocks in (False, True):
