@@ -732,18 +732,24 @@ def main():
             report_sweeps(result, a, W, size, B, world, step_ms, ms)
         elif a.workload == "rotor_sweep":
             launch_ms = ms(events) / a.steps
-            # one read + one write of the state per launch; the heat-bath sweep rides on the last overrelaxation launch when
-            # that holds fewer than 8 sweeps (path_sweep_impl), the QoI on the last launch of the draw
-            split = os.environ.get("MLMCPI_OR_HEAT", "") == "split" or a.n_overrelax % 8 == 0
-            floor = 16.0 * size * B * ((a.n_overrelax + 7) // 8 + (a.n_heatbath if split else max(0, a.n_heatbath - 1)))
+            # one read + one write of the state per launch.  Overrelaxation in closed form (the default; path_sweep_impl): up to
+            # 16 sweeps per launch, and the heat-bath sweep rides on the last of them; sweep by sweep (MLMCPI_OR_KERNEL=block): 8
+            # per launch, the heat bath on the last when that holds fewer than 8.  The QoI rides on the last launch of the draw.
+            closed = os.environ.get("MLMCPI_OR_KERNEL", "") != "block"
+            cap = 16 if closed else 8
+            split = os.environ.get("MLMCPI_OR_HEAT", "") == "split" or (not closed and a.n_overrelax % 8 == 0)
+            floor = 16.0 * size * B * ((a.n_overrelax + cap - 1) // cap + (a.n_heatbath if split else max(0, a.n_heatbath - 1)))
             result["config"] = {"workload": f"rotor M_lat={size}, {a.n_overrelax} overrelaxation + {a.n_heatbath} heat-bath "
                                             "sweeps per step, even/odd order", "chains_per_gpu": B, "chains_total": B * world,
                                 "parallelism": f"chains sharded over {world} GPU(s), no data-path collective"}
             result["roofline"] = register_resident_roofline(
-                "rotor_sweep_kernel<false> + rotor_sweep_kernel<true,true> (all sweeps of a step, QoI and record_sample)", launch_ms, floor,
+                ("rotor_sweep_kernel<true,true> (all sweeps of a step in one launch: overrelaxation in closed form, heat bath, QoI; "
+                 "record_sample)" if closed and a.n_overrelax <= 16 and not split else
+                 "rotor_sweep_kernel<false> + rotor_sweep_kernel<true,true> (all sweeps of a step, QoI and record_sample)"), launch_ms, floor,
                 16.0 * units_per_step, pmc_entry("kernels_valu_busy", workload=a.workload, size=size, chains=B),
-                "overrelaxation sweeps are fused 8 per launch on LDS-resident segments; the heat-bath sweep is "
-                "VALU bound (von Mises sampler)")
+                ("the overrelaxation sweeps of a launch are one closed form (a sweep permutes the differences of the path) on "
+                 "LDS-resident segments" if closed else "overrelaxation sweeps are fused 8 per launch on LDS-resident segments")
+                + "; the heat-bath sweep is VALU bound (von Mises sampler)")
         elif a.workload == "quartic_mlmc":
             result["scaling"] = "strong"
             result["config"] = {"workload": f"quartic MLMC, 5 levels, finest M_lat={size}, a=0.125, nt={a.nt}, one Y sample per "

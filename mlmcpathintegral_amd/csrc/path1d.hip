@@ -502,7 +502,7 @@ template <bool HEAT, bool STEP = false>
 __global__ void __launch_bounds__(256, HEAT && STEP ? MLMCPI_ROTOR_WAVES : 1)
     rotor_sweep_kernel(PathP P, const double *__restrict__ in, double *__restrict__ out, uint32_t owned_len,
                        uint32_t nsweeps, uint32_t kinds, RngKey key0, uint32_t pool_cap, const uint32_t *__restrict__ vs_table,
-                       double *__restrict__ winding_partial = nullptr) {
+                       double *__restrict__ winding_partial = nullptr, uint32_t n_closed = 0) {
   extern __shared__ double lds_all[];
   __shared__ double qoi_red[4];
   // winding_partial != NULL: the segment's share of sum_j mod_2pi(x_j - x_{j-1}) (qoi/qm/qoisusceptibility.cc:8-23) of the
@@ -526,7 +526,66 @@ __global__ void __launch_bounds__(256, HEAT && STEP ? MLMCPI_ROTOR_WAVES : 1)
   }
   __syncthreads();
   const double sig_scale = 2.0 * P.m0 / P.a;  // W'' = (2 m0 / a) |cos((x+ - x-)/2)|
-  for (uint32_t s = 0; s < nsweeps; ++s) {
+  // The first n_closed sweeps of the launch -- overrelaxation sweeps -- in closed form.  The update x_j <- x_{j-1} + x_{j+1} - x_j
+  // (rotoraction.cc:40-56) adds d_j - d_{j-1} to x_j, d_j = x_{j+1} - x_j, and leaves the two differences exchanged; in
+  // even / odd order a sweep moves the difference at an even index two down and the one at an odd index two up, whatever
+  // the path is, so K sweeps add to the pair of sites (j, j + 1), j = 2 p even,
+  //     x_j     += X - S,     S = sum_{s<K} d(j - 1 - 2 s) = sum_s do[p - 1 - s],    X  = sum_{s<K} d(j + 2 s) = sum_s de[p + s],
+  //     x_{j+1} += X' - S,                                                           X' = X - de[p] + de[p + K]
+  // with the differences of the path the launch started from, split by parity (de[i] = d(2 i), do[i] = d(2 i + 1): every
+  // sum is a run of consecutive LDS words, consecutive lanes read consecutive words).  The same map as K sweeps to the
+  // rounding of 2 K additions (the 2-D counterpart: lattice2d.hip, schwinger_perm_kernel); exact where the sweeps are
+  // (buffer sites [2 K, L - 2 K)), the edge sites keep their values as they do under the sweeps' creeping halo.
+  if (n_closed) {
+    const uint32_t H2 = L / 2, K = n_closed;   // L is even (owned lengths, halos and M are) and at most 2048: <= 4 pairs per thread
+    double xa[4], xb[4], dev[4], dov[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const uint32_t p = threadIdx.x + 256 * m;
+      if (p < H2) {
+        xa[m] = buf[2 * p];
+        xb[m] = buf[2 * p + 1];
+        dev[m] = xb[m] - xa[m];
+        dov[m] = (2 * p + 2 < L ? buf[2 * p + 2] : xb[m]) - xb[m];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const uint32_t p = threadIdx.x + 256 * m;
+      if (p < H2) {
+        buf[p] = dev[m];
+        buf[H2 + p] = dov[m];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const uint32_t p = threadIdx.x + 256 * m;
+      if (p >= K && p + K < H2) {
+        double S = 0.0, X = 0.0;
+        const double *od = buf + H2 + p - 1, *ev = buf + p;
+        for (uint32_t q = 0; q < K; ++q) {
+          S += od[-(int)q];
+          X += ev[q];
+        }
+        const double X2 = (X - ev[0]) + ev[K];
+        xa[m] = mod_2pi_fast(xa[m] + (X - S));
+        xb[m] = mod_2pi_fast(xb[m] + (X2 - S));
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const uint32_t p = threadIdx.x + 256 * m;
+      if (p < H2) {
+        buf[2 * p] = xa[m];
+        buf[2 * p + 1] = xb[m];
+      }
+    }
+    __syncthreads();
+  }
+  for (uint32_t s = n_closed; s < nsweeps; ++s) {
     const bool heat = HEAT && ((kinds >> s) & 1u);
     RngKey skey = key;
     skey.step += s;
@@ -958,18 +1017,22 @@ static int path_sweep_impl(const mlmcpi_path_action *act, double *d_x, double *d
   PathP P = make_params(*act);
   hipStream_t st = as_stream(stream);
   const uint32_t total = n_overrelax + n_heatbath;
-  const bool split_heat = tuning().or_heat_split;
+  const Tuning tune = tuning();
+  const bool split_heat = tune.or_heat_split, closed = !tune.or_block;
   double *src = d_x, *dst = d_w0;
   uint32_t s = 0;
   while (s < total) {
     // overrelaxation sweeps (they come first, sampler order) are fused up to 8 per launch: in one dimension the halo
     // of 2 sites per sweep costs next to nothing; a heat-bath sweep gets a launch of its own (sampler-bound)
-    uint32_t n = 1, kinds = 0;
+    uint32_t n = 1, kinds = 0, n_closed = 0;
     if (s < n_overrelax) {
-      n = n_overrelax - s < 8 ? n_overrelax - s : 8;
+      // overrelaxation in closed form (rotor_sweep_kernel; MLMCPI_OR_KERNEL=block: sweep by sweep): up to 16 sweeps per launch
+      const uint32_t cap = closed ? 16u : 8u;
+      n = n_overrelax - s < cap ? n_overrelax - s : cap;
+      if (closed) n_closed = n;
       // the last overrelaxation launch takes the heat-bath sweep behind it along (one pass over the state less; the sweeps
       // of a launch are numbered on from its key, so the draws are those of two launches: MLMCPI_OR_HEAT=split)
-      if (!split_heat && s + n == n_overrelax && n_heatbath >= 1 && n < 8) {
+      if (!split_heat && s + n == n_overrelax && n_heatbath >= 1 && (n < cap || closed)) {
         kinds = 1u << n;
         ++n;
       }
@@ -996,13 +1059,13 @@ static int path_sweep_impl(const mlmcpi_path_action *act, double *d_x, double *d
       if (int rc = scratch((size_t)B * nseg2 * sizeof(double), &partial, st)) return rc;
     if (kinds && step)
       hipLaunchKernelGGL((rotor_sweep_kernel<true, true>), dim3(nseg2, B), dim3(256), lds + VsPool<uint32_t>::bytes(pool_cap), st, P,
-                         (const double *)src, dst, owned, n, kinds, make_key(seed, chain0, sweep0 + s), pool_cap, vs_table, (double *)partial);
+                         (const double *)src, dst, owned, n, kinds, make_key(seed, chain0, sweep0 + s), pool_cap, vs_table, (double *)partial, n_closed);
     else if (kinds)
       hipLaunchKernelGGL(rotor_sweep_kernel<true>, dim3(nseg2, B), dim3(256), lds + HbPool::bytes(pool_cap), st, P,
-                         (const double *)src, dst, owned, n, kinds, make_key(seed, chain0, sweep0 + s), pool_cap, vs_table, (double *)partial);
+                         (const double *)src, dst, owned, n, kinds, make_key(seed, chain0, sweep0 + s), pool_cap, vs_table, (double *)partial, n_closed);
     else
       hipLaunchKernelGGL(rotor_sweep_kernel<false>, dim3(nseg2, B), dim3(256), lds, st, P, (const double *)src, dst, owned, n,
-                         kinds, make_key(seed, chain0, sweep0 + s), 0u, vs_table, (double *)partial);
+                         kinds, make_key(seed, chain0, sweep0 + s), 0u, vs_table, (double *)partial, n_closed);
     MLMCPI_LAUNCH_CHECK("rotor_sweep_kernel");
     if (with_qoi) {
       hipLaunchKernelGGL(path_finish_kernel, dim3((B + 255) / 256), dim3(256), 0, st, (const double *)partial, nseg2, B,

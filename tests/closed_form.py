@@ -37,6 +37,29 @@ def schwinger_overrelax_closed_form(theta, Mt, Mx, K):
     return out.reshape(-1)
 
 
+def rotor_overrelax_closed_form(x, K):
+    """K even / odd overrelaxation sweeps of the rotor path x (rotoraction.cc:40-56: x_j <- x_{j-1} + x_{j+1} - x_j), as
+    rotor_sweep_kernel computes them (path1d.hip): the update exchanges the differences d_j = x_{j+1} - x_j on either side
+    of the site, a sweep moves the difference at an even index two down and the one at an odd index two up, and with
+    de[i] = d(2 i), do[i] = d(2 i + 1) the pair of sites (2 p, 2 p + 1) receives X - S and X' - S, S = sum_{s<K} do[p - 1 - s],
+    X = sum_{s<K} de[p + s], X' = X - de[p] + de[p + K]."""
+    x = np.asarray(x, dtype=np.float64)
+    M = x.size
+    d = np.roll(x, -1) - x
+    de, do = d[0::2], d[1::2]
+    H = M // 2
+    p = np.arange(H)
+    S = np.zeros(H); X = np.zeros(H)
+    for s in range(K):
+        S = S + do[(p - 1 - s) % H]
+        X = X + de[(p + s) % H]
+    X2 = (X - de[p]) + de[(p + K) % H]
+    out = np.empty_like(x)
+    out[0::2] = mod_2pi(x[0::2] + (X - S))
+    out[1::2] = mod_2pi(x[1::2] + (X2 - S))
+    return out
+
+
 def angle_diff(a, b):
     d = np.asarray(a) - np.asarray(b)
     return np.abs(d - 2 * np.pi * np.round(d / (2 * np.pi)))

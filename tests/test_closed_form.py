@@ -3,7 +3,7 @@ of the oracle's device-order restatement of quenchedschwingeraction.cc:57-65 -- 
 import numpy as np
 import pytest
 
-from closed_form import angle_diff, schwinger_overrelax_closed_form
+from closed_form import angle_diff, rotor_overrelax_closed_form, schwinger_overrelax_closed_form
 
 
 @pytest.mark.parametrize("Mt,Mx", [(2, 2), (4, 6), (16, 16), (64, 32), (130, 70)])
@@ -37,3 +37,18 @@ def test_sweeps_permute_the_plaquettes(orc):
     J, I = np.meshgrid(np.arange(Mx), np.arange(Mt), indexing="ij")
     src = P0[(J + 2 * (1 - 2 * (J & 1))) % Mx, (I + 2 * (1 - 2 * (I & 1))) % Mt]
     assert angle_diff(P1, src).max() <= 1e-13
+
+
+@pytest.mark.parametrize("M", [2, 6, 64, 1000])
+@pytest.mark.parametrize("K", [1, 2, 7, 10, 16])
+def test_rotor_closed_form_equals_k_even_odd_sweeps(orc, M, K):
+    """the 1-D counterpart (rotor_sweep_kernel): K even / odd overrelaxation sweeps of rotoraction.cc:40-56 permute the
+    differences of the path"""
+    A = orc.Action(orc.ROTOR, M=M, T_final=M / 8.0, m0=0.25)
+    rng = np.random.default_rng(M + K)
+    x0 = rng.uniform(-np.pi, np.pi, M)
+    want = x0.copy()
+    for s in range(K):
+        A.dev_sweep(want, False, 7, 0, s)
+    err = angle_diff(rotor_overrelax_closed_form(x0, K), want).max()
+    assert err <= 4e-15 * (2 * K + 2) * 8, f"M = {M}, K = {K}: {err:.3e}"

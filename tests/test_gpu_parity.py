@@ -396,15 +396,31 @@ def test_rotor_sweeps_match_oracle(gpu_ops, orc, M, B):
     xd, scratch = dev(x0), torch.empty((B, M), dtype=torch.float64, device="cuda")
     xo = x0.copy()
     sweep = 0
-    for n_or, n_hb in ((1, 0), (6, 0), (0, 1), (3, 2), (5, 1)):
+    # (the overrelaxation sweeps of a launch are one closed form, up to 16 per launch: (10, 1) is one launch, (16, 0) the
+    # deepest, (21, 1) two; MLMCPI_OR_KERNEL=block -- sweep by sweep -- is checked against it below)
+    for n_or, n_hb in ((1, 0), (6, 0), (0, 1), (3, 2), (5, 1), (10, 1), (16, 0), (21, 1)):
         xd.copy_(dev(xo))  # every case starts from identical inputs on both sides
+        x0_case = xo.copy()
         gpu_ops.path_sweep_draw(act, xd, scratch, n_or, n_hb, SEED, 7, sweep)
         for b in range(B):
             for s in range(n_or + n_hb):
                 A.dev_sweep(xo[b], s >= n_or, SEED, 7 + b, sweep + s)
-        sweep += n_or + n_hb
         tol = HB_TOL[min(n_hb, 2)]
         assert_angles_close(xd.cpu().numpy(), xo, tol=tol, what=f"rotor sweeps ({n_or},{n_hb})")
+        if n_hb == 0:   # the closed form against the sweep-by-sweep kernel and against its statement in numpy
+            from mlmcpathintegral_amd import abi
+            from closed_form import angle_diff, rotor_overrelax_closed_form
+            abi.set_option("MLMCPI_OR_KERNEL", "block")
+            try:
+                xs = dev(x0_case)
+                gpu_ops.path_sweep_draw(act, xs, scratch, n_or, 0, SEED, 7, sweep)
+            finally:
+                abi.set_option("MLMCPI_OR_KERNEL", "")
+            assert_angles_close(xs.cpu().numpy(), xd.cpu().numpy(), tol=HB_TOL[0], what=f"rotor closed form vs sweeps ({n_or},0)")
+            if n_or <= 16:
+                for b in range(B):
+                    assert angle_diff(xd[b].cpu().numpy(), rotor_overrelax_closed_form(x0_case[b], n_or)).max() <= 1e-13
+        sweep += n_or + n_hb
 
 
 def test_rotor_heat_bath_behind_the_last_overrelaxation_launch(gpu_ops):
