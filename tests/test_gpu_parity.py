@@ -989,6 +989,15 @@ def test_schwinger_1024_properties(gpu_ops, orc, golden):
     single = x[1:2].clone()
     gpu_ops.lattice_sweep_draw(act, single, torch.empty_like(single), 4, 2, SEED, 1, 0, fuse=2)
     assert torch.equal(single[0], plans[2][1]), "a chain's result must not depend on the batch it runs in"
+    # the reference's draw, 10 + 1 sweeps: ONE launch (closed form + heat bath) against the register-block plan (5; 5 + heat bath)
+    one, two = x.clone(), x.clone()
+    gpu_ops.lattice_sweep_draw(act, one, scratch, 10, 1, SEED, 0, 50)
+    abi.set_option("MLMCPI_OR_KERNEL", "block")
+    try:
+        gpu_ops.lattice_sweep_draw(act, two, scratch, 10, 1, SEED, 0, 50)
+    finally:
+        abi.set_option("MLMCPI_OR_KERNEL", "")
+    assert_angles_close(one.cpu().numpy(), two.cpu().numpy(), tol=HB_TOL[1], what="10 + 1 draw: one launch vs the register-block plan")
     c = x.clone()
     gpu_ops.lattice_sweep_draw(act, c, scratch, 5, 0, SEED, 0, 0, fuse=2)
     S1 = gpu_ops.lattice_evaluate(act, c).cpu().numpy()
