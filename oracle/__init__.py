@@ -86,6 +86,12 @@ _SIGS = {
     "orc_gaussfill_dev_draw": (None, [_d, _dp, _u64, _u32, _u32, _u32, _dp]),
     "orc_expcos_pdf": (_d, [_d, _d, _d, _d]),
     "orc_i0_scaled": (_d, [_d]),
+    "orc_expsin2_pdf": (_d, [_d, _d]),
+    "orc_bessel_product_pdf": (_d, [_d, _d, _d, _d]),
+    "orc_approx_bessel_pdf": (_d, [_d, _d, _d, _d]),
+    "orc_approx_bessel_params": (None, [_d, _d, _dp]),
+    "orc_schwinger_plaquettes": (None, [_vp, _dp, _dp]),
+    "orc_bessel_product_ref_draws": (None, [_u64, _d, _d, _d, _u32, _u32, _dp]),
     "orc_ho_cholesky": (_i, [_vp, _dp]),
     "orc_dev_exact_draw": (None, [_vp, _dp, _dp, _u64, _u32, _u32]),
     "orc_dev_gff_exact_draw": (None, [_vp, _dp, _u64, _u32, _u32]),

@@ -1994,6 +1994,82 @@ void orc_gaussfill_dev_draw(double beta, const double *phi4, uint64_t seed, uint
 double orc_expcos_pdf(double beta, double x, double x_p, double x_m) { return expcos_pdf(beta, x, x_p, x_m); }
 double orc_i0_scaled(double z) { return fast_bessel_i0_scaled(z); }
 
+// ---- densities and reference-order draws for the reference-held pins (tests/golden/schwinger_ref_python.json) ------
+// distribution/expsin2distribution.cc:7-24 (evaluate; fast_2pi_I0_scaled with its own large-argument branch)
+double orc_expsin2_pdf(double x, double sigma) {
+  const double z = 0.5 * sigma;
+  double norm;
+  if (z > 100.) {
+    const double zi = 1. / z;
+    norm = std::sqrt(2. * kPi * zi) * (1. + 0.125 * zi + 0.0703125 * zi * zi);
+  } else {
+    norm = 2. * kPi * std::exp(-z) * std::cyl_bessel_i(0.0, z);
+  }
+  const double s = std::sin(0.5 * x);
+  return std::exp(-sigma * s * s) / norm;
+}
+// distribution/besselproductdistribution.cc:7-12 (evaluate)
+double orc_bessel_product_pdf(double beta, double x, double x_p, double x_m) {
+  BesselProductO bp(beta);
+  return bp.Znorm_inv(x_p - x_m, false) * bessel_i0(2 * beta * std::cos(0.5 * (x - x_p))) *
+         bessel_i0(2 * beta * std::cos(0.5 * (x - x_m)));
+}
+double orc_approx_bessel_pdf(double beta, double x, double x_p, double x_m) { return approx_bessel_pdf(beta, x, x_p, x_m); }
+// approximatebesselproductdistribution.cc:43-54; x0 already folded into [0, pi]
+void orc_approx_bessel_params(double beta, double x0, double *out3) { approx_bessel_params(beta, x0, out3[0], out3[1], out3[2]); }
+// quenchedschwingeraction.cc:13-17: the raw plaquette angle of every vertex, out[Mt * j + i]
+void orc_schwinger_plaquettes(void *h, const double *x, double *out) {
+  ActionO *A = (ActionO *)h;
+  for (int j = 0; j < A->g.Mx; ++j)
+    for (int i = 0; i < A->g.Mt; ++i) out[A->g.Mt * j + i] = A->plaquette(x, i, j);
+}
+// BesselProductDistribution::draw in reference order (besselproductdistribution.hh:88-152): the distribution objects
+// live in the distribution (mutable members, hh:155-160), the engine is the caller's.  `preroll` draws are taken first
+// with an engine of the same seed, as src/test_distribution.cc does (time_sample draws 10^6 before save_distribution
+// reseeds a fresh engine: the normal distribution's cached second variate survives the reseed).
+void orc_bessel_product_ref_draws(uint64_t seed, double beta, double x_p, double x_m, unsigned preroll, unsigned n, double *out) {
+  BesselProductO bp(beta);
+  std::normal_distribution<double> normal(0.0, 1.0);
+  std::uniform_real_distribution<double> uniform(0.0, 1.0);
+  auto draw = [&](std::mt19937_64 &engine) {
+    double dx = x_m - x_p;
+    const double flip = (dx < 0) ? -1 : +1;
+    dx *= flip;
+    const double N_p = std::erf((kPi - 0.5 * dx) / bp.sigma_beta);
+    const double N_m = std::erf(0.5 * dx / bp.sigma_beta) * std::pow(bp.I0_twobeta, 2. * (dx / kPi - 1.));
+    const double C_p = std::pow(bp.I0_twobeta, 2. * (1. - dx * dx / (4. * kPi * kPi)));
+    const double C_m = std::pow(bp.I0_twobeta, 2. * (1. - (dx - 2. * kPi) * (dx - 2. * kPi) / (4. * kPi * kPi)));
+    const double sigma = bp.sigma_beta / std::sqrt(2.);
+    bool accepted = false;
+    double x = 0.0;
+    while (!accepted) {
+      double xi = uniform(engine);
+      double a_min, a_max, mu, C;
+      if (xi >= N_m / (N_p + N_m)) {
+        a_min = -kPi + dx; a_max = +kPi; mu = 0.5 * dx; C = C_p;
+      } else {
+        a_min = -kPi; a_max = -kPi + dx; mu = 0.5 * (dx - 2. * kPi); C = C_m;
+      }
+      while (!accepted) {
+        x = sigma * normal(engine) + mu;
+        accepted = (x >= a_min) && (x < a_max);
+      }
+      const double I0 = bessel_i0(2. * beta * std::cos(0.5 * x));
+      const double I0_dx = bessel_i0(2. * beta * std::cos(0.5 * (x - dx)));
+      const double xs = (x - mu) / bp.sigma_beta;
+      xi = uniform(engine);
+      accepted = xi <= I0 * I0_dx / C * std::exp(xs * xs);
+    }
+    return wrap_2pi(flip * x + x_p);
+  };
+  if (preroll) {
+    std::mt19937_64 engine(seed);
+    for (unsigned k = 0; k < preroll; ++k) (void)draw(engine);
+  }
+  std::mt19937_64 engine(seed);
+  for (unsigned k = 0; k < n; ++k) out[k] = draw(engine);
+}
+
 // ---- exact sampler of the harmonic oscillator (harmonicoscillatoraction.cc:38-66) ---------------------------------
 // build_covariance: precision matrix Sigma(i,i) = a m0 mu2 + 2 m0/a, Sigma(i,i+-1) = -m0/a (periodic), L = chol(Sigma^-1).
 // The inverse is taken by Gauss-Jordan elimination here (Eigen's .inverse() in the reference), the factor by the

@@ -1,0 +1,336 @@
+"""Pins held by the reference itself: the author's Python restatements of the Schwinger plaquette, link maps, mod_2pi and
+of the heat-bath / fill-in densities (/root/reference/tools/plot_schwinger_configuration.py, plot_distribution.py),
+evaluated by tests/golden/make_schwinger_fixture.py into tests/golden/schwinger_ref_python.json, plus four values of
+reference-binary output printed in that tool's docstring (tests/golden/reference_printed_outputs.json).
+
+CPU: the oracle reproduces them (1e-12; the printed values to their 6 digits).  GPU: the same link fields through
+mlmcpi_lattice_evaluate / force / the two QoIs, and the device samplers' histograms against the reference-held ExpCos /
+ExpSin2 densities."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def pins():
+    with open(os.path.join(HERE, "golden", "schwinger_ref_python.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="module")
+def printed():
+    with open(os.path.join(HERE, "golden", "reference_printed_outputs.json")) as f:
+        return json.load(f)
+
+
+def state_of(case, orc):
+    """the link field of a fixture case in OUR SampleState order (link_cart2lin of the oracle), from Cartesian records"""
+    m = case["m"]
+    L = orc.lib()
+    x = np.zeros(2 * m * m)
+    for i, j, mu, v in case["links"]:
+        x[L.orc_link_cart2lin(m, m, i, j, mu)] = v
+    return x
+
+
+# ---- common/auxilliary.hh:42-44 --------------------------------------------------------------------------------------
+def test_mod_2pi_equals_the_reference_python(orc, pins):
+    L = orc.lib()
+    assert len(pins["mod_2pi"]) == 40
+    for x, y in pins["mod_2pi"]:
+        got = L.orc_mod_2pi(x)
+        assert got == y or abs(got - y) <= 4e-16 * max(1.0, abs(x)), (x, got, y)
+        assert -math.pi <= got < math.pi
+
+
+# ---- lattice/lattice2d.hh:348-375 ------------------------------------------------------------------------------------
+def test_link_maps_equal_the_reference_python(orc, pins):
+    L = orc.lib()
+    import ctypes as C
+    for case in pins["schwinger"]:
+        if case["cart2lin"] is None:
+            continue
+        m = case["m"]
+        for i, j, mu, ell in case["cart2lin"] + case["cart2lin_wrapped"]:
+            assert L.orc_link_cart2lin(m, m, i, j, mu) == ell
+        for ell, i, j, mu in case["lin2cart"]:
+            ci, cj, cm = C.c_int(), C.c_int(), C.c_int()
+            L.orc_link_lin2cart(m, m, ell, C.byref(ci), C.byref(cj), C.byref(cm))
+            assert (ci.value, cj.value, cm.value) == (i, j, mu)
+
+
+def test_link_maps_of_the_compiled_reference_equal_the_reference_python(pins):
+    """oracle/_ref (the reference's own lattice2d.cc, compiled as shipped) against the author's Python: the two
+    reference-held statements of the map agree, so either pins the oracle."""
+    ref = os.path.join(os.path.dirname(HERE), "oracle", "_ref", "libref.so")
+    if not os.path.exists(ref):
+        pytest.skip("oracle/_ref not built (no /root/reference on this machine)")
+    import ctypes as C
+    R = C.CDLL(ref)
+    R.ref_lattice2d_new.restype = C.c_void_p
+    R.ref_lattice2d_new.argtypes = [C.c_uint, C.c_uint, C.c_int, C.c_int]
+    R.ref_lattice2d_free.argtypes = [C.c_void_p]
+    R.ref_link_cart2lin.restype = C.c_uint
+    R.ref_link_cart2lin.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    R.ref_link_lin2cart.argtypes = [C.c_void_p, C.c_uint, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    for case in pins["schwinger"]:
+        if case["cart2lin"] is None:
+            continue
+        m = case["m"]
+        h = R.ref_lattice2d_new(m, m, 0, 0)
+        for i, j, mu, ell in case["cart2lin"] + case["cart2lin_wrapped"]:
+            assert R.ref_link_cart2lin(h, i, j, mu) == ell
+        for ell, i, j, mu in case["lin2cart"]:
+            ci, cj, cm = C.c_int(), C.c_int(), C.c_int()
+            R.ref_link_lin2cart(h, ell, C.byref(ci), C.byref(cj), C.byref(cm))
+            assert (ci.value, cj.value, cm.value) == (i, j, mu)
+        R.ref_lattice2d_free(h)
+
+
+# ---- action/qft/quenchedschwingeraction.cc:7-22, qoi/qft/qoiavgplaquette.cc:8-27, qoi2dsusceptibility.cc:8-27 ----------
+@pytest.mark.parametrize("beta", [1.0, 2.5])
+def test_plaquettes_action_and_qois_equal_the_reference_python(orc, pins, beta):
+    L = orc.lib()
+    for case in pins["schwinger"]:
+        m = case["m"]
+        x = state_of(case, orc)
+        A = orc.Action(orc.SCHWINGER, Mt=m, Mx=m, beta=beta)
+        raw = np.zeros(m * m)
+        L.orc_schwinger_plaquettes(A.h, x, raw)
+        want = np.zeros(m * m)
+        for i, j, p in case["plaquettes"]:
+            want[m * j + i] = p
+        got = np.array([L.orc_mod_2pi(v) for v in raw])
+        # a plaquette that lands within rounding of +-pi may wrap either way: compare on the circle
+        d = got - want
+        d -= 2 * np.pi * np.round(d / (2 * np.pi))
+        assert np.abs(d).max() < 1e-13, (m, case["field"])
+        assert np.abs(np.cos(raw) - np.cos(want)).max() < 1e-13
+        # S = beta sum (1 - cos theta_P); <cos theta_P>; (sum mod_2pi theta_P)^2 / 4 pi^2 -- rebuilt from the stored plaquettes
+        S = beta * np.sum(1.0 - np.cos(want))
+        assert abs(A.evaluate(x) - S) <= 1e-12 * max(1.0, abs(S))
+        assert abs(L.orc_qoi_avg_plaquette(x, m, m) - np.cos(want).mean()) <= 1e-13
+        Q = np.sum(want) / (2 * np.pi)
+        assert abs(Q - round(Q)) < 1e-9  # the charge is an integer on a periodic lattice
+        chi = L.orc_qoi_2d_susceptibility(x, m, m)
+        assert abs(chi - Q * Q) <= 1e-9 * max(1.0, Q * Q)
+
+
+# ---- densities ----------------------------------------------------------------------------------------------------------
+def test_expsin2_density_equals_the_reference_python(orc, pins):
+    L = orc.lib()
+    pts = pins["distributions"]["points"]
+    for rec in pins["distributions"]["expsin2"]:
+        got = np.array([L.orc_expsin2_pdf(x, rec["sigma"]) for x in pts])
+        assert np.abs(got / np.array(rec["pdf"]) - 1.0).max() < 1e-12, rec["sigma"]
+
+
+def test_expcos_density_equals_the_reference_python(orc, pins):
+    L = orc.lib()
+    pts = pins["distributions"]["points"]
+    for rec in pins["distributions"]["expcos"]:
+        got = np.array([L.orc_expcos_pdf(rec["beta"], x, rec["x_p"], rec["x_m"]) for x in pts])
+        assert np.abs(got / np.array(rec["pdf"]) - 1.0).max() < 1e-12, rec
+
+
+def test_bessel_product_density_equals_the_reference_python(orc, pins):
+    """the C++ normalises by its cosine series (besselproductdistribution.hh:44-72), the Python by nested quadrature:
+    agreement to 1e-11 up to beta = 4 (1e-12 is the quadrature's own noise where the density is small); at beta = 8 the two
+    differ by 1e-9: the series is cut at n = 32 (hh:46) and scipy's quad is asked for 1.5e-8"""
+    L = orc.lib()
+    pts = pins["distributions"]["points"]
+    for rec in pins["distributions"]["bessel_product"]:
+        got = np.array([L.orc_bessel_product_pdf(rec["beta"], x, rec["x_p"], rec["x_m"]) for x in pts])
+        ratio = got / np.array(rec["pdf"])
+        assert np.abs(ratio - 1.0).max() < (1e-11 if rec["beta"] <= 4.0 else 2e-9), rec["beta"]
+
+
+def test_bessel_product_density_equals_the_printed_reference_output(orc, printed):
+    L = orc.lib()
+    for x, y in printed["points"]:
+        got = L.orc_bessel_product_pdf(float(printed["beta"]), x, printed["x_p"], float(printed["x_m"]))
+        assert abs(got / y - 1.0) < 2e-5, (x, got, y)  # 6 printed digits of x and of y
+
+
+def test_approximate_bessel_product_density_equals_the_reference_python_comb_by_comb(orc, pins):
+    """The Python and the C++ weigh the two Gaussian combs differently (see make_schwinger_fixture.py); the oracle follows
+    approximatebesselproductdistribution.cc:43-54.  Pinned: the widths, both combs, and the mixture with the C++ weight."""
+    L = orc.lib()
+    pts = pins["distributions"]["points"]
+    for rec in pins["distributions"]["approx_bessel_product"]:
+        par = np.zeros(3)
+        L.orc_approx_bessel_params(rec["beta"], rec["x0"], par)
+        got = np.array([L.orc_approx_bessel_pdf(rec["beta"], x, rec["x_p"], rec["x_m"]) for x in pts])
+        if rec["x0"] < 0.125 * math.pi:
+            # the C++'s small-x0 branch: one comb of inverse width beta (the Python: beta cos(x0 / 4), second weight ~ 0)
+            assert par[0] == 1.0 and par[1] == rec["beta"] and par[2] == 0.0
+            assert abs(rec["sigma2_inv_p"] / rec["beta"] - 1.0) < 0.5 * (0.25 * rec["x0"]) ** 2 * 1.01
+            assert np.abs(got - np.array(rec["pdf_python"])).max() < 2e-3 * max(rec["pdf_python"])
+            continue
+        assert abs(par[1] - rec["sigma2_inv_p"]) < 1e-14 and abs(par[2] - rec["sigma2_inv_m"]) < 1e-14
+        s_p, s_m = par[1], par[2]
+        rho_cxx = (s_p / s_m) ** 1.5 * math.exp(-4.0 * (s_p - s_m))
+        rho_py = (s_m / s_p) ** 1.5 * math.exp(-4.0 * (s_p - s_m))
+        assert abs(par[0] - 1.0 / (1.0 + rho_cxx)) < 1e-15
+        assert abs(rec["N_p_python"] - 1.0 / (1.0 + rho_py)) < 1e-15  # the documented difference, not ours
+        want = par[0] * np.array(rec["comb_p"]) + (1.0 - par[0]) * np.array(rec["comb_m"])
+        assert np.abs(got - want).max() < 1e-13, rec
+    # the weight the oracle follows is the one that matches the exact Bessel product better (a check on the reading)
+    bp = pins["distributions"]["bessel_product"][0]
+    ab = pins["distributions"]["approx_bessel_product"][0]
+    exact = np.array(bp["pdf"])
+    cxx = np.array([L.orc_approx_bessel_pdf(ab["beta"], x, ab["x_p"], ab["x_m"]) for x in pts])
+    assert np.abs(cxx - exact).max() < np.abs(np.array(ab["pdf_python"]) - exact).max()
+
+
+def _bin_probabilities(pdf, pts):
+    """probabilities of the 128 cells between the fixture's 129 points (Simpson with the midpoint by cubic interpolation of
+    the periodic, smooth density is overkill: trapezoid on a 128-point periodic grid is spectrally accurate for the total;
+    per cell the error is O(h^3 f'') ~ 1e-5 relative, far below the sampling error of the tests that use it)"""
+    pdf = np.asarray(pdf)
+    h = pts[1] - pts[0]
+    # cubic (Catmull-Rom on the periodic grid) midpoint value -> Simpson per cell
+    f = pdf[:-1]
+    fm1, f0, f1, f2 = np.roll(f, 1), f, np.roll(f, -1), np.roll(f, -2)
+    mid = (-fm1 + 9 * f0 + 9 * f1 - f2) / 16.0
+    p = h * (f0 + 4 * mid + f1) / 6.0
+    return p
+
+
+@pytest.mark.parametrize("idx", [0, 1, 3])
+def test_reference_order_bessel_product_draws_follow_the_reference_held_density(orc, pins, idx):
+    """BesselProductDistribution::draw restated in reference order (mt19937_64, libstdc++ distributions) against the
+    density the reference's Python holds: chi-square over the fixture's 128 cells."""
+    from scipy import stats
+    L = orc.lib()
+    rec = pins["distributions"]["bessel_product"][idx]
+    pts = np.array(pins["distributions"]["points"])
+    n = 200000
+    out = np.zeros(n)
+    L.orc_bessel_product_ref_draws(241857, rec["beta"], rec["x_p"], rec["x_m"], 0, n, out)
+    p = _bin_probabilities(rec["pdf"], pts)
+    assert abs(p.sum() - 1.0) < 1e-6
+    counts, _ = np.histogram(out, bins=pts)
+    keep = p * n > 5  # merge the empty tail cells
+    chi2 = np.sum((counts[keep] - n * p[keep]) ** 2 / (n * p[keep])) + (counts[~keep].sum() - n * p[~keep].sum()) ** 2 / max(n * p[~keep].sum(), 1e-300) * (p[~keep].sum() * n > 1e-3)
+    dof = keep.sum() - 1 + (1 if (~keep).any() else 0)
+    assert stats.chi2.sf(chi2, dof) > 1e-4, (chi2, dof)
+
+
+@pytest.mark.parametrize("idx", [0, 1, 2, 3])
+def test_reference_and_device_order_expcos_draws_follow_the_reference_held_density(orc, pins, idx):
+    from scipy import stats
+    L = orc.lib()
+    rec = pins["distributions"]["expcos"][idx]
+    pts = np.array(pins["distributions"]["points"])
+    p = _bin_probabilities(rec["pdf"], pts)
+    assert abs(p.sum() - 1.0) < 1e-6
+    n = 100000
+    ref = np.zeros(n)
+    L.orc_expcos_draws(2481317, rec["beta"], rec["x_p"], rec["x_m"], n, ref)
+    dev = np.array([L.orc_dev_expcos_draw(5, 0, 0, k, rec["beta"], rec["x_p"], rec["x_m"]) for k in range(n)])
+    for draws in (ref, dev):
+        counts, _ = np.histogram(draws, bins=pts)
+        assert counts.sum() == n
+        keep = p * n > 5
+        c = np.append(counts[keep], counts[~keep].sum())
+        e = np.append(n * p[keep], n * p[~keep].sum())
+        ok = e > 1e-3
+        chi2 = np.sum((c[ok] - e[ok]) ** 2 / e[ok])
+        assert c[~ok].sum() == 0
+        assert stats.chi2.sf(chi2, ok.sum() - 1) > 1e-4, (idx, chi2, ok.sum())
+
+
+# ======================================================== GPU ==========================================================
+def _chi2_against_cells(draws, p, pts):
+    from scipy import stats
+    n = len(draws)
+    counts, _ = np.histogram(draws, bins=pts)
+    assert counts.sum() == n
+    keep = p * n > 5
+    c = np.append(counts[keep], counts[~keep].sum())
+    e = np.append(n * p[keep], n * p[~keep].sum())
+    ok = e > 1e-3
+    assert c[~ok].sum() == 0
+    chi2 = np.sum((c[ok] - e[ok]) ** 2 / e[ok])
+    return stats.chi2.sf(chi2, ok.sum() - 1), chi2, int(ok.sum() - 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("beta", [1.0, 2.5])
+def test_device_evaluate_force_and_qois_on_the_reference_python_fields(gpu_ops, orc, pins, beta):
+    """mlmcpi_lattice_evaluate, mlmcpi_lattice_force, avg-plaquette and charge QoIs fed with the fixture's link fields,
+    against quantities rebuilt from the plaquettes the reference's Python holds (no oracle arithmetic in between except
+    the link index map, itself pinned above)."""
+    import torch
+    from mlmcpathintegral_amd import abi
+    for m in (4, 6, 16):
+        cases = [c for c in pins["schwinger"] if c["m"] == m]
+        x = np.vstack([state_of(c, orc) for c in cases])
+        xd = torch.tensor(x, dtype=torch.float64, device="cuda")
+        act = abi.lattice_action(4, m, m, beta=beta)
+        S = gpu_ops.lattice_evaluate(act, xd).cpu().numpy()
+        F = gpu_ops.lattice_force(act, xd).cpu().numpy()
+        plaq = gpu_ops.qoi_avg_plaquette(xd, m, m).cpu().numpy()
+        chi = gpu_ops.qoi_2d_susceptibility(xd, m, m).cpu().numpy()
+        L = orc.lib()
+        for b, c in enumerate(cases):
+            P = np.zeros((m, m))  # P[i, j]
+            for i, j, p in c["plaquettes"]:
+                P[i, j] = p
+            assert abs(S[b] - beta * np.sum(1.0 - np.cos(P))) <= 1e-12 * max(1.0, abs(S[b]))
+            assert abs(plaq[b] - np.cos(P).mean()) <= 1e-13
+            Q = np.sum(P) / (2 * np.pi)
+            assert abs(chi[b] - Q * Q) <= 1e-9 * max(1.0, Q * Q)
+            # quenchedschwingeraction.cc:68-89 in gather form: F(i,j,0) = beta (sin P(i,j) - sin P(i,j-1)),
+            # F(i,j,1) = beta (sin P(i-1,j) - sin P(i,j))
+            sinP = np.sin(P)
+            for i in range(m):
+                for j in range(m):
+                    f0 = beta * (sinP[i, j] - sinP[i, (j - 1) % m])
+                    f1 = beta * (sinP[(i - 1) % m, j] - sinP[i, j])
+                    assert abs(F[b, L.orc_link_cart2lin(m, m, i, j, 0)] - f0) < 1e-12
+                    assert abs(F[b, L.orc_link_cart2lin(m, m, i, j, 1)] - f1) < 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("idx", [0, 1, 2, 3])
+def test_device_expcos_draws_follow_the_reference_held_density(gpu_ops, pins, idx):
+    """Both device samplers of the Schwinger heat bath (step envelope where 2 beta <= 4, wrapped Cauchy everywhere) against
+    the ExpCos density of the reference's Python at its own (beta, x_p, x_m): chi-square over the fixture's 128 cells."""
+    import torch
+    rec = pins["distributions"]["expcos"][idx]
+    pts = np.array(pins["distributions"]["points"])
+    p = _bin_probabilities(rec["pdf"], pts)
+    n = 400000
+    x_p = torch.full((n,), rec["x_p"], dtype=torch.float64, device="cuda")
+    x_m = torch.full((n,), rec["x_m"], dtype=torch.float64, device="cuda")
+    draws = gpu_ops.test_expcos(20261005, 2, 9, rec["beta"], x_p, x_m).cpu().numpy()
+    pv, chi2, dof = _chi2_against_cells(draws, p, pts)
+    assert pv > 1e-4, ("wrapped Cauchy", idx, chi2, dof)
+    if 2.0 * rec["beta"] <= 4.0:
+        draws = gpu_ops.test_vs_draw(20261005, 4, 13, 2.0 * rec["beta"], x_p, x_m).cpu().numpy()
+        draws = np.where(draws >= np.pi, draws - 2 * np.pi, draws)
+        pv, chi2, dof = _chi2_against_cells(draws, p, pts)
+        assert pv > 1e-4, ("step envelope", idx, chi2, dof)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("idx", [0, 1, 2])
+def test_device_expsin2_draws_follow_the_reference_held_density(gpu_ops, pins, idx):
+    """the rotor heat bath's sampler against the ExpSin2 density of the reference's Python"""
+    rec = pins["distributions"]["expsin2"][idx]
+    pts = np.array(pins["distributions"]["points"])
+    p = _bin_probabilities(rec["pdf"], pts)
+    import torch
+    n = 400000
+    sig = torch.full((n,), rec["sigma"], dtype=torch.float64, device="cuda")
+    draws = gpu_ops.test_expsin2(20261005, 1, 3, sig).cpu().numpy()
+    draws = np.where(draws >= np.pi, draws - 2 * np.pi, draws)
+    pv, chi2, dof = _chi2_against_cells(draws, p, pts)
+    assert pv > 1e-4, (idx, chi2, dof)
