@@ -1059,15 +1059,36 @@ __device__ __forceinline__ void perm_tile_of_workgroup(uint32_t &tile, uint32_t 
   }
 #endif
 }
+// The plane in LDS.  Every stream of the closed form walks a diagonal of the plaquettes of ONE parity class: column and
+// row parity do not change along it, the column moves by 2 e_c and the row by +-2 per step s.  So the plane is kept as four
+// quadrants by (column parity, row parity), each Rh = rows / 2 rows of Wh = WP / 2 values, with the ODD index mirrored:
+//     column C -> u = C / 2 (C even),  Wh - 1 - (C - 1) / 2 (C odd);      row R -> v = R / 2,  Rh - 1 - (R - 1) / 2 likewise.
+// A step of any stream of any task is then (u, v) -> (u + 1, v + 1): ONE byte stride, kStep, for all of them -- whatever
+// the parities, mu = 0 or 1 -- and with the pitch WP a compile-time constant (the width of the deepest launch, kPermMaxK
+// sweeps; a shallower one leaves columns unused) the K reads of a stream are K immediate offsets from one address.  (The
+// row-major plane this replaces cost 6.6 integer instructions of address arithmetic per read: a third of the launch's
+// vector instructions outside the heat bath.)  Same values, same order of additions: results are bit for bit those of the
+// row-major form.
+template <int WP>
+struct PermPlane {
+  static constexpr int Wh = WP / 2, kRow = Wh * 8, kStep = kRow + 8;   // bytes
+  uint32_t Rh, QB;                                                      // rows per quadrant; bytes per quadrant
+  __device__ __forceinline__ explicit PermPlane(uint32_t rows) : Rh(rows / 2), QB((rows / 2) * (uint32_t)kRow) {}
+  // byte offset of plaquette (C, R) = col(C) + row(R)
+  __device__ __forceinline__ uint32_t col(uint32_t C) const { return (C & 1u) ? QB + (uint32_t)(Wh - 1 - (int)(C >> 1)) * 8u : (C >> 1) * 8u; }
+  __device__ __forceinline__ uint32_t row(uint32_t R) const { return (R & 1u) ? 2u * QB + (Rh - 1u - (R >> 1)) * (uint32_t)kRow : (R >> 1) * (uint32_t)kRow; }
+};
+
 // where a thread stands in a build: its theta column, its rows [r, rend) of the `rows`, whether it owns a plaquette column
 struct PermBuildPos {
-  uint32_t c, r, rend, row_off, gj;   // row_off = gj Mt: the lattice row of plane row r, in vertices (< 2^32: check_lattice_dims)
+  uint32_t c, r, rend, row_off, gj;   // row_off = gj Mt: the lattice row of build row r, in vertices (< 2^32: check_lattice_dims)
+  uint32_t cb;                        // PermPlane::col of the plaquette column
   const double2 *p;                   // src + the lattice column
   bool active, owns;
 };
-template <int NT>
-__device__ __forceinline__ PermBuildPos perm_build_pos(const double2 *__restrict__ src, uint32_t Mt, uint32_t Mx, uint32_t gi0, uint32_t gj0,
-                                                       uint32_t W, uint32_t rows) {
+template <int NT, class PP>
+__device__ __forceinline__ PermBuildPos perm_build_pos(const PP &P, const double2 *__restrict__ src, uint32_t Mt, uint32_t Mx, uint32_t gi0,
+                                                       uint32_t gj0, uint32_t W, uint32_t rows) {
   PermBuildPos q;
   // (the wave index on the scalar side: rows, row offsets and the loop conditions of the build are then scalar too)
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave), lane = threadIdx.x % kWave;
@@ -1079,6 +1100,7 @@ __device__ __forceinline__ PermBuildPos perm_build_pos(const double2 *__restrict
   q.rend = g < groups ? min(rows, q.r + rpg) : 0;
   q.active = q.r < q.rend && q.c <= W;   // (not: whole waves, or the lanes beyond theta column W, which nobody reads)
   q.owns = lane < 63 && q.c < W;
+  q.cb = P.col(q.c);
   q.p = src + wrap_add(gi0, q.c, Mt);
   q.gj = wrap_add(gj0, q.r, Mx);
   q.row_off = q.gj * Mt;
@@ -1096,29 +1118,30 @@ __device__ __forceinline__ void perm_rows_load(PermBuildPos &q, uint32_t Mt, uin
     if (q.r + u < q.rend) nxt[u] = q.p[q.row_off];
   }
 }
-// their plaquettes into dst (row 0 of dst = plane row 0 of this build); cur <- the last row, for the next chunk
-template <int U>
-__device__ __forceinline__ void perm_rows_store(PermBuildPos &q, double *dst, uint32_t W, double2 &cur, const double2 (&nxt)[U]) {
+// their plaquettes into the plane (build row 0 = plane row R0); cur <- the last row, for the next chunk
+template <int U, class PP>
+__device__ __forceinline__ void perm_rows_store(PermBuildPos &q, const PP &P, double *plane, uint32_t R0, double2 &cur, const double2 (&nxt)[U]) {
   if (!q.active) return;
+  char *const pb = reinterpret_cast<char *>(plane) + q.cb;
 #pragma unroll
   for (int u = 0; u < U; ++u)
     if (q.r + u < q.rend) {
       const double right = wave_rotate_down(cur.y);   // theta_1 of the next column
-      if (q.owns) dst[(q.r + u) * W + q.c] = ((cur.x + right) - nxt[u].x) - cur.y;
+      if (q.owns) *reinterpret_cast<double *>(pb + P.row(R0 + q.r + u)) = ((cur.x + right) - nxt[u].x) - cur.y;   // (the row part is scalar)
       cur = nxt[u];
     }
   q.r += U;
 }
-template <int NT, int U>
-__device__ __forceinline__ void perm_build_rows(double *dst, const double2 *__restrict__ src, uint32_t Mt, uint32_t Mx, uint32_t gi0,
-                                                uint32_t gj0, uint32_t W, uint32_t rows) {
-  PermBuildPos q = perm_build_pos<NT>(src, Mt, Mx, gi0, gj0, W, rows);
+template <int NT, int U, class PP>
+__device__ __forceinline__ void perm_build_rows(const PP &P, double *plane, const double2 *__restrict__ src, uint32_t Mt, uint32_t Mx,
+                                                uint32_t gi0, uint32_t gj0, uint32_t W, uint32_t rows) {
+  PermBuildPos q = perm_build_pos<NT>(P, src, Mt, Mx, gi0, gj0, W, rows);
   double2 cur = make_double2(0., 0.);
   bool first = true;
   while (__builtin_amdgcn_readfirstlane(q.r) < __builtin_amdgcn_readfirstlane(q.rend)) {   // (uniform per wave)
     double2 nxt[U];
     perm_rows_load<U>(q, Mt, Mx, first, cur, nxt);
-    perm_rows_store<U>(q, dst, W, cur, nxt);
+    perm_rows_store<U>(q, P, plane, 0u, cur, nxt);
     first = false;
   }
 }
@@ -1126,15 +1149,17 @@ __device__ __forceinline__ void perm_build_rows(double *dst, const double2 *__re
 // K sweeps for the (64 + 2 RING) x (TH + 2 RING) vertices around a 64 x TH tile (RING = 0: the tile; RING = 2: what the heat
 // bath behind the sweeps reads; TH = 32: lattices that 64 x 32 tiles divide and 64 x 64 ones do not), in two halves of
 // HR = TH / 2 + RING rows.  NB = 1: one plane of 2 HR + 4 K rows serves both; NB = 2 (K
-// sweeps reach 2 K rows up and down: beyond K = 7 the whole plane does not fit beside a second workgroup): a plane of
+// sweeps reach 2 K rows up and down: beyond K = 6 the whole plane does not fit beside a second workgroup): a plane of
 // HR + 4 K rows; for the second half its upper HR + 4 K - HR rows move down and HR new rows are built on top.
 // Tasks of a half: (HR / 2) x OW column pairs (mu = 0), then HR x (OW / 2) row pairs (mu = 1); thread t takes t, t + NT, ...
 template <int NT, int RING, int TH = 64>
 struct PermGeom {
   static constexpr int OW = 64 + 2 * RING, HR = TH / 2 + RING, NTASK = HR * OW, NV = (NTASK + NT - 1) / NT;
+  static constexpr int WP = OW + 4 * (int)kPermMaxK;   // the plane's pitch (PermPlane): the width of the deepest launch
+  static_assert(HR % 2 == 0 && OW % 2 == 0, "parities of the output = parities of the lattice; the halves move by whole quadrant rows");
   static __host__ __device__ constexpr uint32_t width(uint32_t K) { return OW + 4 * K; }
   static __host__ __device__ constexpr uint32_t rows(uint32_t K, uint32_t NB) { return (NB == 2 ? HR : 2 * HR) + 4 * K; }
-  static __host__ __device__ constexpr size_t plane_bytes(uint32_t K, uint32_t NB) { return (size_t)width(K) * rows(K, NB) * sizeof(double); }
+  static __host__ __device__ constexpr size_t plane_bytes(uint32_t K, uint32_t NB) { return (size_t)WP * rows(K, NB) * sizeof(double); }
 };
 
 // Task k of a thread, t = threadIdx.x + k NT: a column pair (mu = 0: rows r, r + 1 of column c; t < NT0) or a row pair
@@ -1169,20 +1194,48 @@ struct PermTasks {
   }
 };
 
+// Five steps of the three streams of a task: fifteen 8-byte LDS reads at immediate offsets from three addresses, through
+// inline asm (lds_read_f64: the compiler would pair the reads of a stream into ds_read2_b64, half the rate --
+// MI355X_MICROARCH.md, LDS table), one wait naming all fifteen, then the additions in the order s = 0, 1, ...
+template <int STEP>
+__device__ __forceinline__ void perm_gather5(uint32_t pa, uint32_t px, uint32_t px2, double &S, double &X, double &X2) {
+  double a0 = lds_read_f64<0>(pa), x0 = lds_read_f64<0>(px), y0 = lds_read_f64<0>(px2);
+  double a1 = lds_read_f64<STEP>(pa), x1 = lds_read_f64<STEP>(px), y1 = lds_read_f64<STEP>(px2);
+  double a2 = lds_read_f64<2 * STEP>(pa), x2 = lds_read_f64<2 * STEP>(px), y2 = lds_read_f64<2 * STEP>(px2);
+  double a3 = lds_read_f64<3 * STEP>(pa), x3 = lds_read_f64<3 * STEP>(px), y3 = lds_read_f64<3 * STEP>(px2);
+  double a4 = lds_read_f64<4 * STEP>(pa), x4 = lds_read_f64<4 * STEP>(px), y4 = lds_read_f64<4 * STEP>(px2);
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(a0), "+v"(x0), "+v"(y0), "+v"(a1), "+v"(x1), "+v"(y1), "+v"(a2), "+v"(x2), "+v"(y2), "+v"(a3), "+v"(x3), "+v"(y3),
+                 "+v"(a4), "+v"(x4), "+v"(y4)
+               :
+               : "memory");
+  S += a0; X += x0; X2 += y0;
+  S += a1; X += x1; X2 += y1;
+  S += a2; X += x2; X2 += y2;
+  S += a3; X += x3; X2 += y3;
+  S += a4; X += x4; X2 += y4;
+}
+__device__ __forceinline__ void perm_gather1(uint32_t pa, uint32_t px, uint32_t px2, double &S, double &X, double &X2) {
+  double a0 = lds_read_f64<0>(pa), x0 = lds_read_f64<0>(px), y0 = lds_read_f64<0>(px2);
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(x0), "+v"(y0) : : "memory");
+  S += a0; X += x0; X2 += y0;
+}
+
 // res[h][k] = the new angles of the two links of task k of half h
 template <int NT, int RING, int TH = 64>
 __device__ __forceinline__ void perm_sweeps(double *plane, const double2 *__restrict__ src, uint32_t Mt, uint32_t Mx, uint32_t i0,
                                             uint32_t j0, uint32_t K, uint32_t NB, double2 (&res)[2][PermGeom<NT, RING, TH>::NV]) {
   using PG = PermGeom<NT, RING, TH>;
+  using PP = PermPlane<PG::WP>;
   constexpr int HR = PG::HR, NV = PG::NV;
   constexpr int U = 10, UB = 9;   // rows in flight per thread: first build (nothing else is live yet), new rows of the second
   const uint32_t W = PG::width(K), rows = PG::rows(K, NB), H = RING + 2 * K;
+  const PP P(rows);
   // lattice coordinates of plane (0, 0) of the first build, and of output vertex (0, 0)
   const uint32_t gi0 = (i0 + Mt - H % Mt) % Mt, gj0 = (j0 + Mx - H % Mx) % Mx;
   const uint32_t oi0 = (i0 + Mt - RING) % Mt, oj0 = (j0 + Mx - RING) % Mx;
-  const int wb = 8 * (int)W;   // a plane row in bytes
   const PermTasks<NT, RING, TH> tasks;
-  // the links of a half as they are now (HR, RING and the tile origins are even: output parity = lattice parity)
+  // the links of a half as they are now (HR, RING, 2 K and the tile origins are even: output parity = plane parity = lattice parity)
   auto load_theta = [&](int h, double2 (&th)[NV]) {
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
@@ -1199,42 +1252,45 @@ __device__ __forceinline__ void perm_sweeps(double *plane, const double2 *__rest
   };
   // what K sweeps add to them
   auto gather = [&](int h, double2 (&d)[NV]) {
-    const uint32_t row_off = 2 * K + (NB == 2 ? 0 : h * HR);  // plane row of output row 0 of this half
-    const char *const pb = reinterpret_cast<const char *>(plane);
+    const uint32_t row_off = 2 * K + (NB == 2 ? 0 : h * HR);  // plane row of output row 0 of this half (even)
+    const uint32_t lds0 = (uint32_t)(uintptr_t)plane;   // the LDS byte address of the plane (see schwinger_or_kernel)
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
       if (!tasks.valid(k)) continue;
       uint32_t r, c;
       tasks.coords(k, r, c);
-      // byte offsets of the shared stream, of the first of the two others and of the second at s = 0, and their steps per s:
-      //   mu = 0: A_s = P(c + 2 s e_c, r - 1 - 2 s), B_s = P(c + 2 s e_c, r + 2 s), B'_s two rows above;
-      //   mu = 1: D_s = P(c - 1 - 2 s, J_s), J_s = r + 2 (s + 1) e_r, C_s = P(c + 2 s, J_s), C'_s two columns on
-      const int at = ((int)(r + row_off) * (int)W + (int)(c + 2 * K)) * 8;   // the vertex itself
-      int a, x, x2, da, dx;
+      // the shared stream, the first of the two others and the second, at s = 0 (plane coordinates C = c + 2 K, R = r + row_off):
+      //   mu = 0 (R even): A_s = P(C + 2 s e_C, R - 1 - 2 s), B_s = P(C + 2 s e_C, R + 2 s), B'_s two rows above B_s;
+      //   mu = 1 (C even): D_s = P(C - 1 - 2 s, J_s), J_s = R + 2 (s + 1) e_R, C_s = P(C + 2 s, J_s), C'_s two columns on;
+      // in quadrant coordinates every one of them advances by (1, 1) per s
+      const uint32_t C = c + 2 * K, R = r + row_off, Rq = R >> 1;
+      uint32_t a, x, x2;
       if (!tasks.is_mu1(k)) {
-        const int ec16 = 16 - 32 * (int)(c & 1u);
-        a = at - wb;
-        x = at;
-        x2 = at + 2 * wb;
-        da = ec16 - 2 * wb;
-        dx = ec16 + 2 * wb;
+        const uint32_t cb = P.col(C);
+        x = cb + Rq * (uint32_t)PP::kRow;                       // row R, even: v = R / 2
+        x2 = x + (uint32_t)PP::kRow;
+        a = cb + 2u * P.QB + (P.Rh - Rq) * (uint32_t)PP::kRow;  // row R - 1, odd: v = Rh - 1 - (R / 2 - 1)
       } else {
-        const int er2w = 2 * wb - 4 * wb * (int)(r & 1u);
-        a = at + er2w - 8;
-        x = at + er2w;
-        x2 = x + 16;
-        da = er2w - 16;
-        dx = er2w + 16;
+        // J_0 = R + 2 (v = R / 2 + 1) for even R, R - 2 (v = Rh - 1 - ((R - 1) / 2 - 1)) for odd R
+        const uint32_t rb = (R & 1u) ? 2u * P.QB + (P.Rh - Rq) * (uint32_t)PP::kRow : (Rq + 1u) * (uint32_t)PP::kRow;
+        x = rb + (C >> 1) * 8u;                                  // column C, even: u = C / 2
+        x2 = x + 8u;
+        a = rb + P.QB + ((uint32_t)PP::Wh - (C >> 1)) * 8u;      // column C - 1, odd: u = Wh - 1 - (C / 2 - 1)
       }
+      uint32_t pa = lds0 + a, px = lds0 + x, px2 = lds0 + x2;
       double S = 0.0, X = 0.0, X2 = 0.0;
-#pragma unroll 5
-      for (uint32_t s = 0; s < K; ++s) {
-        S += *reinterpret_cast<const double *>(pb + a);
-        X += *reinterpret_cast<const double *>(pb + x);
-        X2 += *reinterpret_cast<const double *>(pb + x2);
-        a += da;
-        x += dx;
-        x2 += dx;
+      uint32_t s = 0;
+      for (; s + 5 <= K; s += 5) {
+        perm_gather5<PP::kStep>(pa, px, px2, S, X, X2);
+        pa += 5 * PP::kStep;
+        px += 5 * PP::kStep;
+        px2 += 5 * PP::kStep;
+      }
+      for (; s < K; ++s) {
+        perm_gather1(pa, px, px2, S, X, X2);
+        pa += PP::kStep;
+        px += PP::kStep;
+        px2 += PP::kStep;
       }
       d[k] = tasks.is_mu1(k) ? make_double2(X - S, X2 - S) : make_double2(S - X, S - X2);
     }
@@ -1245,7 +1301,7 @@ __device__ __forceinline__ void perm_sweeps(double *plane, const double2 *__rest
       if (tasks.valid(k)) d[k] = make_double2(mod_2pi_fast(th[k].x + d[k].x), mod_2pi_fast(th[k].y + d[k].y));
   };
 
-  perm_build_rows<NT, U>(plane, src, Mt, Mx, gi0, gj0, W, rows);
+  perm_build_rows<NT, U>(P, plane, src, Mt, Mx, gi0, gj0, W, rows);
   double2 th[NV];
   if (NB == 1) {
     // one plane: first half (its angles are in flight across the barrier and the first reads of the plane), second half
@@ -1262,32 +1318,34 @@ __device__ __forceinline__ void perm_sweeps(double *plane, const double2 *__rest
   }
   // NB = 2: the HR new rows of the second plane are loaded while the first half is gathered (at most UB rows per thread:
   // HR / 4 row groups); the angles of the first half only after it, so that the gather has the registers
-  PermBuildPos qb = perm_build_pos<NT>(src, Mt, Mx, gi0, wrap_add(gj0, rows, Mx), W, HR);
+  PermBuildPos qb = perm_build_pos<NT>(P, src, Mt, Mx, gi0, wrap_add(gj0, rows, Mx), W, HR);
   double2 curb = make_double2(0., 0.), vb[UB];
   __syncthreads();
   MLMCPI_STAMP(1);  // plane built
   perm_rows_load<UB>(qb, Mt, Mx, true, curb, vb);
   gather(0, res[0]);
   MLMCPI_STAMP(2);  // first half gathered
-  // rows [HR, rows) of the plane become rows [0, rows - HR); the HR new rows on top
-  constexpr int NC = (4 * (int)kPermMaxK * (PG::OW + 4 * (int)kPermMaxK) + NT - 1) / NT;   // (rows - HR) W = 4 K W values
-  const uint32_t nkeep = (rows - HR) * W;
+  // rows [HR, rows) of the plane become rows [0, rows - HR), the HR new rows go on top.  HR is even: a row keeps its parity
+  // and moves by HR / 2 quadrant rows -- down in the quadrants of the even rows, up (mirrored) in those of the odd rows
+  constexpr int NC = (4 * 2 * (int)kPermMaxK * PP::Wh + NT - 1) / NT;   // 4 quadrants x (rows - HR) / 2 = 2 K quadrant rows
+  const uint32_t nkeep = (rows - HR) / 2 * (uint32_t)PP::Wh, shift = (uint32_t)(HR / 2) * (uint32_t)PP::kRow;
   {
     double keep[NC];
+    char *const pbw = reinterpret_cast<char *>(plane);
     __syncthreads();  // the first half has read its plane
 #pragma unroll
     for (int q = 0; q < NC; ++q) {
-      const uint32_t idx = threadIdx.x + q * NT;
-      if (idx < nkeep) keep[q] = plane[idx + HR * W];
+      const uint32_t idx = threadIdx.x + q * NT, e = idx >> 2, qd = idx & 3u;
+      if (e < nkeep) keep[q] = *reinterpret_cast<const double *>(pbw + qd * P.QB + e * 8u + ((qd & 2u) ? 0u : shift));
     }
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < NC; ++q) {
-      const uint32_t idx = threadIdx.x + q * NT;
-      if (idx < nkeep) plane[idx] = keep[q];
+      const uint32_t idx = threadIdx.x + q * NT, e = idx >> 2, qd = idx & 3u;
+      if (e < nkeep) *reinterpret_cast<double *>(pbw + qd * P.QB + e * 8u + ((qd & 2u) ? shift : 0u)) = keep[q];
     }
   }
-  perm_rows_store<UB>(qb, plane + nkeep, W, curb, vb);
+  perm_rows_store<UB>(qb, P, plane, rows - HR, curb, vb);
   load_theta(0, th);
   double2 th1[NV];
   load_theta(1, th1);
