@@ -63,9 +63,12 @@ def parse():
     ap.add_argument("--probes", action="store_true",
                     help="schwinger: time the HBM-bound kernels of the path after the timed steps even with --no-extra-points")
     ap.add_argument("--cpu-draws", type=int, default=0)
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="timed seconds per core of the CPU baseline, at least")
     ap.add_argument("--epsilon", type=float, default=2e-3, help="quartic_mlmc_hier: tolerance of the untimed run to convergence")
     ap.add_argument("--hier-sub-factor", type=float, default=1.0,
                     help="quartic_mlmc_hier: draws between coarse samples = this x the reference's ceil(2 tau_int) (experiment)")
+    ap.add_argument("--allow-variant", action="store_true",
+                    help="tools only (tools/ab.sh): accept MLMCPI_LIB_VARIANT and mark the line as not a record")
     ap.add_argument("--t-final", type=float, default=0.0, help="quartic_mlmc_hier: T_final (default size / 8, i.e. a = 0.125 on the finest level)")
     return ap.parse_args()
 
@@ -95,6 +98,16 @@ def build_id():
         with open(os.path.join(d, f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:12]
+
+
+def lib_sha256(path):
+    """SHA-256 of the shared library this process loaded (abi.LIB_PATH): ties a line to a binary, as kernel_build ties it to
+    the sources."""
+    h = hashlib.sha256()
+    with open(path, "rb") as fh:
+        for chunk in iter(lambda: fh.read(1 << 20), b""):
+            h.update(chunk)
+    return h.hexdigest()
 
 
 def pmc_entry(section, **match):
@@ -138,7 +151,7 @@ def cpu_baseline(a, size):
     dt = a.dt or {"rotor": 0.05, "harmonic": 0.0558}.get(wl, 0.02)
     cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--workload", wl, "--size", str(size),
            "--draws", str(draws), "--n-overrelax", str(a.n_overrelax), "--n-heatbath", str(a.n_heatbath),
-           "--nt", str(a.nt), "--dt", str(dt)]
+           "--nt", str(a.nt), "--dt", str(dt), "--seconds", str(a.cpu_seconds)]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
     if out.returncode != 0:
         return {"value": None, "error": out.stderr[-300:]}
@@ -148,7 +161,9 @@ def cpu_baseline(a, size):
         out16 = {"value": r["point_16"]["value"], "unit": "updates/s", "cores": 16, "per_core": r["point_16"]["per_core"],
                  "note": "the CPU share of a 1-GPU job on the GPU boxes; same sample"}
     return {"value": r["value"], "unit": "updates/s", "cores": r["cores"], "cores_available": r.get("cores_available"),
-            "cpu_quota": r.get("cpu_quota"), "kind": "port", "per_core": r["per_core"], "wall_s": r.get("wall_s"), "point_16": out16,
+            "cpu_quota": r.get("cpu_quota"), "kind": "port", "per_core": r["per_core"], "per_core_min": r.get("per_core_min"),
+            "per_core_max": r.get("per_core_max"), "per_core_std": r.get("per_core_std"), "value_error": r.get("value_error"),
+            "timed_s_per_core": r.get("timed_s_per_core"), "wall_s": r.get("wall_s"), "point_16": out16,
             "sample": r["sample"] + " (reference-order sequential sweeps, mt19937_64)",
             "note": "the port runs ~2.8x faster per core than the reference itself measured in SURVEY 6.2 "
                     "(12 M link-updates/s/core for 10 OR + 1 HB), so gpu_over_cpu understates the gap to the reference"}
@@ -449,6 +464,14 @@ def main():
         sys.exit(2)
     size = a.size or DEFAULT_SIZE[a.workload]
     B = a.chains or DEFAULT_CHAINS[a.workload]
+    # A bench line is a record of the product library.  An experiment build (MLMCPI_LIB_VARIANT, abi.py) is timed only by
+    # the A/B tools, which say so (--allow-variant) and get a line marked as not a record.
+    variant = os.environ.get("MLMCPI_LIB_VARIANT", "")
+    if variant and not a.allow_variant:
+        if rank == 0:
+            print("bench.py: MLMCPI_LIB_VARIANT is set (%r): a bench line records the product library only; "
+                  "unset it, or pass --allow-variant from an A/B tool" % variant, file=sys.stderr)
+        sys.exit(2)
 
     # Under a profiler (rocprofv3 preloads its tool library, which has initialised the GPU in this process already and
     # would be inherited by the children and mix their kernels into the same output directory) no child process is started.
@@ -668,12 +691,14 @@ def main():
     # slowest rank's time travels in the same buffer (one slot per rank, max of the sums)
     packed = chains.pack_moments(acc_of()).cpu()
     collective = "none (one rank)"
+    rank_times = None
     if world > 1:
         slots = [0.0] * world
         slots[rank] = elapsed
         red = exchange.allreduce_sum_host(packed.tolist() + slots)
         packed = torch.tensor(red[:packed.numel()], dtype=torch.float64)
-        elapsed = max(red[packed.numel():])
+        rank_times = list(red[packed.numel():])   # one slot per rank: every rank's own time of the K steps
+        elapsed = max(rank_times)
         collective = (f"mlmcpi_comm_allreduce_sum_host_f64 (libmlmcpi_rccl.so: ncclAllReduce, {rccl['ranks']} ranks)"
                       if backend == "nccl" else f"torch.distributed all_reduce ({backend} rehearsal, {rccl['ranks']} ranks)")
     hier_run = None
@@ -727,7 +752,21 @@ def main():
             "stats_collective": collective,
             "rccl": rccl,
             "kernel_build": build_id(),
+            "lib": os.path.relpath(abi.LIB_PATH, ROOT),
+            "lib_sha256": lib_sha256(abi.LIB_PATH),
+            # experiment builds lying beside the product library (they travel to the GPU box with it); none in a record run
+            "variant_libs_present": sorted(f for f in os.listdir(os.path.dirname(abi.LIB_PATH))
+                                           if f.startswith("libmlmcpi_hip_") and f.endswith(".so")),
         }
+        if variant:
+            result["variant"] = variant
+            result["not_a_record"] = "experiment build loaded through MLMCPI_LIB_VARIANT (A/B tool run)"
+        # per-rank rates (filled from the exchanged times below at N > 1): the first N-GPU run yields a checkable curve
+        # (the MLMC workloads cut ONE job into equal-cost shares: no per-rank rate of its own)
+        result["value_per_gpu"] = (None if a.workload.startswith("quartic_mlmc") else
+                                   [units_per_step * a.steps / t for t in rank_times] if rank_times else [total_units / elapsed])
+        if world > 1 and backend == "nccl":
+            assert rccl and rccl.get("ranks") == world, f"RCCL communicator spans {rccl and rccl.get('ranks')} ranks, launcher started {world}"
         if a.workload in ("schwinger", "gff"):
             report_sweeps(result, a, W, size, B, world, step_ms, ms)
         elif a.workload == "rotor_sweep":
@@ -818,6 +857,11 @@ def main():
                 result["cxx_path"]["over_python_driven"] = cxx["chains_32"]["value_per_gpu"] / (result["value"] / world)
         if cpu is not None:
             p16 = cpu.pop("point_16", None)
+            if a.workload in ("schwinger", "rotor_sweep"):
+                # the CPU port executes all sweeps one by one; the closed form is an identity a CPU code could use as well, so
+                # gpu_over_cpu mixes an algebraic shortcut with hardware speed (ms_per_draw is the like-for-like figure)
+                cpu["closed_form_possible"] = True
+                cpu["executes"] = "every sweep, update by update (reference order)"
             result["cpu_baseline"] = cpu
             if cpu.get("value"):  # against every core the box gives (cpu_baseline.cores of them)
                 result["gpu_over_cpu"] = result["value"] / cpu["value"]
@@ -873,9 +917,11 @@ def register_resident_roofline(kernel, launch_ms, floor_bytes, streaming_bytes, 
             r["issue_frac"] = valu["issue_frac"]
             r["valu"]["issue_frac"] = valu["issue_frac"]
         r["valu"]["from"] = "profile (PMC passes of tools/profile_all.sh on this kernel build), not measured in this run"
-        # the binding resource: vector issue (cost-weighted when the class counters were taken)
+        # the binding resource is vector issue (cost-weighted when the class counters were taken): kept under roofline.valu;
+        # bound / achieved / peak / unit / frac stay on the measured HBM model in every line (schema 2)
         f = valu["issue_frac"] if valu.get("issue_frac") is not None else valu["valu_frac"]
-        r.update({"bound": "valu", "achieved": f * 1024 * 2.4, "peak": 1024 * 2.4, "unit": "Gcycle/s", "frac": f})
+        r["valu"].update({"binding_frac": f, "binding_achieved_Gcycle_per_s": f * 1024 * 2.4, "binding_peak_Gcycle_per_s": 1024 * 2.4})
+    r["schema"] = 2
     return r
 
 
@@ -984,22 +1030,28 @@ def report_sweeps(result, a, W, size, B, world, step_ms, ms):
             "hbm_peak_GBps": HBM_PEAK_GBS, "traffic": dom["traffic"], "launch_ms": dom["launch_ms"],
             "algorithmic_bytes_per_launch": dom["hbm_floor_bytes_per_launch"], "share_of_step": dom["share_of_step"],
             "updates_per_s": dom["updates_per_s"]}
+    # The contract fields (bound, achieved, peak, unit, frac) stay on the measured HBM model in every line, so that frac is
+    # comparable across rounds and with north_star's 60 %: the state read + written once per launch (the bytes no
+    # implementation of this launch can avoid) / the launch time measured in this run / 8 TB/s.  What actually binds a
+    # vector-issue-bound launch sits beside it under roofline.valu.
+    roof.update({"bound": "hbm", "achieved": dom["hbm_floor_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["hbm_frac"],
+                 "schema": 2})
     if "issue_frac" in dom:
         peak = 1024 * 2.4   # G issue cycles per second: 1024 SIMDs x 2.4 GHz
-        roof.update({"bound": "valu", "achieved": dom["issue_frac"] * peak, "peak": peak, "unit": "Gcycle/s",
-                     "frac": dom["issue_frac"], "issue_frac": dom["issue_frac"], "issue_cycles_per_inst": dom["issue_cycles_per_inst"],
-                     "valu_frac": dom["valu_frac"], "valu_insts_per_update": dom["valu_insts_per_update"], "valu_from": dom["valu_from"],
-                     "limited_by": "valu",
-                     "note": "vector-issue bound: achieved = issue cycles of one launch (instruction counts by class from the SQ "
-                             "counters of this kernel build x measured issue cycles per class) / launch time of this run; "
-                             "valu_frac = the same with every instruction charged 4 cycles; hbm_frac = state read + written "
-                             "once / launch time / 8 TB/s (all sweeps of the launch share one HBM round trip)"})
-    else:
-        roof.update({"bound": "hbm", "achieved": dom["hbm_floor_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["hbm_frac"]})
-        if "heat-bath sweep" in dom["role"]:
-            roof["limited_by"] = "valu"
-            roof["note"] = ("this launch is vector-issue bound, but profiles/traffic.json holds no PMC figures of kernel build "
-                            + build_id() + ": only the HBM floor fraction can be quoted")
+        roof["limited_by"] = "valu"
+        roof["valu"] = {"frac": dom["issue_frac"], "achieved": dom["issue_frac"] * peak, "peak": peak, "unit": "Gcycle/s",
+                        "issue_cycles_per_inst": dom["issue_cycles_per_inst"], "valu_frac": dom["valu_frac"],
+                        "valu_insts_per_update": dom["valu_insts_per_update"], "from": dom["valu_from"],
+                        "note": "vector-issue model, NOT measured in this run: instruction counts by class from the SQ counters "
+                                "of this kernel build (profiles/traffic.json) x measured issue cycles per class "
+                                "(profiles/r04_valu_issue_cost.txt) / (1024 SIMDs x 2.4 GHz x the launch time of this run); "
+                                "valu_frac = the same with every instruction charged 4 cycles"}
+        roof["note"] = ("frac is the HBM floor fraction (all sweeps of the launch share one HBM round trip); the launch is "
+                        "vector-issue bound: see roofline.valu")
+    elif "heat-bath sweep" in dom["role"]:
+        roof["limited_by"] = "valu"
+        roof["note"] = ("this launch is vector-issue bound, but profiles/traffic.json holds no PMC figures of kernel build "
+                        + build_id() + ": only the HBM floor fraction can be quoted")
     result["roofline"] = roof
     # whole step: 16 B x every update of the step against the step time, and the bytes the step's launches cannot avoid
     alg_step = 16.0 * sites * B * (a.n_overrelax + a.n_heatbath)
@@ -1016,6 +1068,24 @@ def report_sweeps(result, a, W, size, B, world, step_ms, ms):
         tr = sum(k["traffic"] * k["launches_per_step"] for k in kernels[:-1])
         result["whole_step"].update({"counter_traffic_bytes": tr, "counter_traffic_GBps": tr / (step_ms * 1e-3) / 1e9,
                                      "counter_traffic_frac": tr / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
+    # What the headline number is.  `value` counts every link update of every sweep of the draw; where the
+    # overrelaxation sweeps of a launch are applied in closed form (one fixed permutation of the plaquettes, same state to
+    # 4e-14), ten of the eleven sweeps are not EXECUTED as link updates, so the comparable quantities are the time per draw
+    # and the updates the launch does execute one by one (the heat-bath sweeps).
+    closed_form = a.workload == "schwinger" and bool(getattr(W, "perm", False))
+    executed = sites * B * (a.n_heatbath if closed_form else a.n_overrelax + a.n_heatbath)
+    result["ms_per_draw"] = step_ms
+    result["draws_per_s"] = B * world / (step_ms * 1e-3)
+    result["executed_updates_per_s"] = executed * world / (step_ms * 1e-3)
+    result["equivalent_updates"] = {"value_counts_equivalent_updates": closed_form,
+                                    "sweeps_per_draw": {"overrelaxation": a.n_overrelax, "heat_bath": a.n_heatbath},
+                                    "executed_as_link_updates": {"overrelaxation": 0 if closed_form else a.n_overrelax,
+                                                                 "heat_bath": a.n_heatbath},
+                                    "note": ("value = link updates of all %d sweeps / time; the %d overrelaxation sweeps are one "
+                                             "closed-form map per launch (identical state, tests), so compare ms_per_draw / "
+                                             "draws_per_s across implementations and executed_updates_per_s for sampler work"
+                                             % (a.n_overrelax + a.n_heatbath, a.n_overrelax)) if closed_form else
+                                            "every sweep is executed update by update"}
     result["whole_step"]["note"] = ("algorithmic_over_hbm_peak may pass 1: that is temporal blocking (the sweeps of a launch share "
                                     "one HBM round trip), not skipped work -- the state a launch writes is the state after every one "
                                     "of its sweeps: the sweep-by-sweep kernels agree bit for bit whatever the launch plan, and the "

@@ -392,10 +392,13 @@ int main(int argc, char **argv) {
                   n_levels, st->average(), st->error(), exact, st->tau_int(), mc.get_sampler()->p_accept());
       ZEXPECT(st->average(), st->error(), exact, 5, "GFF hierarchical <phi^2>");
       if (n_levels == 2) EXPECT(mc.get_sampler()->p_accept() > 0.9, "GFF 2-level acceptance %.3f", mc.get_sampler()->p_accept());
-      // 3 levels: 0.987 x the plain-vs-marginal independence test on the 128-vertex rotated level, whose expected acceptance
-      // is 0.070 (numpy with the library's matrices) and which the reference author's Python experiment brackets with 0.20
-      // at 64 and 0.055 at 144 vertices (tests/test_gff_levels.py::test_three_level_acceptance_is_the_plain_vs_marginal_mismatch)
-      if (n_levels == 3) EXPECT(mc.get_sampler()->p_accept() > 0.04 && mc.get_sampler()->p_accept() < 0.12, "GFF 3-level acceptance %.3f", mc.get_sampler()->p_accept());
+      // 3 levels: REPORT ONLY.  The reference's own 3-level acceptance is unknown (no number of it exists anywhere in the
+      // reference); the 8 % seen here equals 0.987 x the plain-vs-marginal independence test on the 128-vertex rotated
+      // level computed in numpy from the library's matrices (0.070 +- 0.003, the equality is asserted where both numbers are
+      // computed for the same lattice: tests/test_gff_levels.py::test_three_level_acceptance_is_the_plain_vs_marginal_mismatch).
+      // An error in the rotated-level fill-in would show as a difference THERE; a window here would only freeze whatever
+      // the acceptance happens to be.
+      if (n_levels == 3) std::printf(" (report only) GFF 3-level acceptance %.3f\n", mc.get_sampler()->p_accept());
     }
     // coarse action: copy_from_fine then evaluate on the rotated level equals evaluating Qhat there (consistency of the
     // vertex maps between the classes)

@@ -18,9 +18,17 @@
  *       Schwinger      theta[b*2*Mt*Mx + 2*Mt*j + 2*i + mu]  (lattice/lattice2d.hh:348-354)
  *   - randomness is counter based: Philox4x32-10 keyed by `seed`, counter =
  *     (site, chain0 + b, step, purpose<<24 | sub).  Results do not depend on grid shape, tile
- *     size or number of GPUs, nor on the number of sweeps fused into a launch -- to the last bit,
- *     except for the Schwinger overrelaxation sweeps, which a launch evaluates as one closed form:
- *     there the fused depth shows in the last bits (<= 4e-14).  The contract is spelled out in DESIGN.md.
+ *     size, batch composition or number of GPUs -- to the last bit.
+ *   - BIT REPRODUCIBILITY ACROSS LAUNCH PLANS holds for a FIXED (n_overrelax, fuse, MLMCPI_OR_KERNEL) setting only.
+ *     The overrelaxation sweeps of one launch of the Schwinger action (mlmcpi_lattice_sweep_draw*) and of
+ *     the rotor (mlmcpi_path_sweep_draw*) are evaluated as ONE closed form (K sweeps = one signed sum of
+ *     2 K plaquettes / path differences per link / site): the same map as K single sweeps, other rounding.
+ *     K sweeps in one launch and the same sweeps in two launches -- another `fuse`, or
+ *     MLMCPI_OR_KERNEL=block (which makes BOTH actions sweep by sweep) -- differ in the last bits
+ *     (<= 4e-14 Schwinger at K = 10, <= 2e-15 rotor).  A heat-bath accept/reject decision that sits on
+ *     such a difference flips, after which two chains diverge: compare, checkpoint and resume runs under
+ *     one launch plan, and record it (K per launch: bench.py's config.overrelaxation_launches).  The
+ *     sweep-by-sweep kernels (GFF always) agree bit for bit whatever the plan.  Spelled out in DESIGN.md 3 / 9.
  */
 #ifndef MLMCPI_HIP_H
 #define MLMCPI_HIP_H
@@ -146,7 +154,11 @@ int mlmcpi_path_hmc_run_layout(const mlmcpi_path_action *act, uint32_t B, uint32
 /* OverrelaxedHeatBathSampler::draw (sampler/overrelaxedheatbathsampler.cc:8-31) for the rotor:
  * n_overrelax sweeps of RotorAction::overrelaxation_update (rotoraction.cc:40-56) then n_heatbath
  * sweeps of heatbath_update (:20-37), even sites then odd sites within each sweep.  Sweep s of
- * this call uses Philox step sweep0 + s.  d_x is updated in place; d_scratch is B*M doubles. */
+ * this call uses Philox step sweep0 + s.  d_x is updated in place; d_scratch is B*M doubles.
+ * Up to 16 overrelaxation sweeps of a launch are applied in closed form (more: launches of equal depth);
+ * MLMCPI_OR_KERNEL=block sweeps one by one, 8 per launch.  The two agree to <= 2e-15 without a heat bath
+ * behind (the same map, other rounding), NOT bit for bit: see "bit reproducibility across launch plans"
+ * at the top of this header. */
 int mlmcpi_path_sweep_draw(const mlmcpi_path_action *act, double *d_x, double *d_scratch, uint32_t B,
                            uint32_t n_overrelax, uint32_t n_heatbath, uint64_t seed, uint32_t chain0,
                            uint32_t sweep0, void *stream);

@@ -531,9 +531,12 @@ __device__ __forceinline__ void heatbath_cells(uint32_t total, const RngKey &key
   const PhiloxVKeys *const vk = LEAN ? nullptr : &vk_;
   for (uint32_t b0 = 0; b0 < total; b0 += S * NT) {  // uniform trip count: the barriers below need every thread
     uint32_t *cnt = pool.count() + (pool.use & 1u);
-    // The other counter (the one of the previous and of the next use) is cleared HERE: after wave 0's read of it in the
-    // previous use's drain (thread 0 is in wave 0: program order) and before the barrier of this use, which every push
-    // of the next use follows.
+    // The other counter (the one of the previous and of the next use) is cleared HERE.  Invariant: a WORKGROUP BARRIER
+    // separates the drain of use u from the start of use u + 1 -- every thread takes part in a drain, so program order in
+    // thread 0 alone would not do.  Within a call that barrier is the one at the end of the b0 loop below; between two
+    // calls it is the caller's barrier between colour phases (every call site has one: the next phase reads what this
+    // one wrote).  The clear therefore follows every read of this counter in the previous use's drain, and precedes the
+    // barrier of this use, which every push of the next use follows.
     if (pool.cap && threadIdx.x == 0) pool.count()[(pool.use + 1u) & 1u] = 0;
 #pragma unroll
     for (int m = 0; m < S; ++m) {
@@ -549,7 +552,7 @@ __device__ __forceinline__ void heatbath_cells(uint32_t total, const RngKey &key
           const uint32_t slot = atomicAdd(cnt, 1u);
           if (slot < pool.cap) {
             pool.kap()[slot] = kap; pool.cen()[slot] = cen; pool.site()[slot] = site; pool.off()[slot] = off;
-            continue;  // wave 0 finishes this cell after the barrier
+            continue;  // finished after the barrier, by whichever thread takes the entry
           }
         }
         // no pool, or pool full: retry here
@@ -573,7 +576,7 @@ __device__ __forceinline__ void heatbath_cells(uint32_t total, const RngKey &key
       }
       ++pool.use;
       // Another pass of this phase follows (more than S NT cells: tiles larger than the default): its pushes reuse the
-      // entry arrays wave 0 is still draining, so it waits.  (Between two phases the caller's own barrier does that.)
+      // entry arrays the drain above is still reading, so it waits.  (Between two phases the caller's own barrier does that.)
       if (b0 + S * NT < total) __syncthreads();
     }
   }
@@ -801,7 +804,8 @@ struct VsPool {
 // site from the tile image; kappa_exact(off) = the fp64 concentration (rare); commit(off, angle).  The caller puts a
 // barrier behind the call (every call site has one: the next phase reads what this one wrote).
 // Pass 0 walks the cells of the phase (thread t: cells t, t + NT, ...), pass 1 the list (the rare exact test is a function
-// call, vs_exact_pair, so that the two copies of the attempt code stay small).  S is not used any more.
+// call, vs_exact_pair, so that the two copies of the attempt code stay small).  S (cells per thread and pass of
+// heatbath_cells, whose signature the call sites share) is not used here.
 // LEAN (the 1-D rotor sweeps, whose 256-thread workgroups live on occupancy): one copy of the cell code with a run-time flag and
 // the round keys on the scalar side -- 59 instead of 97 VGPRs, 7 instead of 4 waves per SIMD (the fast form cost the rotor
 // sweeps 10 %; it gains the fused Schwinger launch, which LDS holds at 4 waves per SIMD anyway, 3 %).

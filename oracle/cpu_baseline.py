@@ -17,7 +17,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def _worker(args):
     import numpy as np
     import oracle as O
-    workload, size, draws, n_or, n_hb, nt, dt = args
+    workload, size, draws, n_or, n_hb, nt, dt, seconds = args
     L = O.lib()
     if workload == "schwinger":
         A = O.Action(O.SCHWINGER, Mt=size, Mx=size, beta=1.0)
@@ -53,18 +53,24 @@ def _worker(args):
         x = np.zeros(A.size)
     for _ in range(2):
         draw(x)  # warm-up (page in, first touch, a first pass of thermalisation)
+    # at least `draws` draws and at least `seconds` of them: the sample carries an error bar (spread over the cores)
     t0 = time.perf_counter()
-    for _ in range(draws):
+    done = 0
+    while True:
         draw(x)
-    el = time.perf_counter() - t0
-    return units * draws, el
+        done += 1
+        el = time.perf_counter() - t0
+        if done >= draws and el >= seconds:
+            break
+    return units * done, el, done
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="schwinger")
     ap.add_argument("--size", type=int, default=1024)
-    ap.add_argument("--draws", type=int, default=4)
+    ap.add_argument("--draws", type=int, default=4, help="draws per core at least")
+    ap.add_argument("--seconds", type=float, default=20.0, help="timed seconds per core at least (BASELINE.md section 3: 10-30 s of CPU work)")
     ap.add_argument("--cores", type=int, default=0)
     ap.add_argument("--n-overrelax", type=int, default=10)
     ap.add_argument("--n-heatbath", type=int, default=1)
@@ -88,20 +94,27 @@ def main():
     cores = a.cores or min(avail, quota)
     import oracle as O
     O.build()  # compile once, before forking
-    job = (a.workload, a.size, a.draws, a.n_overrelax, a.n_heatbath, a.nt, a.dt)
+    job = (a.workload, a.size, a.draws, a.n_overrelax, a.n_heatbath, a.nt, a.dt, a.seconds)
 
     def run(n):
         t0 = time.perf_counter()
         with mp.get_context("fork").Pool(n) as pool:
             res = pool.map(_worker, [job] * n, chunksize=1)
         wall = time.perf_counter() - t0
-        rate = sum(u / el for u, el in res)  # all processes run concurrently: aggregate rate
-        return {"value": rate, "per_core": rate / n, "cores": n, "wall_s": wall}
+        rates = [u / el for u, el, _ in res]
+        rate = sum(rates)  # all processes run concurrently: aggregate rate
+        mean = rate / n
+        std = (sum((r - mean) ** 2 for r in rates) / max(1, n - 1)) ** 0.5
+        return {"value": rate, "per_core": mean, "per_core_min": min(rates), "per_core_max": max(rates), "per_core_std": std,
+                "value_error": std * n ** 0.5, "cores": n, "wall_s": wall, "timed_s_per_core": sum(el for _, el, _ in res) / n,
+                "draws_per_core": [d for _, _, d in res]}
 
     out = run(cores)
     out.update(cores_available=avail, cpu_quota=quota,
-               sample=f"{a.draws} draws per core of {a.workload} {a.size}, one chain per core")
+               sample=f"{min(out['draws_per_core'])}-{max(out['draws_per_core'])} draws per core (>= {a.seconds:g} s timed) of "
+                      f"{a.workload} {a.size}, one chain per core")
     if cores > 16 and not a.cores:
+        job = job[:-1] + (min(a.seconds, 5.0),)   # the second point: a short sample
         out["point_16"] = run(16)
     print(json.dumps(out))
 

@@ -8,7 +8,7 @@ OUT=gpurun_out/ab_$TAG.txt
 : > $OUT
 for round in 1 2 3; do
   for V in "$@"; do
-    MLMCPI_LIB_VARIANT=$V timeout -k 10 200 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-extra-points ${AB_ARGS:-} 2>/dev/null | python -c "
+    MLMCPI_LIB_VARIANT=$V timeout -k 10 200 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-extra-points --allow-variant ${AB_ARGS:-} 2>/dev/null | python -c "
 import json, sys
 d = json.loads(sys.stdin.readline())
 ks = ' '.join('%s %.4f' % (k['kernel'].split('(')[0][-24:], k['launch_ms']) for k in d.get('kernels', []))
