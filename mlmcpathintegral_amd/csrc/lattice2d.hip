@@ -916,7 +916,10 @@ __device__ __forceinline__ void schwinger_image_heat(double *th0, double *th1, V
   // write-out and the optional QoI, as in schwinger_sweep_kernel
   double acc[1] = {0.0};
   double2 *dst = out + (size_t)b * Mt * Mx;
+  // (a tile on the upper / right edge of a lattice that 64 x 64 tiles do not divide reaches beyond it: those vertices are
+  // periodic images of vertices another tile owns -- computed here like any halo, neither written nor counted)
   for_region<NT>(TH, TW, [&](uint32_t r, uint32_t c) {
+    if (j0 + r >= Mx || i0 + c >= Mt) return;
     const uint32_t o = (r + HB) * bw + (c + HB);
     store_streaming(&dst[(size_t)(j0 + r) * Mt + (i0 + c)], th0[o], th1[o]);
     if (qoi_op) {
@@ -1325,6 +1328,11 @@ __device__ __forceinline__ void perm_sweeps(double *plane, const double2 *__rest
   perm_rows_load<UB>(qb, Mt, Mx, true, curb, vb);
   gather(0, res[0]);
   MLMCPI_STAMP(2);  // first half gathered
+#ifdef MLMCPI_THETA_EARLY
+  // experiment (r05, same-box A/B: 0.781 against 0.778 ms without): the angles of the first half in flight while the plane's
+  // rows move -- the longer live range costs a spill inside the second gather, which then waits for every load in flight
+  load_theta(0, th);
+#endif
   // rows [HR, rows) of the plane become rows [0, rows - HR), the HR new rows go on top.  HR is even: a row keeps its parity
   // and moves by HR / 2 quadrant rows -- down in the quadrants of the even rows, up (mirrored) in those of the odd rows
   constexpr int NC = (4 * 2 * (int)kPermMaxK * PP::Wh + NT - 1) / NT;   // 4 quadrants x (rows - HR) / 2 = 2 K quadrant rows
@@ -1346,12 +1354,14 @@ __device__ __forceinline__ void perm_sweeps(double *plane, const double2 *__rest
     }
   }
   perm_rows_store<UB>(qb, P, plane, rows - HR, curb, vb);
+#ifndef MLMCPI_THETA_EARLY
   load_theta(0, th);
+#endif
   double2 th1[NV];
   load_theta(1, th1);
   __syncthreads();
   MLMCPI_STAMP(10);  // second plane built
-  finish(th, res[0]);
+  finish(th, res[0]);   // (behind the gather instead: 48 bytes of spills)
   gather(1, res[1]);
   finish(th1, res[1]);
 }
@@ -1408,7 +1418,8 @@ __global__ void __launch_bounds__(512, 4)
 #pragma unroll
   for (int k = 0; k < 64 * TH / NT; ++k) {  // a wave writes a row of the tile
     const uint32_t v = threadIdx.x + k * NT, r = v / 64, c = v % 64;
-    store_streaming(&dst[(size_t)(j0 + r) * Mt + (i0 + c)], th0[v], th1[v]);
+    if (j0 + r < Mx && i0 + c < Mt)   // (an edge tile of a lattice the tiles do not divide: see schwinger_image_heat)
+      store_streaming(&dst[(size_t)(j0 + r) * Mt + (i0 + c)], th0[v], th1[v]);
   }
 }
 
@@ -2614,8 +2625,16 @@ static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, doub
                           (uint64_t)(act->Mt / 64) * (act->Mx / 64) * B <= kComputeUnits;
   // Schwinger overrelaxation in closed form (schwinger_perm_kernel, schwinger_perm_heat_kernel): the default where 64 x 64
   // tiles divide the lattice; MLMCPI_OR_KERNEL=block|patch|lds select the sweep-by-sweep kernels
-  const bool perm = schw && !tune.or_block && !tune.or_lds && !tune.or_patch && !tune.tile_w && act->Mt % 64 == 0 && act->Mx % 32 == 0;
-  const bool perm64 = perm && act->Mx % 64 == 0;   // 64 x 64 tiles (else 64 x 32: the heat bath is a launch of its own)
+  // r05: any even lattice of at least one tile.  Tiles on the upper / right edge of a lattice the tiles do not divide reach
+  // beyond it; what lies there are periodic images of vertices other tiles own (the plane wraps as often as needed):
+  // computed like any halo, not written.  64 x 64 tiles where they divide Mx and wherever the fused launch applies (both
+  // extents >= 128: its image must not wrap onto itself), else 64 x 32 (the heat bath is then a launch of its own);
+  // lattices that would more than double the work through padding stay with the sweep-by-sweep kernels.
+  const bool perm_shape = schw && act->Mt >= 64 && act->Mx >= 32;
+  const bool perm64 = perm_shape && (act->Mx % 64 == 0 || (act->Mt >= 128 && act->Mx >= 128));
+  const uint32_t perm_th = perm64 ? 64 : 32, perm_tx = (act->Mt + 63) / 64, perm_ty = (act->Mx + perm_th - 1) / perm_th;
+  const bool perm = perm_shape && !tune.or_block && !tune.or_lds && !tune.or_patch && !tune.tile_w &&
+                    (uint64_t)perm_tx * 64 * perm_ty * perm_th <= (uint64_t)2 * act->Mt * act->Mx + (uint64_t)act->Mt * act->Mx / 5;
   const uint32_t fuse_arg = fuse;
   if (fuse == 0) fuse = whole_draw ? n_overrelax : (or_blocks || gff_blocks32) ? 6 : 4;
   if (fuse > kMaxFuse) fuse = kMaxFuse;
@@ -2647,7 +2666,7 @@ static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, doub
       // as few launches as kPermMaxK (or the caller's `fuse`) allows, of equal depth
       const uint32_t rem = n_overrelax - s, kmax = fuse_arg ? std::min(fuse_arg, kPermMaxK) : kPermMaxK;
       const uint32_t launches = (rem + kmax - 1) / kmax, K = (rem + launches - 1) / launches;
-      const dim3 bgrid((act->Mt / 64) * (act->Mx / (perm64 ? 64 : 32)), B);
+      const dim3 bgrid(perm_tx * perm_ty, B);
       const double2 *in2 = (const double2 *)src;
       double2 *out2 = (double2 *)dst;
       if (perm64 && !tune.or_heat_split && s + K == n_overrelax && n_heatbath >= 1 && act->Mt >= 128 && act->Mx >= 128) {
@@ -2670,7 +2689,7 @@ static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, doub
         const uint32_t NB = PHG::lds_bytes(K, 1) <= lds_max ? 1 : 2;
         const size_t lds = PHG::lds_bytes(K, NB);
         if (lds > lds_max) return fail(MLMCPI_ERR_INVALID, "closed-form plane of %u sweeps does not fit", K);
-#define MLMCPI_PERM_HEAT(NN, SS) hipLaunchKernelGGL((schwinger_perm_heat_kernel<NN, SS>), bgrid, dim3(NN), lds, st, act->Mt, act->Mx, act->beta, in2, out2, act->Mt / 64, K, NB, hkey, op, (double *)partial, vs_table)
+#define MLMCPI_PERM_HEAT(NN, SS) hipLaunchKernelGGL((schwinger_perm_heat_kernel<NN, SS>), bgrid, dim3(NN), lds, st, act->Mt, act->Mx, act->beta, in2, out2, perm_tx, K, NB, hkey, op, (double *)partial, vs_table)
         if (wide) { if (step) MLMCPI_PERM_HEAT(1024, true); else MLMCPI_PERM_HEAT(1024, false); }
         else { if (step) MLMCPI_PERM_HEAT(512, true); else MLMCPI_PERM_HEAT(512, false); }
 #undef MLMCPI_PERM_HEAT
@@ -2687,11 +2706,11 @@ static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, doub
       if (perm64) {
         using PG0 = PermGeom<512, 0, 64>;
         const uint32_t NB = PG0::plane_bytes(K, 1) <= kPermPlaneMax ? 1 : 2;
-        hipLaunchKernelGGL(schwinger_perm_kernel<64>, bgrid, dim3(512), perm_lds_bytes<64>(K, NB), st, act->Mt, act->Mx, in2, out2, act->Mt / 64, K, NB);
+        hipLaunchKernelGGL(schwinger_perm_kernel<64>, bgrid, dim3(512), perm_lds_bytes<64>(K, NB), st, act->Mt, act->Mx, in2, out2, perm_tx, K, NB);
       } else {
         using PG0 = PermGeom<512, 0, 32>;
         const uint32_t NB = PG0::plane_bytes(K, 1) <= kPermPlaneMax ? 1 : 2;
-        hipLaunchKernelGGL(schwinger_perm_kernel<32>, bgrid, dim3(512), perm_lds_bytes<32>(K, NB), st, act->Mt, act->Mx, in2, out2, act->Mt / 64, K, NB);
+        hipLaunchKernelGGL(schwinger_perm_kernel<32>, bgrid, dim3(512), perm_lds_bytes<32>(K, NB), st, act->Mt, act->Mx, in2, out2, perm_tx, K, NB);
       }
       MLMCPI_LAUNCH_CHECK("schwinger_perm_kernel");
       advance();

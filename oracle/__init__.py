@@ -91,6 +91,8 @@ _SIGS = {
     "orc_approx_bessel_pdf": (_d, [_d, _d, _d, _d]),
     "orc_approx_bessel_params": (None, [_d, _d, _dp]),
     "orc_schwinger_plaquettes": (None, [_vp, _dp, _dp]),
+    "orc_mlmc_ref_run": (None, [_i, _u32, _d, _d, _d, _d, _d, _u32, _u32, _d, _u32, _u32, _u32, _u32, _i, _u64, _dp, _dp]),
+    "orc_single_level_ref_run": (None, [_i, _u32, _d, _d, _d, _d, _d, _u32, _u32, _d, _u32, _u32, _u32, _u64, _dp]),
     "orc_bessel_product_ref_draws": (None, [_u64, _d, _d, _d, _u32, _u32, _dp]),
     "orc_ho_cholesky": (_i, [_vp, _dp]),
     "orc_dev_exact_draw": (None, [_vp, _dp, _dp, _u64, _u32, _u32]),

@@ -1531,6 +1531,205 @@ struct StatsO {
   double error() const { return std::sqrt(tau_int() * variance() / (1.0 * n)); }
 };
 
+// ---------------------------------------------------------------------------------------------
+// Multilevel callers in REFERENCE ORDER (1-D actions): sequential, std::mt19937_64 engines with the reference's seeds
+// (+ a replica offset, as the reference's MPI ranks get distinct seeds), one object per class of the reference.
+// Purpose: to see what the reference's scheme itself does at a low hierarchical acceptance -- the
+// delayed-acceptance two-level step fed with coarse samples taken ceil(2 tau_int) draws apart, tau_int re-read on
+// every coarse draw.  Not timed, not shipped.
+// ---------------------------------------------------------------------------------------------
+void *orc_action_1d_impl(int kind, unsigned M, double T_final, double m0, double mu2, double lambda, double x0) {
+  uint64_t seed = kind == ROTOR ? 21172817ull : 124129017ull;
+  ActionO *A = new ActionO((Kind)kind, seed);
+  A->M = M; A->T_final = T_final; A->a = T_final / M; A->m0 = m0; A->mu2 = mu2; A->lambda = lambda; A->x0 = x0;
+  return A;
+}
+struct SamplerO {  // sampler/sampler.hh:18-44 + montecarlo/mcmcstep.hh:21-72
+  virtual ~SamplerO() {}
+  virtual void draw(double *out) = 0;
+  virtual void set_state(const double *x) = 0;
+  virtual bool accepted() const = 0;
+};
+struct HmcSamplerO : SamplerO {  // HMCSampler behind the Sampler interface
+  HmcO h;
+  HmcSamplerO(ActionO *A, unsigned nt, double dt, unsigned n_burnin, uint64_t seed_offset) : h(A, nt, dt, 1, 0, 0, 0, 0) {
+    h.engine.seed(8923759ull + seed_offset);
+    std::vector<double> tmp(A->size(), 0.0);
+    for (unsigned i = 0; i < n_burnin; ++i) h.draw(tmp.data());
+    h.reset();
+  }
+  void draw(double *out) override { h.draw(out); }
+  void set_state(const double *x) override { std::copy(x, x + h.cur.size(), h.cur.begin()); }  // hmcsampler.cc:72-74
+  bool accepted() const override { return h.accept; }
+};
+// montecarlo/twolevelmetropolisstep.{hh,cc} with GaussianConditionedFineAction (action/qm/gaussianconditionedfineaction.cc:7-43)
+// and QMAction::copy_from_coarse / copy_from_fine (action/qm/qmaction.cc:7-24).  (The reference's constructor also times
+// 10000 draws from a zero coarse state; that only advances the engines and is left out.)
+struct TwoLevelStepO : StepCounters {
+  ActionO *F, *C;
+  std::mt19937_64 engine, cfa_engine;
+  std::uniform_real_distribution<double> uniform{0.0, 1.0};
+  std::normal_distribution<double> cfa_normal{0.0, 1.0};
+  std::vector<double> theta, thetaC, prime;
+  double S_theta = 0, cfa_theta = 0;
+  TwoLevelStepO(ActionO *F_, ActionO *C_, uint64_t seed_offset)
+      : F(F_), C(C_), engine(89216491ull + seed_offset), cfa_engine(11897197ull + seed_offset), theta(F_->M, 0.0), thetaC(C_->M, 0.0),
+        prime(F_->M, 0.0) {
+    S_theta = F->evaluate(theta.data());
+    cfa_theta = cfa_gaussian(*F, theta.data());
+  }
+  void set_state(const double *x) {  // twolevelmetropolisstep.cc:92-97
+    std::copy(x, x + theta.size(), theta.begin());
+    S_theta = F->evaluate(theta.data());
+    cfa_theta = cfa_gaussian(*F, theta.data());
+  }
+  void draw(const double *coarse, double *out) {  // twolevelmetropolisstep.cc:35-89
+    const unsigned M = F->M, Mc = M / 2;
+    for (unsigned j = 0; j < Mc; ++j) prime[2 * j] = coarse[j];
+    for (unsigned j = 0; j < Mc - 1; ++j) {  // interior points, then the one that wraps around
+      const double xm = prime[2 * j], xp = prime[2 * (j + 1)];
+      prime[2 * j + 1] = F->w_minimum(xm, xp) + cfa_normal(cfa_engine) * (1. / std::sqrt(F->w_curvature(xm, xp)));
+    }
+    {
+      const double xm = prime[M - 2], xp = prime[0];
+      prime[M - 1] = F->w_minimum(xm, xp) + cfa_normal(cfa_engine) * (1. / std::sqrt(F->w_curvature(xm, xp)));
+    }
+    const double S_prime = F->evaluate(prime.data());
+    const double dS_fine = S_prime - S_theta;
+    for (unsigned j = 0; j < Mc; ++j) thetaC[j] = theta[2 * j];
+    const double dS_coarse = C->evaluate(thetaC.data()) - C->evaluate(coarse);
+    const double cfa_prime = cfa_gaussian(*F, prime.data());
+    const double dS = dS_fine + dS_coarse + (cfa_theta - cfa_prime);
+    accept = dS < 0.0 ? true : (uniform(engine) < std::exp(-dS));
+    if (accept) {
+      theta = prime;
+      S_theta = S_prime;
+      cfa_theta = cfa_prime;
+    }
+    ++n_total;
+    n_accepted += accept ? 1 : 0;
+    if (accept) std::copy(theta.begin(), theta.end(), out);  // copy_if_rejected == false
+  }
+};
+// sampler/hierarchicalsampler.cc:8-81 on the actions acts[top .. L): restrict, one draw of the coarsest-level sampler, two-level
+// steps up, break at the first rejection
+struct HierarchicalO : SamplerO, StepCounters {
+  std::vector<ActionO *> act;                        // act[0] = the sampler's own (finest) level
+  std::vector<std::unique_ptr<TwoLevelStepO>> step;  // step[l]: act[l + 1] -> act[l]
+  std::unique_ptr<HmcSamplerO> coarse;
+  std::vector<std::vector<double>> state;
+  HierarchicalO(const std::vector<ActionO *> &acts, unsigned top, unsigned nt, double dt, uint64_t seed_offset) {
+    for (unsigned l = top; l < acts.size(); ++l) act.push_back(acts[l]);
+    for (unsigned l = 0; l + 1 < act.size(); ++l) step.emplace_back(new TwoLevelStepO(act[l], act[l + 1], seed_offset + 1000003ull * (top + 1) + 7ull * l));
+    for (ActionO *A : act) state.emplace_back(A->M, 0.0);
+    coarse.reset(new HmcSamplerO(act.back(), nt, dt, 0, seed_offset + 1000003ull * (top + 1)));
+  }
+  void draw(double *out) override {
+    const int n = (int)act.size();
+    accept = true;
+    for (int l = 1; l < n; ++l)
+      for (unsigned j = 0; j < act[l]->M; ++j) state[l][j] = state[l - 1][2 * j];
+    for (int l = n - 1; l >= 0; --l) {
+      if (l == n - 1) {
+        coarse->set_state(state[l].data());
+        coarse->draw(state[l].data());
+        accept = accept && coarse->accepted();
+      } else {
+        step[l]->set_state(state[l].data());
+        step[l]->draw(state[l + 1].data(), state[l].data());
+        accept = accept && step[l]->accept;
+      }
+      if (!accept) break;
+    }
+    ++n_total;
+    n_accepted += accept ? 1 : 0;
+    if (accept) std::copy(state[0].begin(), state[0].end(), out);
+  }
+  void set_state(const double *x) override { std::copy(x, x + state[0].size(), state[0].begin()); }
+  bool accepted() const override { return accept; }
+};
+// montecarlo/montecarlomultilevel.cc:71-204 with sampler = 'hierarchical': burn-in, then n_samples Y samples per level (the
+// reference adapts the numbers to a tolerance; fixed here), coarse samples through draw_coarse_sample (:170-190).
+// sub_mode 0: the reference -- ceil(2 tau_int) of the coarse sampler's QoI, re-read on every coarse draw (window k_max);
+// sub_mode n > 0: n draws apart, fixed (experiment).  QoI = QoIXsquared.
+struct MlmcRefO {
+  std::vector<std::unique_ptr<ActionO>> owned;
+  std::vector<ActionO *> act;
+  std::vector<std::unique_ptr<TwoLevelStepO>> step;
+  std::vector<std::unique_ptr<HierarchicalO>> sampler;  // sampler[l]: for act[l + 1]
+  std::vector<StatsO> stats_Y, stats_sampler, stats_fine, stats_coarse;   // Y = fine - coarse part of the QoI, and the parts
+  std::vector<std::vector<double>> phi, phi_coarse;
+  std::vector<double> t_indep;
+  std::vector<unsigned> n_indep, t_sampler;
+  unsigned L, sub_mode;
+  static double xsq(const std::vector<double> &x) {  // qoi/qm/qoixsquared.cc:7-20
+    double s = 0;
+    for (double v : x) s += v * v;
+    return s / x.size();
+  }
+  MlmcRefO(int kind, unsigned M, double T_final, double m0, double mu2, double lambda, double x0, unsigned n_level, unsigned nt, double dt,
+           unsigned window, unsigned sub_mode_, uint64_t seed_offset)
+      : L(n_level), sub_mode(sub_mode_) {
+    for (unsigned l = 0; l < L; ++l) {
+      ActionO *A = (ActionO *)orc_action_1d_impl(kind, M >> l, T_final, m0, mu2, lambda, x0);
+      owned.emplace_back(A);
+      act.push_back(A);
+    }
+    for (unsigned l = 0; l + 1 < L; ++l) {
+      step.emplace_back(new TwoLevelStepO(act[l], act[l + 1], seed_offset + 500009ull * (l + 1)));
+      sampler.emplace_back(new HierarchicalO(act, l + 1, nt, dt, seed_offset));
+      stats_sampler.emplace_back(window);
+    }
+    for (unsigned l = 0; l < L; ++l) {
+      stats_Y.emplace_back(window);
+      stats_fine.emplace_back(window);
+      stats_coarse.emplace_back(window);
+      phi.emplace_back(act[l]->M, 0.0);
+      phi_coarse.emplace_back(act[l]->M, 0.0);
+    }
+    t_indep.assign(L, 0.0);
+    n_indep.assign(L, 0);
+    t_sampler.assign(L, 0);
+  }
+  void draw_coarse_sample(unsigned level, std::vector<double> &x) {  // montecarlomultilevel.cc:170-190
+    StatsO &st = stats_sampler[level - 1];
+    for (;;) {
+      const double need = sub_mode ? (double)sub_mode : std::ceil(2. * st.tau_int());   // re-read every time round, as the while loop does
+      if (!(t_sampler[level - 1] < need)) break;
+      sampler[level - 1]->draw(x.data());
+      st.record(xsq(x));
+      ++t_sampler[level - 1];
+    }
+    t_indep[level - 1] = (n_indep[level - 1] * t_indep[level - 1] + t_sampler[level - 1]) / (1.0 + n_indep[level - 1]);
+    ++n_indep[level - 1];
+    t_sampler[level - 1] = 0;
+  }
+  double sample_Y(int level, bool sub_sample) {
+    if (level == (int)L - 1) {
+      if (sub_sample) draw_coarse_sample(level, phi[level]); else sampler[level - 1]->draw(phi[level].data());
+      return xsq(phi[level]);
+    }
+    if (sub_sample) draw_coarse_sample(level + 1, phi_coarse[level + 1]); else sampler[level]->draw(phi_coarse[level + 1].data());
+    step[level]->draw(phi_coarse[level + 1].data(), phi[level].data());
+    const double qf = xsq(phi[level]), qc = xsq(phi_coarse[level + 1]);
+    if (sub_sample) {
+      stats_fine[level].record(qf);
+      stats_coarse[level].record(qc);
+    }
+    return qf - qc;
+  }
+  // only_level >= 0: that level alone (the levels are independent estimators)
+  void run(unsigned n_burnin, unsigned n_samples, int only_level = -1) {
+    for (unsigned l = 0; l < L; ++l) stats_Y[l].hard_reset();
+    for (int level = (int)L - 1; level >= 0; --level)   // :83-101 (burn-in draws are not sub-sampled)
+      for (unsigned j = 0; j < n_burnin && (only_level < 0 || only_level == level); ++j) stats_Y[level].record(sample_Y(level, false));
+    for (unsigned l = 0; l < L; ++l) stats_Y[l].reset();
+    for (unsigned l = 0; l + 1 < L; ++l) stats_sampler[l].reset();
+    for (int level = (int)L - 1; level >= 0; --level)
+      for (unsigned j = 0; j < n_samples && (only_level < 0 || only_level == level); ++j) stats_Y[level].record(sample_Y(level, true));
+  }
+};
+
 }  // namespace
 
 // =============================================================================================
@@ -1797,10 +1996,7 @@ void orc_neighbours1d(unsigned M, unsigned *out) {  // lattice/lattice1d.cc:12-1
 // Engine seeds: rotoraction.hh:106, quenchedschwingeraction.hh:116, gffaction.hh:182,
 // harmonicoscillatoraction.hh:100 (HO engine only feeds the exact sampler, unused here).
 void *orc_action_1d(int kind, unsigned M, double T_final, double m0, double mu2, double lambda, double x0) {
-  uint64_t seed = kind == ROTOR ? 21172817ull : 124129017ull;
-  ActionO *A = new ActionO((Kind)kind, seed);
-  A->M = M; A->T_final = T_final; A->a = T_final / M; A->m0 = m0; A->mu2 = mu2; A->lambda = lambda; A->x0 = x0;
-  return A;
+  return orc_action_1d_impl(kind, M, T_final, m0, mu2, lambda, x0);
 }
 void *orc_action_gff(int Mt, int Mx, double mass) {  // gffaction.hh:164-185
   ActionO *A = new ActionO(GFF, 2481317ull);
@@ -1832,6 +2028,65 @@ void orc_action_staples(void *h, const double *x, unsigned l, double *tp, double
   int i, j, mu;
   A->g.link_inv(l, i, j, mu);
   A->staples(x, i, j, mu, *tp, *tm);
+}
+
+// ---- reference-order multilevel run (MlmcRefO) and the single-level HMC chain it must agree with -------------------------
+// out[level][8] = mean(Y), variance, tau_int, samples, mean draws between coarse samples (t_indep), acceptance of the level's
+// two-level step, mean of the fine part of Y, mean of its coarse part; acc[level] = acceptance of the hierarchical sampler feeding level `level` (the sampler of act[level + 1];
+// last entry: of the coarsest level's own sampler)
+void orc_mlmc_ref_run(int kind, unsigned M, double T_final, double m0, double mu2, double lambda, double x0, unsigned n_level, unsigned nt,
+                      double dt, unsigned window, unsigned sub_mode, unsigned n_burnin, unsigned n_samples, int only_level, uint64_t seed_offset,
+                      double *out, double *acc) {
+  MlmcRefO R(kind, M, T_final, m0, mu2, lambda, x0, n_level, nt, dt, window, sub_mode, seed_offset);
+  R.run(n_burnin, n_samples, only_level);
+  for (unsigned l = 0; l < n_level; ++l) {
+    if (only_level >= 0 && (int)l != only_level) {
+      for (int q = 0; q < 8; ++q) out[8 * l + q] = 0.0;
+      acc[l] = 0.0;
+      continue;
+    }
+    out[8 * l + 0] = R.stats_Y[l].avg;
+    out[8 * l + 1] = R.stats_Y[l].variance();
+    out[8 * l + 2] = R.stats_Y[l].tau_int();
+    out[8 * l + 3] = R.stats_Y[l].n;
+    out[8 * l + 4] = l + 1 < n_level ? R.t_indep[l] : R.t_indep[n_level - 2];
+    out[8 * l + 5] = l + 1 < n_level ? R.step[l]->p_accept() : 1.0;
+    out[8 * l + 6] = l + 1 < n_level ? R.stats_fine[l].avg : R.stats_Y[l].avg;
+    out[8 * l + 7] = l + 1 < n_level ? R.stats_coarse[l].avg : 0.0;
+    acc[l] = R.sampler[l + 1 < n_level ? l : n_level - 2]->p_accept();
+  }
+}
+// single-level chains of the same action for comparison: HMC (hmcsampler.cc) or the hierarchical sampler ON ITS OWN
+// (hierarchicalsampler.cc: exact by construction -- delayed acceptance from the restricted current state).
+// out = mean, variance, tau_int, samples, acceptance
+void orc_single_level_ref_run(int kind, unsigned M, double T_final, double m0, double mu2, double lambda, double x0, unsigned n_level,
+                              unsigned nt, double dt, unsigned window, unsigned n_burnin, unsigned n_samples, uint64_t seed_offset, double *out) {
+  std::vector<std::unique_ptr<ActionO>> owned;
+  std::vector<ActionO *> act;
+  for (unsigned l = 0; l < n_level; ++l) {
+    owned.emplace_back((ActionO *)orc_action_1d_impl(kind, M >> l, T_final, m0, mu2, lambda, x0));
+    act.push_back(owned.back().get());
+  }
+  std::unique_ptr<SamplerO> S;
+  StepCounters *cnt;
+  if (n_level == 1) {
+    auto *h = new HmcSamplerO(act[0], nt, dt, 0, seed_offset);
+    S.reset(h);
+    cnt = &h->h;
+  } else {
+    auto *h = new HierarchicalO(act, 0, nt, dt, seed_offset);
+    S.reset(h);
+    cnt = h;
+  }
+  StatsO st(window);
+  std::vector<double> x(M, 0.0);
+  for (unsigned j = 0; j < n_burnin; ++j) S->draw(x.data());
+  cnt->reset();
+  for (unsigned j = 0; j < n_samples; ++j) {
+    S->draw(x.data());
+    st.record(MlmcRefO::xsq(x));
+  }
+  out[0] = st.avg; out[1] = st.variance(); out[2] = st.tau_int(); out[3] = st.n; out[4] = cnt->p_accept();
 }
 
 // rejection samplers with the reference engine of a fresh RefRng (seeded) -- for distribution tests

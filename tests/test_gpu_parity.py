@@ -590,7 +590,10 @@ def test_lattice_sweeps_match_oracle(gpu_ops, orc, kind, Mt, Mx, kw, B, fuse):
 
 
 @pytest.mark.parametrize("Mt,Mx,B,beta", [(64, 64, 2, 1.0), (128, 128, 2, 1.0), (192, 128, 1, 2.0), (128, 256, 2, 3.0),
-                                          (64, 32, 2, 1.0), (192, 96, 1, 1.0)])   # the last two: 64 x 32 tiles
+                                          (64, 32, 2, 1.0), (192, 96, 1, 1.0),   # the last two: 64 x 32 tiles
+                                          # r05: lattices no tile divides (masked edge tiles): 64 x 32 tiles + heat-bath launch
+                                          # (an extent below 128), the one-launch draw on 64 x 64 tiles (both >= 128)
+                                          (130, 70, 2, 1.0), (70, 130, 1, 1.0), (200, 136, 1, 1.0), (130, 198, 2, 2.5)])
 def test_closed_form_overrelaxation_matches_oracle(gpu_ops, orc, Mt, Mx, B, beta):
     """schwinger_perm_kernel / schwinger_perm_heat_kernel (K <= 10 overrelaxation sweeps per launch as ONE fixed permutation
     of the plaquettes; the default where 64 x 64 tiles divide the lattice) at every depth the register-block kernels do not
@@ -629,7 +632,8 @@ def test_closed_form_overrelaxation_matches_oracle(gpu_ops, orc, Mt, Mx, B, beta
 
 @pytest.mark.parametrize("Mt,Mx,B,beta", [(128, 128, 3, 1.0), (192, 128, 2, 2.0), (256, 128, 2, 0.3), (1024, 1024, 2, 1.0),
                                           # r04: beyond 2 beta = 4 the fused launch draws from the wrapped-Cauchy envelope
-                                          (128, 192, 2, 3.0), (256, 256, 2, 40.0)])
+                                          (128, 192, 2, 3.0), (256, 256, 2, 40.0),
+                                          (200, 136, 2, 1.0), (130, 262, 1, 1.0)])   # r05: masked edge tiles of the fused launch
 def test_overrelaxation_and_heat_bath_in_one_launch_equal_two_launches(gpu_ops, Mt, Mx, B, beta):
     """schwinger_or_heat_kernel<K> (the last K <= 5 overrelaxation sweeps of a draw, the heat-bath sweep behind them and
     the QoI in one launch) against the same draw with the heat bath in a launch of its own (MLMCPI_OR_HEAT=split): states
@@ -1114,7 +1118,8 @@ def test_schwinger_gaussian_cfa_twolevel_step_matches_oracle(gpu_ops, orc, Mt, M
         theta = step.theta.cpu().numpy().copy()
 
 
-@pytest.mark.parametrize("Mt,Mx,B,n_or,n_hb", [(1024, 1024, 2, 2, 1), (64, 64, 3, 0, 1), (48, 20, 2, 3, 2), (128, 64, 2, 1, 1)])
+@pytest.mark.parametrize("Mt,Mx,B,n_or,n_hb", [(1024, 1024, 2, 2, 1), (64, 64, 3, 0, 1), (48, 20, 2, 3, 2), (128, 64, 2, 1, 1),
+                                               (200, 136, 2, 10, 1), (1000, 1000, 1, 10, 1), (130, 70, 2, 10, 1)])   # r05: masked edge tiles
 def test_fused_qoi_equals_separate_evaluation(gpu_ops, Mt, Mx, B, n_or, n_hb):
     """mlmcpi_lattice_sweep_draw_qoi: the QoI summed inside the draw's last launch equals the stand-alone QoI kernels on
     the same result (average plaquette and Q^2 / 4 pi^2), and the state is the one the plain draw produces, bit for bit;
