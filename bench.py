@@ -678,8 +678,12 @@ def main():
             units_per_step = sum(exchange.allreduce_sum_host([float(units_rank)]))
         fuse = 1
 
+        hier_work = {"start": None}   # site-steps at the first timed step: the draws between coarse samples follow the running tau_int
+
         def step(record):
             if record:
+                if hier_work["start"] is None:
+                    hier_work["start"] = (sum(lv.site_steps for lv in est.levels.values()), {l: lv.n_sub_sum for l, lv in est.levels.items()})
                 e0, e1 = ev(), ev()
                 e0.record()
             est.pass_(1)
@@ -724,6 +728,13 @@ def main():
         acc_of = lambda: acc
 
     elapsed = time_steps(torch, dist, world, step, a.steps, a.warmup)
+    if a.workload == "quartic_mlmc_hier":
+        # the work actually done in the timed steps (the sub-sampling follows the running tau_int)
+        done = sum(lv.site_steps for lv in est.levels.values()) - hier_work["start"][0]
+        units_per_step = done / a.steps
+        if world > 1:
+            units_per_step = sum(exchange.allreduce_sum_host([float(units_per_step)]))
+        sub = {l: (lv.n_sub_sum - hier_work["start"][1][l]) / a.steps for l, lv in est.levels.items()}
 
     # (side measurements on one rank only: at N > 1 they would only stagger the ranks in front of the statistics all-reduce)
     if a.workload == "schwinger" and world == 1 and (a.probes or (not a.no_extra_points and a.chains == 0)):
@@ -892,7 +903,7 @@ def main():
                     "against single-level HMC then checks that initialisation, not the hierarchical sampler, and 'epsilon "
                     "reached' comes from independent frozen chains.  See the T_final = M_lat / 32 line for moving chains")
             launch_ms = ms(events) / a.steps
-            floor = 16.0 * sum(lv.n_sub * lv.B * lv.sampler.acts[-1].M for lv in est.levels.values())  # coarsest states, once per trajectory
+            floor = 16.0 * sum(sub[l] * lv.B * lv.sampler.acts[-1].M for l, lv in est.levels.items())  # coarsest states, once per trajectory
             result["roofline"] = register_resident_roofline(
                 "hmc_trajectory_kernel<1,R> (coarsest-level HMC of every hierarchical draw, M_lat = %d: R = 16 sites per lane, 2 waves per chain at 2048 chains; > 95 %% of the site-steps)" % (size >> 4), launch_ms, floor,
                 32.0 * units_per_step / world, pmc_entry("kernels_valu_busy", workload=a.workload, size=size, chains=B),

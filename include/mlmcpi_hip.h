@@ -397,6 +397,13 @@ int mlmcpi_schwinger_beta_coarse_nonperturbative(double beta, uint32_t n_plaq, i
  * d_acc holds, per chain, the packed sums [n, sum q, sum q^2, sum q^3, sum q^4] that the
  * cross-rank reduction (one RCCL all-reduce of B*5 doubles) combines; see DESIGN.md. */
 int mlmcpi_stats_accumulate(double *d_acc, const double *d_q, uint32_t B, void *stream);
+/* Statistics::record_sample WITH the autocorrelation window (common/statistics.cc:4-27: running average, running averages
+ * S_k of Q_j Q_{j-k} for k < window over a deque of the last `window` values), batched: d_state[B][2 * window + 3] =
+ * per chain [n, average, S_0 .. S_{window-1}, head, ring[window]], zero-initialised by the caller.  What
+ * MonteCarloMultiLevel::draw_coarse_sample (montecarlo/montecarlomultilevel.cc:170-190) re-reads on every coarse draw:
+ * tau_int = max(1, 1 + 2 sum_{k>=1} (1 - k/n)(S_k - avg^2)/(S_0 - avg^2)) (statistics.cc:38-61), computed by the caller
+ * from the state (per chain, or with the autocovariances averaged over the chains of a batch). */
+int mlmcpi_stats_window_record(double *d_state, const double *d_q, uint32_t B, uint32_t window, void *stream);
 
 /* ---- test hooks: raw RNG streams, single draws (used by parity tests only) -------------------- */
 int mlmcpi_test_philox(const uint32_t *ctr4, const uint32_t *key2, uint32_t *out4);

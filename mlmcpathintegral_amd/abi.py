@@ -112,6 +112,7 @@ SIGNATURES = {
     "mlmcpi_lattice_hmc_workspace_bytes": (_i, [_LA, _u32, C.POINTER(_sz)]),
     "mlmcpi_lattice_hmc_draw": (_i, [_LA, _vp, _u32, _u32, _d, _u32, _u64, _u32, _u32, _vp, _vp, _vp, _vp]),
     "mlmcpi_stats_accumulate": (_i, [_vp, _vp, _u32, _vp]),
+    "mlmcpi_stats_window_record": (_i, [_vp, _vp, _u32, _u32, _vp]),
     "mlmcpi_test_philox": (_i, [_vp, _vp, _vp]),
     "mlmcpi_test_random": (_i, [_u64, _u32, _u32, _u32, _u32, _u32, _vp, _vp]),
     "mlmcpi_test_expcos": (_i, [_u64, _u32, _u32, _d, _vp, _vp, _u32, _vp, _vp]),
@@ -139,6 +140,8 @@ def load():
                               "(run `make -C mlmcpathintegral_amd/csrc`); there is no CPU fallback")
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
+            if _VARIANT and not hasattr(lib, name):
+                continue  # an experiment build of older sources (A/B tools only): entry points added since are absent
             f = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
             f.restype, f.argtypes = res, args
         _lib = lib

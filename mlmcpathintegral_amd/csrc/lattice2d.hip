@@ -1239,19 +1239,36 @@ __device__ __forceinline__ void perm_sweeps(double *plane, const double2 *__rest
   const uint32_t oi0 = (i0 + Mt - RING) % Mt, oj0 = (j0 + Mx - RING) % Mx;
   const PermTasks<NT, RING, TH> tasks;
   // the links of a half as they are now (HR, RING, 2 K and the tile origins are even: output parity = plane parity = lattice parity)
-  auto load_theta = [&](int h, double2 (&th)[NV]) {
+  // (32-bit byte offsets from the chain's base pointer -- the host admits lattices of less than 2^28 vertices to these
+  // kernels --, wraps by the unsigned-minimum trick: v >= n ? v - n : v = min(v, v - n); twice more for extents below
+  // the output window's, a uniform branch.  The 64-bit pointer form this replaces cost 30 vector instructions per task.)
+  const char *const src_b = reinterpret_cast<const char *>(src);
+  const bool small_lattice = Mx < (uint32_t)(2 * HR + 2) || Mt < (uint32_t)(PG::OW + 2);   // (uniform: two copies of the loop)
+  auto load_theta_of = [&](int h, double2 (&th)[NV], auto small) {
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
       if (!tasks.valid(k)) continue;
       uint32_t r, c;
       tasks.coords(k, r, c);
-      const uint32_t gr = wrap_add(oj0, r + h * HR, Mx), gc = wrap_add(oi0, c, Mt);
-      const double2 *v = src + ((size_t)gr * Mt + gc);
-      if (!tasks.is_mu1(k))
-        th[k] = make_double2(v->x, (gr + 1 == Mx ? v - (size_t)gr * Mt : v + Mt)->x);
-      else
-        th[k] = make_double2(v->y, (gc + 1 == Mt ? v - gc : v + 1)->y);
+      uint32_t gr = oj0 + r + h * HR, gc = oi0 + c;
+      gr = min(gr, gr - Mx);
+      gc = min(gc, gc - Mt);
+      if ((bool)small) {
+        gr = min(gr, gr - Mx); gr = min(gr, gr - Mx);
+        gc = min(gc, gc - Mt); gc = min(gc, gc - Mt);
+      }
+      const uint32_t o = (gr * Mt + gc) * 16u;
+      if (!tasks.is_mu1(k)) {
+        const uint32_t o2 = gr + 1 == Mx ? o - gr * Mt * 16u : o + Mt * 16u;
+        th[k] = make_double2(*reinterpret_cast<const double *>(src_b + o), *reinterpret_cast<const double *>(src_b + o2));
+      } else {
+        const uint32_t o2 = gc + 1 == Mt ? o - gc * 16u : o + 16u;
+        th[k] = make_double2(*reinterpret_cast<const double *>(src_b + o + 8u), *reinterpret_cast<const double *>(src_b + o2 + 8u));
+      }
     }
+  };
+  auto load_theta = [&](int h, double2 (&th)[NV]) {
+    if (small_lattice) load_theta_of(h, th, std::true_type{}); else load_theta_of(h, th, std::false_type{});
   };
   // what K sweeps add to them
   auto gather = [&](int h, double2 (&d)[NV]) {
@@ -2241,6 +2258,33 @@ __global__ void __launch_bounds__(256) lattice_init_kernel(int kind, uint32_t n,
   }
 }
 
+// Statistics::record_sample with its autocorrelation window (common/statistics.cc:4-27), one chain per thread: per chain
+// [n, a1 = running average, S_0 .. S_{W-1} = running averages of Q_j Q_{j-k}, head, ring of the last W values].  The same
+// recurrences as the reference: a1 <- ((n - 1) a1 + Q) / n; S_k <- ((N_k - 1) S_k + Q Q_{-k}) / N_k, N_k = n - k, over the k
+// the window holds.  tau_int = max(1, 1 + 2 sum_{k >= 1} (1 - k / n) (S_k - a1^2) / (S_0 - a1^2)) is left to the caller
+// (:38-61): the multilevel driver reads it between draws (montecarlomultilevel.cc:170-190).
+__global__ void stats_window_record_kernel(double *__restrict__ state, const double *__restrict__ q, uint32_t B, uint32_t W) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  double *st = state + (size_t)b * (2 * W + 3);
+  double *S = st + 2, *ring = st + 3 + W;
+  const double Q = q[b];
+  const double n = st[0] + 1.0;
+  uint32_t head = (uint32_t)st[2 + W];   // slot of the most recent value
+  head = head + 1 == W ? 0 : head + 1;
+  ring[head] = Q;
+  st[2 + W] = (double)head;
+  st[0] = n;
+  st[1] = ((n - 1.0) * st[1] + Q) / n;
+  const uint32_t filled = n < (double)W ? (uint32_t)n : W;
+  uint32_t slot = head;
+  for (uint32_t k = 0; k < filled; ++k) {
+    const double Nk = n - (double)k;
+    S[k] = ((Nk - 1.0) * S[k] + Q * ring[slot]) / Nk;
+    slot = slot == 0 ? W - 1 : slot - 1;
+  }
+}
+
 // packed per-chain sums for the cross-rank reduction: [n, sum q, sum q^2, sum q^3, sum q^4]
 __global__ void stats_accumulate_kernel(double *__restrict__ acc, const double *__restrict__ q, uint32_t B) {
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2630,7 +2674,7 @@ static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, doub
   // computed like any halo, not written.  64 x 64 tiles where they divide Mx and wherever the fused launch applies (both
   // extents >= 128: its image must not wrap onto itself), else 64 x 32 (the heat bath is then a launch of its own);
   // lattices that would more than double the work through padding stay with the sweep-by-sweep kernels.
-  const bool perm_shape = schw && act->Mt >= 64 && act->Mx >= 32;
+  const bool perm_shape = schw && act->Mt >= 64 && act->Mx >= 32 && (uint64_t)act->Mt * act->Mx < (1ull << 28);   // (32-bit byte offsets)
   const bool perm64 = perm_shape && (act->Mx % 64 == 0 || (act->Mt >= 128 && act->Mx >= 128));
   const uint32_t perm_th = perm64 ? 64 : 32, perm_tx = (act->Mt + 63) / 64, perm_ty = (act->Mx + perm_th - 1) / perm_th;
   const bool perm = perm_shape && !tune.or_block && !tune.or_lds && !tune.or_patch && !tune.tile_w &&
@@ -3067,6 +3111,13 @@ int mlmcpi_lattice_site_updates(const mlmcpi_lattice_action *act, double *d_stat
     hipLaunchKernelGGL((lattice_site_update_kernel<false>), grid, block, 0, as_stream(stream), act->Mt, act->Mx, gff_mu2(*act), d_state,
                        B, d_sites, n, site, (int)heat, key, vs_table);
   MLMCPI_LAUNCH_CHECK("lattice_site_update_kernel");
+  return MLMCPI_OK;
+}
+
+int mlmcpi_stats_window_record(double *d_state, const double *d_q, uint32_t B, uint32_t window, void *stream) {
+  MLMCPI_REQUIRE(d_state && d_q && B > 0 && window > 0 && window <= 1024, "bad arguments");
+  hipLaunchKernelGGL(stats_window_record_kernel, dim3((B + 255) / 256), dim3(256), 0, as_stream(stream), d_state, d_q, B, window);
+  MLMCPI_LAUNCH_CHECK("stats_window_record_kernel");
   return MLMCPI_OK;
 }
 

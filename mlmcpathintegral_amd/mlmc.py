@@ -153,13 +153,28 @@ class HierPathLevel(PathLevel):
         self.step_accepted = torch.zeros(B, dtype=torch.int64, device="cuda")
         self.window, self.n_sub = window, 1
         self.tau_coarse = 1.0
+        # draw_coarse_sample (montecarlomultilevel.cc:170-190) re-reads ceil(2 tau_int) of the coarse sampler's QoI on every
+        # coarse draw.  running = True (the default, r05): the same here -- every sampler draw is recorded in windowed
+        # statistics on the device (mlmcpi_stats_window_record) and the number of draws up to the next coarse sample is
+        # re-evaluated before each sample, with the autocovariances averaged over the chains of the batch (the reference
+        # has one chain; a batch shares one count, so that its chains stay in step).  running = False: the count found in
+        # thermalise() stays (r03 / r04 behaviour).
+        self.running = True
+        self.wstats = ops.stats_window_state(B, window)
+        self.n_sub_sum = 0
+        self._tau_ready = self._tau_queued = None
 
     def thermalise(self, n, dts=None):
         self.sampler.thermalise(n, 24, dt_top=None if dts is None else dts[self.sampler.top])
         # tau_int of the coarse sampler's QoI: the reference's windowed estimator (common/statistics.cc:38-61:
         # 1 + 2 sum_{k < window} (1 - k/n) C_k / C_0), with the autocovariances C_k averaged over all chains of the batch
         n_series = 8 * self.window   # length of the tau_int series; `n` stays the burn-in length the caller asked for
-        q = torch.stack([self.qoi(self.sampler.draw(count=False)).clone() for _ in range(n_series)])   # [n_series, B]
+        qs = []
+        for _ in range(n_series):
+            qv = self.qoi(self.sampler.draw(count=False)).clone()
+            ops.stats_window_record(self.wstats, qv)   # (the running estimate starts from this series)
+            qs.append(qv)
+        q = torch.stack(qs)   # [n_series, B]
         d = q - q.mean()
         c0 = float((d * d).mean())
         tau = 1.0
@@ -182,9 +197,37 @@ class HierPathLevel(PathLevel):
             for _ in range(16):
                 self.step.draw(self.sampler.draw(count=False))
 
+    def _draws_to_next_sample(self):
+        """ceil(2 tau_int) with the tau_int read behind the sample before the last one: the value travels to the host
+        without stalling the stream (pinned buffer + event), so the levels of a pass keep overlapping; deterministic (the
+        lag is exactly one sample; the estimate moves by O(1 / n) per draw)."""
+        if not self.running:
+            return self.n_sub
+        ready, self._tau_ready = self._tau_ready, self._tau_queued
+        if ready is not None:
+            ev, buf = ready
+            ev.synchronize()
+            self.tau_coarse = max(1.0, float(buf[0]))
+        n = max(1, int(-(-2.0 * self.tau_coarse // 1)))            # ceil(2 tau_int), montecarlomultilevel.cc:173
+        n = min(n, 2 * (1 + 2 * self.window))                       # (what a stationary series can give with this window)
+        return max(1, int(round(n * getattr(self, "sub_factor", 1.0))))
+
+    def _queue_tau(self):
+        buf = torch.empty(1, dtype=torch.float64, pin_memory=True)
+        buf.copy_(ops.stats_window_tau_int(self.wstats, pooled=True).reshape(1), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._tau_queued = (ev, buf)
+
     def sample(self):
+        self.n_sub = self._draws_to_next_sample()
         for _ in range(self.n_sub):
             x = self.sampler.draw()
+            if self.running:
+                ops.stats_window_record(self.wstats, self.qoi(x))
+        if self.running:
+            self._queue_tau()
+        self.n_sub_sum += self.n_sub
         self.site_steps += self.n_sub * self.sampler.cost * self.B
         if self.coarsest:
             y = self.qoi(x)

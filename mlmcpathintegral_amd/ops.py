@@ -374,6 +374,34 @@ def stats_accumulate(acc, q):
     abi.call("mlmcpi_stats_accumulate", _p(acc), _p(q), q.shape[0], _stream())
 
 
+def stats_window_state(B, window, device="cuda"):
+    """zeroed state of mlmcpi_stats_window_record for B chains"""
+    return torch.zeros((B, 2 * window + 3), dtype=torch.float64, device=device)
+
+
+def stats_window_record(state, q):
+    """Statistics::record_sample with the autocorrelation window, one chain per row of `state`"""
+    window = (state.shape[1] - 3) // 2
+    abi.call("mlmcpi_stats_window_record", _p(state), _p(q), q.shape[0], window, _stream())
+
+
+def stats_window_tau_int(state, pooled=True):
+    """Statistics::tau_int (common/statistics.cc:38-61) from the windowed state: per chain, or -- pooled -- with the
+    autocovariances averaged over the chains of the batch first (one number for the batch)."""
+    W = (state.shape[1] - 3) // 2
+    n = state[:, 0:1]
+    a1 = state[:, 1:2]
+    cov = state[:, 2:2 + W] - a1 * a1                                  # [B, W]
+    k = torch.arange(W, dtype=torch.float64, device=state.device)[None, :]
+    wgt = 1.0 - k / torch.clamp(n, min=1.0)   # (the reference sums ALL k < window, also those the series has not reached: statistics.cc:86-88)
+    if pooled:   # a 0-dim device tensor: no synchronisation here (the multilevel driver reads it one sample later)
+        c = (cov * wgt).mean(dim=0)
+        tau = 1.0 + 2.0 * c[1:].sum() / c[0]
+        return torch.clamp(torch.nan_to_num(tau, nan=1.0, posinf=1.0, neginf=1.0), min=1.0)
+    tau = 1.0 + 2.0 * (cov * wgt)[:, 1:].sum(dim=1) / cov[:, 0]
+    return torch.clamp(torch.nan_to_num(tau, nan=1.0), min=1.0)
+
+
 # ---- test hooks -------------------------------------------------------------------------------------
 def test_random(seed, chain, step, purpose, sub, n, device="cuda"):
     out = torch.empty((n, 4), dtype=torch.float64, device=device)

@@ -435,3 +435,77 @@ def test_schwinger_headline_sampler_matches_cpu_chain(gpu_ops, orc):
     zcheck("headline sampler 64^2: <plaquette> GPU chain vs CPU chain", mp, ep, rp.mean(), batch_err(rp), gate=HEADLINE_SIGMA)
     zcheck("headline sampler 64^2: Q^2/(4 pi^2) GPU chain vs CPU chain", mq, eq, rq.mean(), batch_err(rq), gate=HEADLINE_SIGMA)
     zcheck("headline sampler 64^2: <plaquette> GPU chain vs I1(1)/I0(1)", mp, ep, 0.44638996)
+
+
+def test_windowed_statistics_on_the_device_equal_the_oracle(gpu_ops, orc):
+    """mlmcpi_stats_window_record (Statistics::record_sample with its autocorrelation window, one chain per thread) against
+    the oracle's Statistics restatement (itself bit for bit the compiled reference, tests/test_abi_host.py): average,
+    variance and tau_int per chain after 7, 20 and 150 samples of correlated series, window 20 and 5."""
+    L = orc.lib()
+    rng = np.random.default_rng(5)
+    for window in (20, 5):
+        B, n = 6, 150
+        series = np.zeros((n, B))
+        for b in range(B):   # AR(1) with different correlations
+            rho, v = 0.15 * b, 0.0
+            for j in range(n):
+                v = rho * v + rng.normal()
+                series[j, b] = 0.3 + v
+        state = gpu_ops.stats_window_state(B, window)
+        handles = [L.orc_stats_new(window) for _ in range(B)]
+        for j in range(n):
+            gpu_ops.stats_window_record(state, torch.tensor(series[j], dtype=torch.float64, device="cuda"))
+            for b in range(B):
+                L.orc_stats_record(handles[b], np.ascontiguousarray(series[j, b:b + 1]), 1)
+            if j + 1 in (7, 20, 150):
+                st = state.cpu().numpy()
+                tau = gpu_ops.stats_window_tau_int(state, pooled=False).cpu().numpy()
+                for b in range(B):
+                    out = np.zeros(6)
+                    L.orc_stats_get(handles[b], out)   # average, variance, variance_error, tau_int, error, samples
+                    nn, a1, S0 = st[b, 0], st[b, 1], st[b, 2]
+                    assert nn == j + 1 == out[5]
+                    assert abs(a1 - out[0]) < 1e-13
+                    assert abs(nn / (nn - 1.0) * (S0 - a1 * a1) - out[1]) < 1e-12
+                    assert abs(tau[b] - out[3]) < 1e-10, (window, j, b, tau[b], out[3])
+        for h in handles:
+            L.orc_stats_free(h)
+
+
+def test_device_reproduces_the_bias_of_the_reference_scheme_at_low_hierarchical_acceptance(gpu_ops):
+    """VERDICT r04 item 4 / ADVICE r04 (medium).  The multilevel estimator of the reference feeds its two-level steps with
+    coarse samples taken ceil(2 tau_int) draws of a HierarchicalSampler apart (montecarlomultilevel.cc:170-190).  When
+    that sampler accepts rarely (12 % here) its sojourn times are long-tailed, consecutive coarse samples are not
+    independent, and the two-level chain -- exact for independent proposals -- is BIASED: the reference-order restatement
+    in the oracle (MlmcRefO, mt19937_64, sequential; tools/exp_hier_bias.py, profiles/r05_hier_bias_reference_order_level0.json),
+    quartic double well, 3 levels 1024 / 512 / 256 sites, T = 256, 8 x 150000 samples, finds for level 0
+        fine part  <x^2> = 0.585904 +- 0.000189   against single-level HMC 0.591391 +- 0.000054   (-27.9 sigma)
+        coarse part        0.568512 +- 0.000115   against HMC on 512 sites 0.568467 +- 0.000041   (+0.4 sigma: the sampler is exact)
+        Y_0              = 0.017392 +- 0.000102   against 0.022924 expected                        (-45 sigma).
+    Here: the same level on the device (Philox streams, multicolour order of nothing -- 1-D paths --, running tau_int pooled
+    over the batch) lands on the ORACLE's biased value, not on the unbiased one: the device composition is the reference's."""
+    from mlmcpathintegral_amd import abi, mlmc
+    par = dict(lam=1.0, x0=1.0)
+    M0, T, B = 1024, 256.0, 384
+    est = mlmc.PathMLMC(abi.QUARTIC, M0, T, 3, B=B, nt=100, dt0=0.05, seed=SEED + 11, params=par, hierarchical=True, dt_coarse=0.1)
+    lv = est.levels[0]
+    lv.thermalise(300, est.dts)
+    fine_part, coarse_part = [], []
+    n_samples = 260
+    for _ in range(n_samples):
+        y = lv.sample()
+        fine_part.append(gpu_ops.qoi_xsquared(lv.step.theta).clone())
+        coarse_part.append(fine_part[-1] - y)
+    f, ef = chain_mean_and_error(torch.stack(fine_part[20:]))
+    c, ec = chain_mean_and_error(torch.stack(coarse_part[20:]))
+    hier_acc = lv.sampler.p_accept()
+    two_acc = float(lv.step_accepted.double().mean()) / max(1, lv.n_draws)
+    print(f"device level 0: fine part {f:.6f} +- {ef:.6f}, coarse part {c:.6f} +- {ec:.6f}, draws between coarse samples "
+          f"{lv.n_sub_sum / n_samples:.1f}, hierarchical acceptance {hier_acc}, two-level acceptance {two_acc:.3f}")
+    assert 0.05 < min(hier_acc.values()) < 0.25 and 0.3 < two_acc < 0.6            # the regime of the oracle run (0.126, 0.449)
+    assert 30 < lv.n_sub_sum / n_samples < 60                                      # the oracle: 44.2
+    zcheck(_where() + ": coarse part vs single-level HMC on 512 sites (the hierarchical sampler is exact)", c, ec, 0.5684667, 0.0000407)
+    zcheck(_where() + ": fine part vs the reference-order oracle's (biased) value", f, ef, 0.5859039, 0.0001892)
+    z_unbiased = (f - 0.5913911) / math.hypot(ef, 0.0000538)
+    print(f"[z] fine part vs single-level HMC on 1024 sites: z = {z_unbiased:+.2f} (the reference scheme's bias: -27.9 sigma in the oracle run)")
+    assert z_unbiased < -4.0, "the two-level chain fed by the sub-sampled hierarchical sampler should show the scheme's bias"
