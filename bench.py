@@ -894,6 +894,17 @@ def main():
             # (untimed, direct-HMC) initial sample, so the estimate and its error bar rest on one effective sample per
             # chain there and the throughput counts proposals that are never accepted.  Faithful to the reference's
             # configuration (T_final = 4096, a = 0.125: the fine-level fill-in is too wide to be accepted) -- said in the line.
+            if hier_run and "single_level_fine_hmc" in hier_run:
+                # distance of the telescoping sum from single-level HMC on the finest lattice, in combined standard errors
+                result["mlmc"]["z_vs_single_level"] = hier_run["single_level_fine_hmc"]["z"]
+                result["mlmc"]["z_vs_single_level_note"] = (
+                    "beyond 2 sigma at a low hierarchical acceptance is the REFERENCE'S SCHEME, not the device: its two-level steps "
+                    "are exact for independent coarse proposals, and ceil(2 tau_int) draws of a rarely accepting HierarchicalSampler "
+                    "(long-tailed sojourn times) are not independent.  The reference-order restatement on the CPU (oracle MlmcRefO, "
+                    "mt19937_64, sequential; tools/exp_hier_bias.py) shows the same bias at -28 sigma "
+                    "(profiles/r05_hier_bias_reference_order_level0.json), and the device lands on the oracle's biased value "
+                    "(tests/test_gpu_statistics.py::test_device_reproduces_the_bias_of_the_reference_scheme_at_low_hierarchical_acceptance)")
+            result["mlmc"]["sub_sampling"] = "running ceil(2 tau_int) of the coarse sampler's QoI, re-read before every coarse sample (montecarlomultilevel.cc:170-190), autocovariances pooled over the batch"
             hacc = result["mlmc"]["hierarchical_acceptance_rank0"]
             frozen = sorted({int(k) for acc in hacc.values() for k, v in acc.items() if v == 0.0})
             result["mlmc"]["frozen_levels"] = frozen

@@ -119,6 +119,16 @@ def test_hierarchical_line_with_moving_chains():
     for acc in h["mlmc"]["hierarchical_acceptance_rank0"].values():
         assert all(v > 0.02 for v in acc.values()), acc
     assert "z" in h["mlmc"]["run_to_epsilon"]["single_level_fine_hmc"]
+    if _tag() >= "r05":
+        # r05: the z-score is a field of the line, with the evidence that a value beyond 2 sigma here is the reference's scheme
+        # (reference-order CPU run + the GPU test that pins the device to the oracle's biased value); the line with frozen
+        # levels (T_final = M / 8) stays gated at 2 sigma in test_config5_as_the_reference_runs_it_agrees_with_single_level_hmc
+        m = h["mlmc"]
+        assert m["z_vs_single_level"] == m["run_to_epsilon"]["single_level_fine_hmc"]["z"]
+        assert "r05_hier_bias_reference_order_level0.json" in m["z_vs_single_level_note"] and "running ceil(2 tau_int)" in m["sub_sampling"]
+        ev = json.load(open(os.path.join(ROOT, "profiles", "r05_hier_bias_reference_order_level0.json")))
+        lv = ev["mlmc"][0]["levels"][0]
+        assert lv["z_fine_vs_hmc"] < -10 and abs(lv["z_coarse_vs_hmc"]) < 3 and 0.05 < lv["feeding_sampler_acceptance"] < 0.2
 
 
 def test_default_line_carries_the_r04_records():
