@@ -283,6 +283,9 @@ def fast_path_cliff(torch, abi, ops, a, rank, headline_rate):
             ("64 x 64", "schwinger", 64, 64, 1.0, 4096,
              "closed-form overrelaxation launch + generic heat-bath kernel (one 64 x 64 tile is the lattice: the fused "
              "launch's image would wrap around it twice)"),
+            ("gff 1000 x 1000 (no tile divides it)", "gff", 1000, 1000, None, 256,
+             "r05: gff_or_block_kernel<5, 32> + gff_or_heat_kernel<5, 32> on 32 x 32 tiles with masked edge tiles (1.05 x the lattice's "
+             "work); r04: generic sweep kernels"),
             ("gff 96 x 96", "gff", 96, 96, None, 8192,
              "gff_or_block_kernel<5, 32> + gff_or_heat_kernel<5, 32>: register blocks on 32 x 32 tiles (r04; generic tiles before: 339 G/s)")):
         act = abi.lattice_action(abi.SCHWINGER, Mt, Mx, beta=beta) if kind == "schwinger" else abi.lattice_action(abi.GFF, Mt, Mx, mass=10.0)

@@ -1186,7 +1186,13 @@ struct PermTasks {
       uint32_t q = q0 + dq, cc = c0 + dc;
       if (cc >= (uint32_t)OW) { cc -= OW; ++q; }
       r = 2 * q;
+#ifndef MLMCPI_PERM_LANES_BY_COLUMN
+      // the first OW / 2 tasks of a row pair take the even columns, the rest the odd ones: a 32-lane group of a gather read
+      // stays inside one quadrant of the plane, contiguous banks (r05, same-box A/B: 0.7703 against 0.7747 ms with c = cc)
+      c = cc < (uint32_t)(OW / 2) ? 2 * cc : 2 * (cc - OW / 2) + 1;
+#else
       c = cc;
+#endif
     } else {            // t - NT0 = (q1 + dq) OW2 + c1 + dc, dq possibly negative
       const int off = k * NT - NT0, dq = off >= 0 ? off / OW2 : -((-off + OW2 - 1) / OW2), dc = off - dq * OW2;   // 0 <= dc < OW2
       uint32_t q = q1 + (uint32_t)dq, cc = c1 + (uint32_t)dc;
@@ -1907,7 +1913,10 @@ __global__ void __launch_bounds__((GffBlockGeom<K, T>::NT))
     for (int i = 0; i < 2; ++i) {
       const double2 w = stage[64 * i + lane];
       const int r = ur[i] + c;
-      if (uq[i] >= 0 && r >= 0 && r < TH) *(double2 *)(dst + (size_t)(j0 + r) * Mt + (i0 + uq[i])) = w;
+      // (r05: an edge tile of a lattice the tiles do not divide reaches beyond it -- periodic images of sites other tiles
+      // own, computed like any halo, not written; Mt is even, so a pair lies inside or outside as a whole)
+      if (uq[i] >= 0 && r >= 0 && r < TH && j0 + (uint32_t)r < Mx && i0 + (uint32_t)uq[i] < Mt)
+        *(double2 *)(dst + (size_t)(j0 + r) * Mt + (i0 + uq[i])) = w;
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -2015,6 +2024,7 @@ __global__ void __launch_bounds__((GffHeatGeom<K, T>::NT), 4)
   double acc[1] = {0.0};
   double *dst = out + (size_t)b * Mt * Mx;
   for_region<NT>(TH, TW, [&](uint32_t r, uint32_t c) {
+    if (j0 + r >= Mx || i0 + c >= Mt) return;   // (the part of an edge tile beyond the lattice: see gff_or_block_kernel)
     const double v = phi[(r + HB) * bw + (c + HB)];
     dst[(size_t)(j0 + r) * Mt + (i0 + c)] = v;
     if (qoi_op) acc[0] += v * v;
@@ -2659,8 +2669,12 @@ static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, doub
   const bool schw = act->kind == MLMCPI_SCHWINGER;
   // GFF lattices that 32 x 32 tiles divide and 64 x 64 ones do not (or that are below 128, where the 64-tile fused launch
   // does not apply): the register-block kernels on 32 x 32 tiles, same launch plan
-  const bool gff_blocks32 = !schw && !tune.or_lds && !tune.or_patch && !tune.tile_w && act->Mt % 32 == 0 && act->Mx % 32 == 0 &&
-                            act->Mt >= 64 && act->Mx >= 64 && !(or_blocks && act->Mt >= 128 && act->Mx >= 128);
+  // (r05: also lattices no tile divides -- edge tiles computed whole and written in part -- unless the padding would more
+  // than double the work)
+  const uint32_t g32_tx = (act->Mt + 31) / 32, g32_ty = (act->Mx + 31) / 32;
+  const bool gff_blocks32 = !schw && !tune.or_lds && !tune.or_patch && !tune.tile_w && act->Mt >= 64 && act->Mx >= 64 &&
+                            !(or_blocks && act->Mt >= 128 && act->Mx >= 128) &&
+                            (uint64_t)g32_tx * g32_ty * 1024 <= (uint64_t)2 * act->Mt * act->Mx + (uint64_t)act->Mt * act->Mx / 5;
   // One chain (at most one workgroup of the fused launch per CU: nothing to overlap a second launch's load and store
   // phases with): the whole draw in ONE launch of schwinger_or_heat_kernel<n_overrelax, wide> while its halo fits a
   // workgroup (n_overrelax <= 10) -- the library default only; a caller's `fuse` is kept.
@@ -2877,7 +2891,7 @@ static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, doub
       rc = MLMCPI_OK;
     } else if (!schw && !kinds && !g.overridden && gff_blocks32 && n <= 6) {
       const double mu2 = gff_mu2(*act);
-      dim3 bgrid((act->Mt / 32) * (act->Mx / 32), B);
+      dim3 bgrid(g32_tx * g32_ty, B);
       if (!tune.or_heat_split && s + n == n_overrelax && n_heatbath >= 1 && n <= 5) {
         const bool with_qoi = qoi_kind && s + n + 1 == total;
         void *partial = nullptr;
@@ -2885,7 +2899,7 @@ static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, doub
           if (int rcs = scratch((size_t)B * bgrid.x * sizeof(double), &partial, st)) return rcs;
         const int op = with_qoi ? (int)L_PHI2 : 0;
         const RngKey hkey = make_key(seed, chain0, sweep0 + s + n);
-#define MLMCPI_GFF_HEAT32(KK) hipLaunchKernelGGL((gff_or_heat_kernel<KK, 32>), bgrid, dim3((GffHeatGeom<KK, 32>::NT)), (GffHeatGeom<KK, 32>::lds_bytes), st, act->Mt, act->Mx, mu2, (const double *)src, dst, act->Mt / 32, hkey, op, (double *)partial)
+#define MLMCPI_GFF_HEAT32(KK) hipLaunchKernelGGL((gff_or_heat_kernel<KK, 32>), bgrid, dim3((GffHeatGeom<KK, 32>::NT)), (GffHeatGeom<KK, 32>::lds_bytes), st, act->Mt, act->Mx, mu2, (const double *)src, dst, g32_tx, hkey, op, (double *)partial)
         switch (n) {
           case 1: MLMCPI_GFF_HEAT32(1); break;
           case 2: MLMCPI_GFF_HEAT32(2); break;
@@ -2904,7 +2918,7 @@ static int sweep_draw_impl(const mlmcpi_lattice_action *act, double *d_phi, doub
         s += n + 1;
         continue;
       }
-#define MLMCPI_GFF_BLOCK32(KK) hipLaunchKernelGGL((gff_or_block_kernel<KK, 32>), bgrid, dim3((GffBlockGeom<KK, 32>::NT)), (GffBlockGeom<KK, 32>::lds_bytes), st, act->Mt, act->Mx, mu2, (const double *)src, dst, act->Mt / 32)
+#define MLMCPI_GFF_BLOCK32(KK) hipLaunchKernelGGL((gff_or_block_kernel<KK, 32>), bgrid, dim3((GffBlockGeom<KK, 32>::NT)), (GffBlockGeom<KK, 32>::lds_bytes), st, act->Mt, act->Mx, mu2, (const double *)src, dst, g32_tx)
       switch (n) {
         case 1: MLMCPI_GFF_BLOCK32(1); break;
         case 2: MLMCPI_GFF_BLOCK32(2); break;

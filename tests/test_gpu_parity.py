@@ -686,7 +686,8 @@ def test_wide_workgroups_of_the_fused_launch_change_nothing(gpu_ops, Mt, Mx, B):
 
 
 @pytest.mark.parametrize("M,B,mass", [(128, 3, 3.0), (192, 2, 10.0), (512, 2, 10.0),
-                                      (96, 3, 10.0), (64, 2, 3.0), (160, 2, 10.0)])   # r04: 32 x 32 tiles
+                                      (96, 3, 10.0), (64, 2, 3.0), (160, 2, 10.0),    # r04: 32 x 32 tiles
+                                      (130, 2, 10.0), (200, 2, 3.0)])                  # r05: ... with masked edge tiles
 def test_gff_overrelaxation_and_heat_bath_in_one_launch_equal_two_launches(gpu_ops, M, B, mass):
     """gff_or_heat_kernel<K> against the two launches it replaces (MLMCPI_OR_HEAT=split): field bit for bit, phi^2 to rounding.
     (Lattices of 96, 64, 160 sites: the register-block kernels on 32 x 32 tiles, gff_or_heat_kernel<K, 32>.)"""
@@ -1166,7 +1167,8 @@ def test_draw_qoi_record_in_one_call_equals_the_three_steps(gpu_ops, kind, M, B)
         gpu_ops.lattice_sweep_draw_qoi(act, x0, torch.empty_like(x0), x0.clone(), 2, 0, SEED, 6, 0, qk, acc=torch.zeros((B, 5), dtype=torch.float64, device="cuda"))
 
 
-@pytest.mark.parametrize("M,B,n_or,n_hb", [(512, 3, 5, 1), (64, 2, 0, 1), (20, 2, 3, 2), (192, 2, 1, 1), (96, 2, 10, 1)])
+@pytest.mark.parametrize("M,B,n_or,n_hb", [(512, 3, 5, 1), (64, 2, 0, 1), (20, 2, 3, 2), (192, 2, 1, 1), (96, 2, 10, 1),
+                                           (130, 2, 10, 1), (1000, 1, 10, 1)])   # r05: masked edge tiles
 def test_fused_gff_qoi_equals_separate_evaluation(gpu_ops, M, B, n_or, n_hb):
     """The same for the GFF action: QoI2DPhiSquared (qoi kind 3) summed inside the heat-bath launch."""
     from mlmcpathintegral_amd import abi
