@@ -241,7 +241,12 @@ def test_hier_level_burns_its_own_state_in_for_the_length_asked(monkeypatch):
     lv.level, lv.B, lv.chain0, lv.window, lv.coarsest = 0, 4, 0, 20, False
     lv.sampler, lv.hmc, lv.step = FakeSampler(), FakeSampler.hmc, FakeStep()
     lv.qoi = lambda x: x
+    # r05: the series of the first tau_int estimate also feeds the windowed statistics of the running estimate
+    lv.wstats = torch.zeros((4, 2 * 20 + 3), dtype=torch.float64)
+    recorded = []
+    monkeypatch.setattr(mlmc.ops, "stats_window_record", lambda state, q: recorded.append(q.clone()))
     lv.thermalise(400, [0.02, 0.03])
+    assert len(recorded) == 8 * 20
     assert calls["sampler"] == (400, 24, 0.03)
     assert calls["thermalise"] == [400] and lv.n_burnin_theta == 400
     assert calls["dt"] == [0.02]
