@@ -14,7 +14,10 @@ def adiff(a, b):
     return float(torch.minimum(d, (d - 2 * np.pi).abs()).max())
 worst = 0.0
 n = 0
-for Mt, Mx in itertools.product((64, 128, 192, 320), (32, 64, 96, 128, 160, 256)):
+# r05: + lattices no tile divides (masked edge tiles), the smallest extents the closed form takes, extents around the
+# windows of the fused launch (66 ... 70, 126 ... 134)
+RAGGED = [(64, 34), (66, 32), (66, 34), (70, 70), (68, 128), (126, 130), (130, 126), (134, 66), (200, 72), (250, 250), (322, 130), (64, 250)]
+for Mt, Mx in list(itertools.product((64, 128, 192, 320), (32, 64, 96, 128, 160, 256))) + RAGGED:
     for beta in (1.0, 3.0):
         act = abi.lattice_action(abi.SCHWINGER, Mt, Mx, beta=beta)
         B = 1 + (Mt // 64 + Mx // 32) % 3
@@ -56,3 +59,24 @@ for M in (2, 4, 6, 64, 1000, 2048, 4100, 65536):
         if d > (5e-13 if n_hb == 0 else 5e-9):
             print(f"MISMATCH rotor M={M} ({n_or},{n_hb}): {d:.3e}", flush=True)
 print(f"rotor: {n} cases, largest overrelaxation-only difference {worst:.3e}", flush=True)
+
+# GFF register-block kernels on 32 x 32 tiles with masked edges (r05) against the LDS-resident sweep-by-sweep kernels: bit for bit
+worst, n = 0, 0
+for M in (64, 66, 70, 96, 100, 130, 190, 250):
+    act = abi.lattice_action(abi.GFF, M, M, mass=3.0)
+    x0 = ops.lattice_initialise(act, 2, SEED, 0)
+    for n_or, n_hb in ((1, 0), (5, 0), (6, 1), (10, 1), (3, 2)):
+        res = {}
+        for kern in ("lds", ""):
+            abi.set_option("MLMCPI_OR_KERNEL", kern)
+            try:
+                x = x0.clone()
+                ops.lattice_sweep_draw(act, x, torch.empty_like(x), n_or, n_hb, SEED, 0, 3)
+                res[kern] = x
+            finally:
+                abi.set_option("MLMCPI_OR_KERNEL", "")
+        n += 1
+        if not torch.equal(res["lds"], res[""]):
+            worst += 1
+            print(f"MISMATCH gff {M}x{M} ({n_or},{n_hb}): {float((res['lds'] - res['']).abs().max()):.3e}", flush=True)
+print(f"gff: {n} cases, {worst} not bit-identical", flush=True)
