@@ -893,6 +893,66 @@ __device__ __forceinline__ void heatbath_cells_step(uint32_t total, const RngKey
   ++pool.use;
 }
 
+// The same colour phase for callers that know a closed-form map thread -> cells (the fused Schwinger launch: a wave takes
+// whole rows of the tile image).  heatbath_cells_step above hands out cells by their linear index, so every cell pays an
+// integer division for its (row, column), a second one inside setup() for the Philox site, and the wraps of both
+// coordinates: ~30 integer instructions of a ~200-instruction cell.  Here pass 0 is NIT rounds of NT cells whose LDS offset
+// and Philox site the caller advances itself -- main_cell(off, site) is called NIT times by every thread, in order -- and
+// only what the map leaves over (n_left cells: left_off(i), i < n_left) joins the list pass, whose cells get their site from
+// site_of(off) as before.  Which cell a lane works on does not enter any result (a cell's random numbers are fixed by
+// (site, attempt)): bit for bit the results of heatbath_cells_step.  stencil(off, cell) = centre, class, kappa' (not the site).
+template <int NT, int NIT, class E, class Main, class Left, class SiteOf, class Stencil, class KappaExact, class Commit>
+__device__ __forceinline__ void heatbath_cells_step_mapped(uint32_t n_left, const RngKey &key, VsPool<E> &pool, Main main_cell, Left left_off,
+                                                           SiteOf site_of, Stencil stencil, KappaExact kappa_exact, Commit commit) {
+  using P = VsPool<E>;
+  constexpr uint32_t kOffMask = (1u << P::kOffBits) - 1;
+  uint32_t *const cnt = pool.count + (pool.use & 1u);
+  // the counter of the NEXT use (see heatbath_cells_step); this form needs the list: pool.cap > 0
+  if (threadIdx.x == 0) pool.count[(pool.use & 1u) ^ 1u] = 0;
+  const PhiloxVKeys vk_ = philox_vkeys(key.k0, key.k1);
+  const PhiloxVKeys *const vk = &vk_;
+  auto cell = [&](uint32_t off, uint32_t site, uint32_t pair, auto on_list) {   // two copies, as in heatbath_cells_step
+    VsCell c;
+    stencil(off, c);
+    double th = 0.0;
+    bool neg = false;
+    for (;;) {
+      if (vs_attempt_pair(key, vk, site, pair, c.kp, c.cls, pool.tab, [&] { return kappa_exact(off); }, th, neg)) {
+        commit(off, mod_2pi_fast(c.centre + (neg ? -th : th)));
+        return;
+      }
+      ++pair;
+      if ((bool)on_list && pair == 1) {
+        const uint32_t slot = atomicAdd(cnt, 1u);
+        if (slot < pool.cap) {
+          pool.buf[slot] = (E)(off | (pair << P::kOffBits));
+          return;
+        }
+      }
+    }
+  };
+  for (int k = 0; k < NIT; ++k) {
+    uint32_t off, site;
+    main_cell(off, site);
+    cell(off, site, 0u, std::true_type{});
+  }
+  __syncthreads();
+  const uint32_t n_list = min(*cnt, pool.cap);
+  const uint32_t n = n_list + n_left;
+  for (uint32_t i = threadIdx.x; i < n; i += NT) {
+    uint32_t off, pair = 0;
+    if (i < n_list) {
+      const uint32_t e = pool.buf[i];
+      off = e & kOffMask;
+      pair = e >> P::kOffBits;
+    } else {
+      off = left_off(i - n_list);
+    }
+    cell(off, site_of(off), pair, std::false_type{});
+  }
+  ++pool.use;
+}
+
 // one draw x ~ exp(kappa cos(x - centre)) for the conditional between x_p and x_m (test hook; the sweeps go through
 // heatbath_cells_step): returns mod_2pi(centre + x)
 __device__ __forceinline__ double vs_draw(const RngKey &k, uint32_t site, double scale, double x_p, double x_m, const VsTable &tab) {

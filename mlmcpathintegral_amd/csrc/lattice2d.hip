@@ -856,6 +856,16 @@ __device__ __forceinline__ void schwinger_image_heat(double *th0, double *th1, V
   RngKey skey = key0;
   skey.chain += b;
   const double beta2 = 2. * beta;
+  // Step-envelope phases with whole waves per round (NT = 512, 1024): the cells of pass 0 by a closed-form map
+  // (heatbath_cells_step_mapped); other workgroup sizes, the wrapped-Cauchy sampler and -DMLMCPI_HB_LINEAR (the form this
+  // replaces, for same-box A/B) hand them out by linear index.
+#ifdef MLMCPI_HB_LINEAR
+  constexpr bool kMapped = false;
+#else
+  constexpr bool kMapped = STEP && 32 % (NT / kWave) == 0;
+#endif
+  constexpr uint32_t NW = NT / kWave, NIT = kMapped ? 32 / NW : 1;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave), lane = threadIdx.x % kWave;
   for (uint32_t par = 0; par < 2; ++par) {  // mu = 0: rows [HB, HB + TH] of one parity, columns [HB - 1, HB + TW]
     const uint32_t r_first = HB + par, nr = (HB + TH - r_first) / 2 + 1;
     constexpr uint32_t ncol = TW + 2;
@@ -869,7 +879,36 @@ __device__ __forceinline__ void schwinger_image_heat(double *th0, double *th1, V
             site = 2 * (wrap(sr, r, Mx) * Mt + wrap(sc, c, Mt));
           },
           [&](uint32_t o, double v) { th0[o] = v; });
-    else
+    else if constexpr (kMapped) {
+      // pass 0: wave w takes rows ri = w + NW k (k < NIT: 32 of the 33 rows), lane l column ci = l (64 of the 66); the
+      // row of the Philox site is a scalar, its column one register for the whole phase
+      uint32_t o_next = (r_first + 2 * wave) * bw + (HB - 1) + lane;
+      uint32_t srow = wrap(sr, r_first + 2 * wave, Mx);                  // (scalar)
+      const uint32_t scol = wrap(sc, HB - 1 + lane, Mt), n_top = (nr - NIT * NW) * ncol;
+      heatbath_cells_step_mapped<NT, NIT, uint32_t>(
+          n_top + 2 * (NIT * NW), skey, vpool,
+          [&](uint32_t &o, uint32_t &site) {
+            o = o_next;
+            site = (srow * Mt + scol) << 1;
+            o_next += 2 * NW * bw;
+            srow = wrap(srow, 2 * NW, Mx);
+          },
+          [&](uint32_t i) {   // left over: row ri = 32 of the even phase (66 cells), then columns 64, 65 of the rows before it
+            const uint32_t j = i - n_top, ri = i < n_top ? (uint32_t)(NIT * NW) : j >> 1, ci = i < n_top ? i : 64 + (j & 1u);
+            return (r_first + 2 * ri) * bw + (HB - 1) + ci;
+          },
+          [&](uint32_t o) {
+            const uint32_t r = o / bw, c = o - r * bw;
+            return 2 * (wrap(sr, r, Mx) * Mt + wrap(sc, c, Mt));
+          },
+          [&](uint32_t o, VsCell &cell) {
+            vs_cell(beta2, th0[o + bw] + th1[o] - th1[o + 1], th0[o - bw] + th1[o - bw + 1] - th1[o - bw], cell);
+          },
+          [&](uint32_t o) {
+            return vs_kappa_exact(beta2, th0[o + bw] + th1[o] - th1[o + 1], th0[o - bw] + th1[o - bw + 1] - th1[o - bw]);
+          },
+          [&](uint32_t o, double v) { th0[o] = v; });
+    } else
     heatbath_region_step<NT, 5, true, uint32_t>(
         nr, ncol, r_first * bw + (HB - 1), 2 * bw, 1, skey, vpool,
         [&](uint32_t o, VsCell &cell) {
@@ -897,7 +936,35 @@ __device__ __forceinline__ void schwinger_image_heat(double *th0, double *th1, V
             site = 2 * (wrap(sr, r, Mx) * Mt + wrap(sc, c, Mt)) + 1;
           },
           [&](uint32_t o, double v) { th1[o] = v; });
-    else
+    else if constexpr (kMapped) {
+      // pass 0: a wave takes two rows and 32 columns per round -- lane l: row ri = 2 (w + NW k) + (l >> 5), column ci = l & 31;
+      // the 33rd column of the even phase is left over
+      const uint32_t r0 = HB + 2 * wave + (lane >> 5), c0 = c_first + 2 * (lane & 31u);
+      uint32_t o_next = r0 * bw + c0;
+      uint32_t rowmt = wrap(sr, r0, Mx) * Mt;
+      const uint32_t scol = wrap(sc, c0, Mt), mxmt = Mx * Mt;
+      heatbath_cells_step_mapped<NT, NIT, uint32_t>(
+          (nc - 32) * (uint32_t)TH, skey, vpool,
+          [&](uint32_t &o, uint32_t &site) {
+            o = o_next;
+            site = ((rowmt + scol) << 1) | 1u;
+            o_next += 2 * NW * bw;
+            rowmt += 2 * NW * Mt;
+            rowmt = min(rowmt, rowmt - mxmt);   // (wraps once: the image is no taller than the lattice)
+          },
+          [&](uint32_t i) { return (HB + i) * bw + c_first + 64; },
+          [&](uint32_t o) {
+            const uint32_t r = o / bw, c = o - r * bw;
+            return 2 * (wrap(sr, r, Mx) * Mt + wrap(sc, c, Mt)) + 1;
+          },
+          [&](uint32_t o, VsCell &cell) {
+            vs_cell(beta2, th0[o] + th1[o + 1] - th0[o + bw], th0[o + bw - 1] + th1[o - 1] - th0[o - 1], cell);
+          },
+          [&](uint32_t o) {
+            return vs_kappa_exact(beta2, th0[o] + th1[o + 1] - th0[o + bw], th0[o + bw - 1] + th1[o - 1] - th0[o - 1]);
+          },
+          [&](uint32_t o, double v) { th1[o] = v; });
+    } else
     heatbath_region_step<NT, 5, true, uint32_t>(
         TH, nc, HB * bw + c_first, bw, 2, skey, vpool,
         [&](uint32_t o, VsCell &cell) {
