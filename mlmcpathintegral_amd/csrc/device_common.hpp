@@ -931,11 +931,73 @@ __device__ __forceinline__ void heatbath_cells_step_mapped(uint32_t n_left, cons
       }
     }
   };
+#ifndef MLMCPI_HB_CELLS1
+  // Two cells per lane and round, stage by stage (stencils, Philox calls, table look-ups, screening tests of both, then the
+  // rare exact test of either behind ONE branch): a cell is one dependency chain with four LDS round trips in it, and a SIMD
+  // holds four waves -- two of them this stage's --, so the second chain fills what the first one waits for
+  static_assert(NIT % 2 == 0, "rounds come in pairs");
+  for (int k = 0; k < NIT; k += 2) {
+    uint32_t off[2], site[2], ca[2], cb[2];
+    VsCell c[2];
+    U4 q[2];
+    float pa[2], pb[2];
+    bool acc_a[2], acc_b[2], rej_a[2], rej_b[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) main_cell(off[j], site[j]);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) stencil(off[j], c[j]);
+    const uint32_t w3 = (P_VONMISES << 24);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) q[j] = philox4x32_10(site[j], key.chain, key.step, w3, key.k0, key.k1, vk_);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      pa[j] = vs_accept_prob(q[j].y, c[j].kp, c[j].cls, pool.tab, ca[j]);
+      pb[j] = vs_accept_prob(q[j].w, c[j].kp, c[j].cls, pool.tab, cb[j]);
+    }
+    bool open = false;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const float la = (float)q[j].x, lb = (float)q[j].z;
+      acc_a[j] = la <= fmaf(pa[j], pool.tab.s_acc, -kVsU2Slack);
+      acc_b[j] = lb <= fmaf(pb[j], pool.tab.s_acc, -kVsU2Slack);
+      rej_a[j] = la >= fmaf(pa[j], pool.tab.s_rej, kVsU2Slack);
+      rej_b[j] = lb >= fmaf(pb[j], pool.tab.s_rej, kVsU2Slack);
+      // open: the first attempt undecided, or rejected and the second undecided
+      open = open || (!acc_a[j] && (!rej_a[j] || (!acc_b[j] && !rej_b[j])));
+    }
+    if (open) {   // (one attempt in ~10^4: the exact test, as in vs_attempt_pair)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        if (!acc_a[j] && (!rej_a[j] || (!acc_b[j] && !rej_b[j]))) {
+          const uint8_t *row = pool.tab.base + c[j].cls + kVsLwOff;
+          const uint32_t r = vs_exact_pair(key.k0, key.k1, key.chain, key.step, site[j], w3, q[j], ca[j] | (cb[j] << 8), *(const float *)(row + ca[j]),
+                                           *(const float *)(row + cb[j]), kappa_exact(off[j]), rej_a[j] ? 0 : -1, acc_b[j] ? 1 : rej_b[j] ? 0 : -1,
+                                           pool.tab.base);
+          acc_a[j] = (r & 3u) == 1u;
+          acc_b[j] = (r >> 2) == 1u;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if (acc_a[j] || acc_b[j]) {
+        const bool first = acc_a[j];
+        const uint32_t lo = first ? q[j].x : q[j].z, hi = first ? q[j].y : q[j].w;
+        const double th = vs_theta(lo, hi, first ? ca[j] : cb[j], pool.tab);
+        commit(off[j], mod_2pi_fast(c[j].centre + ((lo & 0x200u) ? -th : th)));
+      } else {
+        const uint32_t slot = atomicAdd(cnt, 1u);
+        if (slot < pool.cap) pool.buf[slot] = (E)(off[j] | (1u << P::kOffBits));
+        else cell(off[j], site[j], 1u, std::false_type{});   // list full: finished where it is
+      }
+    }
+  }
+#else
   for (int k = 0; k < NIT; ++k) {
     uint32_t off, site;
     main_cell(off, site);
     cell(off, site, 0u, std::true_type{});
   }
+#endif
   __syncthreads();
   const uint32_t n_list = min(*cnt, pool.cap);
   const uint32_t n = n_list + n_left;

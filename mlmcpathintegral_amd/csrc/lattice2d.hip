@@ -1112,6 +1112,9 @@ __global__ void __launch_bounds__(WIDE ? 1024 : OrHeatGeom<K>::NT, 4)
 // U + 1 rows in flight per thread.  W + 1 <= Mt and rows + 1 <= Mx are not required: columns and rows wrap as often as
 // needed (a 64 x 64 lattice is its own halo).
 constexpr uint32_t kPermMaxK = 10;  // sweeps per launch
+#ifndef MLMCPI_PERM_U
+#define MLMCPI_PERM_U 19   // rows in flight per thread in the first plane build: all of a thread's rows at the deepest launch (r05: one round trip to HBM instead of two, 10 + 9 rows: -4.2 % on the launch, same-box A/B)
+#endif
 
 // Workgroups are handed to the 8 XCDs round robin by their linear index; each XCD has its own L2.  Experiment
 // (-DMLMCPI_XCD_MAP): XCD x takes the x-th eighth of the (chain, tile) list instead, so that the workgroups resident on an
@@ -1304,7 +1307,7 @@ __device__ __forceinline__ void perm_sweeps(double *plane, const double2 *__rest
   using PG = PermGeom<NT, RING, TH>;
   using PP = PermPlane<PG::WP>;
   constexpr int HR = PG::HR, NV = PG::NV;
-  constexpr int U = 10, UB = 9;   // rows in flight per thread: first build (nothing else is live yet), new rows of the second
+  constexpr int U = MLMCPI_PERM_U, UB = 9;   // rows in flight per thread: first build (nothing else is live yet), new rows of the second
   const uint32_t W = PG::width(K), rows = PG::rows(K, NB), H = RING + 2 * K;
   const PP P(rows);
   // lattice coordinates of plane (0, 0) of the first build, and of output vertex (0, 0)
@@ -1430,13 +1433,15 @@ __device__ __forceinline__ void perm_sweeps(double *plane, const double2 *__rest
   {
     double keep[NC];
     char *const pbw = reinterpret_cast<char *>(plane);
-    __syncthreads();  // the first half has read its plane
+    // (a thread reads what it moves as soon as its own gather is done -- reads beside the reads of the gathers still running
+    // -- and ONE barrier separates every read of the old plane, the gathers' and these, from the writes; the barrier that
+    // used to stand in front of these reads as well was worth 0.1 % of the launch, same-box A/B)
 #pragma unroll
     for (int q = 0; q < NC; ++q) {
       const uint32_t idx = threadIdx.x + q * NT, e = idx >> 2, qd = idx & 3u;
       if (e < nkeep) keep[q] = *reinterpret_cast<const double *>(pbw + qd * P.QB + e * 8u + ((qd & 2u) ? 0u : shift));
     }
-    __syncthreads();
+    __syncthreads();  // the first half has read its plane, and so have the threads that move its rows
 #pragma unroll
     for (int q = 0; q < NC; ++q) {
       const uint32_t idx = threadIdx.x + q * NT, e = idx >> 2, qd = idx & 3u;
