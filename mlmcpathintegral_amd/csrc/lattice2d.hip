@@ -1113,7 +1113,7 @@ __global__ void __launch_bounds__(WIDE ? 1024 : OrHeatGeom<K>::NT, 4)
 // needed (a 64 x 64 lattice is its own halo).
 constexpr uint32_t kPermMaxK = 10;  // sweeps per launch
 #ifndef MLMCPI_PERM_U
-#define MLMCPI_PERM_U 19   // rows in flight per thread in the first plane build: all of a thread's rows at the deepest launch (r05: one round trip to HBM instead of two, 10 + 9 rows: -4.2 % on the launch, same-box A/B)
+#define MLMCPI_PERM_U 0    // rows in flight per thread in the first plane build; 0 = all of a thread's rows at the deepest launch (19 at 512 threads; r05: one round trip to HBM instead of two, 10 + 9 rows: -4.2 % on the launch, same-box A/B)
 #endif
 
 // Workgroups are handed to the 8 XCDs round robin by their linear index; each XCD has its own L2.  Experiment
@@ -1235,6 +1235,84 @@ struct PermGeom {
   static __host__ __device__ constexpr size_t plane_bytes(uint32_t K, uint32_t NB) { return (size_t)WP * rows(K, NB) * sizeof(double); }
 };
 
+// The tasks of a half and who takes them.  A task is a column pair (mu = 0: rows r, r + 1 of column c) or a row pair
+// (mu = 1: columns c, c + 1 of row r), coordinates inside the half.  r05: whole WAVES take whole rows -- wave-task m of a
+// half is, for m < HR / 2, the mu = 0 tasks of row pair m in columns 0 .. 63 (lane l: the even columns on lanes 0 .. 31,
+// the odd ones on 32 .. 63: a 32-lane group of a gather read stays inside one quadrant of the plane, contiguous banks),
+// and for m >= HR / 2 the mu = 1 tasks of rows 2 (m - HR / 2) + (l >> 5) in column pairs l & 31; wave w takes m = w, w + NW,
+// ... (slot k: m = w + NW k).  The kind of a slot and the row of its tasks are then wave-uniform and the column of a lane
+// is the same in every slot: what was ~65 vector instructions of index arithmetic per task in the three places that need
+// coordinates (own angles, gather, image) is scalar work plus a few additions.  The columns beyond 64 of the 68-wide
+// output of the fused launch (4 x HR / 2 mu = 0 tasks, 2 x HR mu = 1 tasks) are left-over wave-tasks of one kind each, in
+// the last slot of waves that have no main task there.  Which lane computes a task does not enter its result.
+// (-DMLMCPI_PERM_TASKS_LINEAR: thread t takes tasks t, t + NT, ... of the list "mu = 0 row pairs, then mu = 1 rows", r04.)
+#ifndef MLMCPI_PERM_TASKS_LINEAR
+template <int NT, int RING, int TH = 64>
+struct PermTasks {
+  using PG = PermGeom<NT, RING, TH>;
+  static constexpr int OW = PG::OW, HR = PG::HR, H2 = HR / 2, NW = NT / kWave, NS = (HR + NW - 1) / NW;
+  static constexpr int XC = OW - 64;                                   // columns beyond a wave's 64 (0 or 4)
+  static constexpr int L0 = XC * H2, L1 = (XC / 2) * HR;               // left-over tasks, mu = 0 and mu = 1
+  static constexpr int NL0 = (L0 + 63) / 64, NL1 = (L1 + 63) / 64;     // ... as wave-tasks
+  static constexpr int WF = HR - NW * (NS - 1);                        // the first wave without a main task in slot NS - 1
+  static_assert(PG::NV == NS, "slots per thread");
+  static_assert(NL0 + NL1 <= NW - WF, "the left-over wave-tasks fit the free last slots");
+  uint32_t wave, lane, c_mu0, c_mu1, r_lo;
+  __device__ PermTasks() {
+    wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    lane = threadIdx.x % kWave;
+    c_mu0 = lane < 32 ? 2 * lane : 2 * (lane - 32) + 1;
+    c_mu1 = 2 * (lane & 31u);
+    r_lo = lane >> 5;
+  }
+  // slot k of this thread: false when there is no task in it; mu1 is wave-uniform
+  __device__ __forceinline__ bool task(int k, bool &mu1, uint32_t &r, uint32_t &c) const {
+    const uint32_t m = wave + (uint32_t)(NW * k);
+    mu1 = false; r = 0; c = 0;
+    if (NW * k + NW - 1 < H2 || m < (uint32_t)H2) {            // (the first clause: known at compile time for the early slots)
+      r = 2 * m;
+      c = c_mu0;
+      return true;
+    }
+    if (m < (uint32_t)HR) {
+      mu1 = true;
+      r = 2 * (m - H2) + r_lo;
+      c = c_mu1;
+      return true;
+    }
+    if (XC > 0 && k == NS - 1) {
+      const uint32_t j = wave - (uint32_t)WF;
+      if (j < (uint32_t)NL0) {                                // mu = 0, columns 64 ..: task L = row pair L / XC, column 64 + L % XC
+        const uint32_t L = 64 * j + lane;
+        r = 2 * (L / (XC ? XC : 1));
+        c = 64 + L % (XC ? XC : 1);
+        return L < (uint32_t)L0;
+      }
+      if (j < (uint32_t)(NL0 + NL1)) {                        // mu = 1, column pairs 32 ..: row L / (XC / 2), column 64 + 2 (L % (XC / 2))
+        const uint32_t L = 64 * (j - NL0) + lane;
+        mu1 = true;
+        r = L / (XC > 1 ? XC / 2 : 1);
+        c = 64 + 2 * (L % (XC > 1 ? XC / 2 : 1));
+        return L < (uint32_t)L1;
+      }
+    }
+    return false;
+  }
+  __device__ __forceinline__ bool valid(int k) const {
+    bool mu1; uint32_t r, c;
+    return task(k, mu1, r, c);
+  }
+  __device__ __forceinline__ bool is_mu1(int k) const {
+    bool mu1; uint32_t r, c;
+    task(k, mu1, r, c);
+    return mu1;
+  }
+  __device__ __forceinline__ void coords(int k, uint32_t &r, uint32_t &c) const {
+    bool mu1;
+    task(k, mu1, r, c);
+  }
+};
+#else
 // Task k of a thread, t = threadIdx.x + k NT: a column pair (mu = 0: rows r, r + 1 of column c; t < NT0) or a row pair
 // (mu = 1: columns c, c + 1 of row r), coordinates inside the half.  Two divisions per thread (PermTasks), then constants.
 template <int NT, int RING, int TH = 64>
@@ -1256,13 +1334,9 @@ struct PermTasks {
       uint32_t q = q0 + dq, cc = c0 + dc;
       if (cc >= (uint32_t)OW) { cc -= OW; ++q; }
       r = 2 * q;
-#ifndef MLMCPI_PERM_LANES_BY_COLUMN
       // the first OW / 2 tasks of a row pair take the even columns, the rest the odd ones: a 32-lane group of a gather read
       // stays inside one quadrant of the plane, contiguous banks (r05, same-box A/B: 0.7703 against 0.7747 ms with c = cc)
       c = cc < (uint32_t)(OW / 2) ? 2 * cc : 2 * (cc - OW / 2) + 1;
-#else
-      c = cc;
-#endif
     } else {            // t - NT0 = (q1 + dq) OW2 + c1 + dc, dq possibly negative
       const int off = k * NT - NT0, dq = off >= 0 ? off / OW2 : -((-off + OW2 - 1) / OW2), dc = off - dq * OW2;   // 0 <= dc < OW2
       uint32_t q = q1 + (uint32_t)dq, cc = c1 + (uint32_t)dc;
@@ -1272,6 +1346,7 @@ struct PermTasks {
     }
   }
 };
+#endif
 
 // Five steps of the three streams of a task: fifteen 8-byte LDS reads at immediate offsets from three addresses, through
 // inline asm (lds_read_f64: the compiler would pair the reads of a stream into ds_read2_b64, half the rate --
@@ -1307,7 +1382,9 @@ __device__ __forceinline__ void perm_sweeps(double *plane, const double2 *__rest
   using PG = PermGeom<NT, RING, TH>;
   using PP = PermPlane<PG::WP>;
   constexpr int HR = PG::HR, NV = PG::NV;
-  constexpr int U = MLMCPI_PERM_U, UB = 9;   // rows in flight per thread: first build (nothing else is live yet), new rows of the second
+  // all of a thread's rows at the deepest launch: (HR + 4 kPermMaxK) rows over (NT / 64) / 2 row groups (W > 63: two column waves)
+  constexpr int kGroups = NT / kWave / 2;
+  constexpr int U = MLMCPI_PERM_U ? MLMCPI_PERM_U : (HR + 4 * (int)kPermMaxK + kGroups - 1) / kGroups, UB = (HR + kGroups - 1) / kGroups;   // rows in flight per thread: first build (nothing else is live yet), new rows of the second
   const uint32_t W = PG::width(K), rows = PG::rows(K, NB), H = RING + 2 * K;
   const PP P(rows);
   // lattice coordinates of plane (0, 0) of the first build, and of output vertex (0, 0)
@@ -1448,8 +1525,11 @@ __device__ __forceinline__ void perm_sweeps(double *plane, const double2 *__rest
       if (e < nkeep) *reinterpret_cast<double *>(pbw + qd * P.QB + e * 8u + ((qd & 2u) ? shift : 0u)) = keep[q];
     }
   }
+#ifdef MLMCPI_THETA_MID
+  load_theta(0, th);
+#endif
   perm_rows_store<UB>(qb, P, plane, rows - HR, curb, vb);
-#ifndef MLMCPI_THETA_EARLY
+#if !defined(MLMCPI_THETA_EARLY) && !defined(MLMCPI_THETA_MID)
   load_theta(0, th);
 #endif
   double2 th1[NV];
