@@ -456,15 +456,18 @@ class SweepWorkload:
         self.fused = a.n_heatbath > 0 and not a.no_fused_qoi
         if self.fused:  # sampler->draw's last launch sums the QoI of the new sample while the tile is in LDS
             d = self.or_heat_depth  # > 0: that launch also holds the last d overrelaxation sweeps (same launches as one call)
+            # ... and the launch that finishes the QoI records the sample too (mlmcpi_lattice_sweep_draw_qoi_record, the call
+            # the C++ sampler's draw_with_qoi makes when it is handed the moments): no launch of its own for record_sample
             self.x, self.scratch, q = ops.lattice_sweep_draw_qoi(self.act, cur, oth, cur, d, a.n_heatbath, a.seed, self.chain0,
                                                                  s + a.n_overrelax - d, 1 if self.kind == "schwinger" else 3,
-                                                                 0 if self.whole else (d or self.fuse))
+                                                                 0 if self.whole else (d or self.fuse), acc=self.acc)
         else:
             self.x, self.scratch = ops.lattice_sweep_draw_pingpong(self.act, cur, oth, 0, a.n_heatbath, a.seed, self.chain0,
                                                                    s + a.n_overrelax, self.fuse)
         if record:
             e[3].record()
-        ops.stats_accumulate(self.acc, q if self.fused else self.qoi())  # qoi->evaluate + record_sample
+        if not self.fused:
+            ops.stats_accumulate(self.acc, self.qoi())  # qoi->evaluate + record_sample
         if record:
             e[4].record()
             self.ev["or"].append((e[0], e[1]))
@@ -1094,16 +1097,21 @@ def report_sweeps(result, a, W, size, B, world, step_ms, ms):
                pmc_entry("entries", chains=B, fuse=1, kind="heatbath", **wl), pmc_entry("valu", kind="heatbath", **wl))
         if fused:
             kernels[-1]["role"] = "heat-bath sweep + qoi->evaluate (QoI summed while the tile is in LDS)"
-    qk = record("stats_accumulate_kernel" if fused else
-                ("schwinger_reduce_band_kernel" if a.workload == "schwinger" else "lattice_reduce_kernel") + " (QoI) + stats_accumulate_kernel",
-                "record_sample (the QoI is fused into the heat-bath launch)" if fused else "qoi->evaluate + record_sample", W.ev["qoi"], 1, 1,
-                8.0 * B if fused else 0.5 * state_rw, None, None)
-    del qk["updates_per_s"], qk["algorithmic_bytes_per_launch"], qk["algorithmic_GBps"], qk["sweeps_per_launch"]
+    if fused:
+        # no launch of its own: lattice_finish_kernel (one wave per chain sums the tiles' partial QoIs and updates the chain's
+        # moments) is inside the interval of the launch above
+        kernels[-1]["interval_includes"] = "lattice_finish_kernel (one wave per chain: the tiles' partial QoIs summed, the chain's moments updated)"
+        result["record_sample_launch"] = "none of its own: the launch that finishes the QoI updates the moments (mlmcpi_lattice_sweep_draw_qoi_record)"
+    else:
+        qk = record(("schwinger_reduce_band_kernel" if a.workload == "schwinger" else "lattice_reduce_kernel") + " (QoI) + stats_accumulate_kernel",
+                    "qoi->evaluate + record_sample", W.ev["qoi"], 1, 1, 0.5 * state_rw, None, None)
+        del qk["updates_per_s"], qk["algorithmic_bytes_per_launch"], qk["algorithmic_GBps"], qk["sweeps_per_launch"]
     result["kernels"] = kernels
     # roofline: the kernel with the largest share of the step.  `achieved` = algorithmic bytes (16 B x the updates of one
     # launch) / launch time; for a single-sweep launch that equals the HBM floor, for a fused launch the floor is used
     # (a fused launch shares one HBM round trip among its sweeps, so the per-update model is not a bound for it).
-    dom = max(kernels[:-1], key=lambda k: k["share_of_step"])
+    body = kernels if fused else kernels[:-1]   # (not fused: the last entry is the QoI pass + record_sample)
+    dom = max(body, key=lambda k: k["share_of_step"])
     result["qoi_fused_into_draw"] = fused
     # What binds the dominant kernel.  The heat-bath launches are vector-issue bound (Philox + von Mises sampler, SURVEY
     # A.2: the contract's "hbm" | "mfma" has no word for it, so it is called what it is): frac = issue_frac = the launch's
@@ -1148,8 +1156,8 @@ def report_sweeps(result, a, W, size, B, world, step_ms, ms):
                             "hbm_floor_bytes": floor_step, "hbm_floor_GBps": floor_step / (step_ms * 1e-3) / 1e9,
                             "hbm_floor_frac": floor_step / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                             "kernel_ms_sum": sum(k["launch_ms"] * k["launches_per_step"] for k in kernels)}
-    if all(k["traffic"] is not None for k in kernels[:-1]):
-        tr = sum(k["traffic"] * k["launches_per_step"] for k in kernels[:-1])
+    if all(k["traffic"] is not None for k in body):
+        tr = sum(k["traffic"] * k["launches_per_step"] for k in body)
         result["whole_step"].update({"counter_traffic_bytes": tr, "counter_traffic_GBps": tr / (step_ms * 1e-3) / 1e9,
                                      "counter_traffic_frac": tr / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
     # What the headline number is.  `value` counts every link update of every sweep of the draw; where the
