@@ -8,17 +8,18 @@
 #include <stdint.h>
 #include <stdio.h>
 
-enum Op { FMA32, ADD64, FMA64, MAD64, BITOP3, PHILOX, EXP32 };
+enum Op { FMA32, ADD64, FMA64, MAD64, BITOP3, PHILOX, EXP32, PKFMA32 };
 
 template <int OP>
 __device__ __forceinline__ void step(uint32_t &lo, uint32_t &hi, uint32_t k) {
   if (OP == FMA32) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(lo) : "v"(k));
   if (OP == EXP32) asm volatile("v_exp_f32 %0, %0" : "+v"(lo));
   if (OP == BITOP3) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(lo) : "v"(k), "v"(hi));
-  if (OP == ADD64 || OP == FMA64 || OP == MAD64 || OP == PHILOX) {
+  if (OP == ADD64 || OP == FMA64 || OP == MAD64 || OP == PHILOX || OP == PKFMA32) {
     uint64_t v = ((uint64_t)hi << 32) | lo;
     if (OP == ADD64) asm volatile("v_add_f64 %0, %0, %1" : "+v"(v) : "v"((uint64_t)k << 32));
     if (OP == FMA64) asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(v) : "v"((uint64_t)k << 32));
+    if (OP == PKFMA32) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(v) : "v"(((uint64_t)k << 32) | k));
     if (OP == MAD64) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(v) : "v"(lo), "v"(k) : "vcc");
     if (OP == PHILOX) {  // one half round: product, then hi ^ counter ^ key (two instructions)
       asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(v) : "v"(lo), "v"(k) : "vcc");
@@ -84,6 +85,6 @@ int main() {
   const int n_cu = prop.multiProcessorCount;
   printf("%s, %d CUs; a wave's own cycles per instruction = (cycles on the SIMD) x (waves per SIMD)\n", prop.name, n_cu);
 #define ALL(OP) run<OP, 1>(#OP, d_out, n_cu); run<OP, 2>(#OP, d_out, n_cu); run<OP, 4>(#OP, d_out, n_cu);
-  ALL(FMA32) ALL(BITOP3) ALL(MAD64) ALL(PHILOX) ALL(ADD64) ALL(FMA64) ALL(EXP32)
+  ALL(PKFMA32) ALL(FMA32) ALL(BITOP3) ALL(MAD64) ALL(PHILOX) ALL(ADD64) ALL(FMA64) ALL(EXP32)
   return 0;
 }
