@@ -1184,9 +1184,11 @@ __device__ __forceinline__ PermBuildPos perm_build_pos(const PP &P, const double
   PermBuildPos q;
   // (the wave index on the scalar side: rows, row offsets and the loop conditions of the build are then scalar too)
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave), lane = threadIdx.x % kWave;
-  const uint32_t nwc = (W + 62) / 63, groups = (NT / kWave) / nwc;   // column waves per row group (W <= 108: at most 2), row groups
-  const uint32_t g = wave / nwc, cw = wave - g * nwc;
-  const uint32_t rpg = (rows + groups - 1) / groups;
+  const uint32_t nwc = W > 63 ? 2 : 1;                                // column waves per row group (W <= 108: at most 2)
+  const uint32_t groups = (NT / kWave) >> (nwc - 1);                   // row groups
+  const uint32_t g = wave >> (nwc - 1), cw = wave & (nwc - 1);
+  static_assert(((NT / kWave) & (NT / kWave - 1)) == 0, "waves per workgroup: a power of two (shifts for divisions)");
+  const uint32_t rpg = groups == 4 ? (rows + 3) >> 2 : groups == 8 ? (rows + 7) >> 3 : (rows + groups - 1) / groups;
   q.c = 63 * cw + lane;                                                // theta column; the plaquette column of lanes 0 .. 62
   q.r = g * rpg;
   q.rend = g < groups ? min(rows, q.r + rpg) : 0;
@@ -1407,8 +1409,11 @@ __device__ __forceinline__ void perm_sweeps(double *plane, const double2 *__rest
   const uint32_t W = PG::width(K), rows = PG::rows(K, NB), H = RING + 2 * K;
   const PP P(rows);
   // lattice coordinates of plane (0, 0) of the first build, and of output vertex (0, 0)
-  const uint32_t gi0 = (i0 + Mt - H % Mt) % Mt, gj0 = (j0 + Mx - H % Mx) % Mx;
-  const uint32_t oi0 = (i0 + Mt - RING) % Mt, oj0 = (j0 + Mx - RING) % Mx;
+  // (x - h) mod n for x < n: a comparison where h <= n -- the rule; the two modulo operations of the general form are ~80
+  // instructions each in front of the first load of the workgroup
+  auto back = [](uint32_t x, uint32_t h, uint32_t n) { return h <= n ? (x >= h ? x - h : x + n - h) : (x + n - h % n) % n; };
+  const uint32_t gi0 = back(i0, H, Mt), gj0 = back(j0, H, Mx);
+  const uint32_t oi0 = back(i0, RING, Mt), oj0 = back(j0, RING, Mx);
   const PermTasks<NT, RING, TH> tasks;
   // the links of a half as they are now (HR, RING, 2 K and the tile origins are even: output parity = plane parity = lattice parity)
   // (32-bit byte offsets from the chain's base pointer -- the host admits lattices of less than 2^28 vertices to these
