@@ -2187,6 +2187,59 @@ __global__ void __launch_bounds__((GffHeatGeom<K, T>::NT), 4)
   constexpr uint32_t nrow = TH + 2, nhalf = (TW + 2) / 2, total = nrow * nhalf, CELLS = (total + NT - 1) / NT;
   double partner[CELLS];  // the normal of (r, c ^ 1), the colour-1 cell of the same Box-Muller pair
   const PhiloxVKeys vk = philox_vkeys(skey.k0, skey.k1);
+  // one colour-0 cell (image row r, column c, offset o, lattice site ell) and the parked normal of its pair
+  auto cell0 = [&](uint32_t o, uint32_t ell, double &parked) {
+    double n0, n1, nb[4];
+    stencil_load(o, nb);   // in flight under the Philox call and the Box-Muller transform
+    rng_normals(skey, vk, ell >> 1, P_GFF_NORMAL, 0, n0, n1);
+    parked = (ell & 1u) ? n0 : n1;
+    phi[o] = fma(stencil_sum(nb), inv_kappa, sigma * ((ell & 1u) ? n1 : n0));
+  };
+  auto cell1 = [&](uint32_t o, double parked) {
+    double nb[4];
+    stencil_load(o, nb);
+    phi[o] = fma(stencil_sum(nb), inv_kappa, sigma * parked);
+  };
+  if constexpr (NT == 512 && T == 64) {
+    // r05: cells by a closed-form map instead of by linear index (a division by 33, the parity of the row, two wraps and a
+    // multiplication per cell and colour: ~29 of the ~240 vector instructions of a pair): a wave takes two rows x 32 cells
+    // per round -- lane l: row 1 + 2 (w + 8 k) + (l >> 5), column 1 + (l >> 5) + 2 (l & 31), the same in every round --, four
+    // rounds cover rows 1 .. 64; rows 65, 66 and the 33rd cell of every row (130 cells) are a fifth round of 130 threads,
+    // as many as the linear hand-out leaves for its last.  Which lane draws a pair does not enter the result.
+    static_assert(CELLS == 5 && nhalf == 33 && nrow == 66, "64 x 64 tile, 512 threads");
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid / kWave), lane = tid % kWave, rr = lane >> 5;
+    const uint32_t r0 = 1 + 2 * wave + rr, c0 = 1 + rr + 2 * (lane & 31u);
+    const uint32_t colw = wrap(sc, c0, Mt), mxmt = Mx * Mt;
+    uint32_t rowmt = wrap(sr, r0, Mx) * Mt, o = r0 * bw + c0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+      cell0(o, rowmt + colw, partner[k]);
+      o += 16 * bw;
+      rowmt += 16 * Mt;
+      rowmt = min(rowmt, rowmt - mxmt);   // (one wrap: the image is no taller than the lattice)
+    }
+    // the fifth round: t < 66: rows 65, 66, cell t % 33; 66 <= t < 130: row 1 + (t - 66), the 33rd cell
+    const bool extra = tid < 130;
+    const uint32_t xr = tid < 66 ? 65 + tid / 33 : 1 + (tid - 66), xci = tid < 66 ? tid % 33 : 32;
+    const uint32_t xc = HB - 1 + ((xr + HB - 1) & 1u) + 2 * xci, xo = xr * bw + xc;
+    partner[4] = 0.0;
+    if (extra) cell0(xo, wrap(sr, xr, Mx) * Mt + wrap(sc, xc, Mt), partner[4]);
+    __syncthreads();
+    // colour 1: the cell (r, c ^ 1) of every colour-0 cell, where that lies inside the tile
+    const uint32_t c1 = c0 ^ 1u;
+    const bool col_in = c1 >= (uint32_t)HB && c1 < (uint32_t)(HB + TW);
+    o = r0 * bw + c1;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+      const uint32_t r = r0 + 16 * k;
+      if (col_in && r >= (uint32_t)HB && r < (uint32_t)(HB + TH)) cell1(o, partner[k]);
+      o += 16 * bw;
+    }
+    const uint32_t xc1 = xc ^ 1u;
+    if (extra && xr >= (uint32_t)HB && xr < (uint32_t)(HB + TH) && xc1 >= (uint32_t)HB && xc1 < (uint32_t)(HB + TW))
+      cell1(xr * bw + xc1, partner[4]);
+    __syncthreads();
+  } else {
 #pragma unroll
   for (uint32_t k = 0; k < CELLS; ++k) {
     const uint32_t idx = tid + k * NT;
@@ -2194,13 +2247,7 @@ __global__ void __launch_bounds__((GffHeatGeom<K, T>::NT), 4)
     if (idx >= total) continue;
     const uint32_t ri = idx / nhalf, r = HB - 1 + ri;
     const uint32_t c = HB - 1 + ((r + HB - 1) & 1u) + 2 * (idx - ri * nhalf);
-    const uint32_t o = r * bw + c;
-    const uint32_t ell = wrap(sr, r, Mx) * Mt + wrap(sc, c, Mt);
-    double n0, n1, nb[4];
-    stencil_load(o, nb);   // in flight under the Philox call and the Box-Muller transform
-    rng_normals(skey, vk, ell >> 1, P_GFF_NORMAL, 0, n0, n1);
-    partner[k] = (ell & 1u) ? n0 : n1;
-    phi[o] = fma(stencil_sum(nb), inv_kappa, sigma * ((ell & 1u) ? n1 : n0));
+    cell0(r * bw + c, wrap(sr, r, Mx) * Mt + wrap(sc, c, Mt), partner[k]);
   }
   __syncthreads();
   // colour 1: the tile; the cell (r, c ^ 1) of every colour-0 cell, where that lies inside the tile
@@ -2211,12 +2258,10 @@ __global__ void __launch_bounds__((GffHeatGeom<K, T>::NT), 4)
     const uint32_t ri = idx / nhalf, r = HB - 1 + ri;
     const uint32_t c = (HB - 1 + ((r + HB - 1) & 1u) + 2 * (idx - ri * nhalf)) ^ 1u;
     if (r < (uint32_t)HB || r >= (uint32_t)(HB + TH) || c < (uint32_t)HB || c >= (uint32_t)(HB + TW)) continue;
-    const uint32_t o = r * bw + c;
-    double nb[4];
-    stencil_load(o, nb);
-    phi[o] = fma(stencil_sum(nb), inv_kappa, sigma * partner[k]);
+    cell1(r * bw + c, partner[k]);
   }
   __syncthreads();
+  }
 
   double acc[1] = {0.0};
   double *dst = out + (size_t)b * Mt * Mx;
