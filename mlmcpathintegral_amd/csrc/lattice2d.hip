@@ -1039,7 +1039,7 @@ struct OrHeatGeom {
   // in front of the image: the sampler's tables and the list of open cells -- a colour phase leaves about 5 % of its ~2200
   // cells on it at beta = 1 (110 entries on average; a list that overflows leaves cells to their own lanes, measured at
   // +20 % on the launch with 64 entries)
-  static constexpr uint32_t pool_cap = 256, hb_pool_cap = 128;   // step-envelope list; wrapped-Cauchy pool (24 B per entry)
+  static constexpr uint32_t pool_cap = 448, hb_pool_cap = 128;   // step-envelope list (r05: 256 -> 448 for concentrations up to 8: a phase leaves 11 % of its cells there; the bytes are the wrapped-Cauchy pool's either way); wrapped-Cauchy pool (24 B per entry)
   static constexpr size_t pool_bytes_of(size_t a, size_t b) { return ((a > b ? a : b) + 15) / 16 * 16; }
   static constexpr size_t pool_bytes = pool_bytes_of(VsPool<uint32_t>::bytes(pool_cap), HbPool::bytes(hb_pool_cap));
   static constexpr size_t hb_bytes = image_bytes + pool_bytes;
@@ -1050,7 +1050,7 @@ struct OrHeatGeom {
 // WIDE: 1024 threads per workgroup, for launches with at most one workgroup per CU (few chains): the register-block part
 // runs on the first OrHeatGeom<K>::NT threads as before, the heat-bath part on all sixteen waves.
 // STEP = false (r04): the heat-bath part draws from the wrapped-Cauchy envelope (heatbath_region, as
-// schwinger_sweep_kernel<true, ., 64, 32, false> does): actions beyond 2 beta = 4 get the fused launch too.
+// schwinger_sweep_kernel<true, ., 64, 32, false> does): actions beyond 2 beta = kVsKappaMax get the fused launch too.
 template <int K, bool WIDE = false, bool STEP = true>
 __global__ void __launch_bounds__(WIDE ? 1024 : OrHeatGeom<K>::NT, 4)
     schwinger_or_heat_kernel(uint32_t Mt, uint32_t Mx, double beta, const double2 *__restrict__ in, double2 *__restrict__ out,
