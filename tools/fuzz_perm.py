@@ -18,7 +18,7 @@ n = 0
 # windows of the fused launch (66 ... 70, 126 ... 134)
 RAGGED = [(64, 34), (66, 32), (66, 34), (70, 70), (68, 128), (126, 130), (130, 126), (134, 66), (200, 72), (250, 250), (322, 130), (64, 250)]
 for Mt, Mx in list(itertools.product((64, 128, 192, 320), (32, 64, 96, 128, 160, 256))) + RAGGED:
-    for beta in (1.0, 3.0):
+    for beta in (1.0, 3.0, 5.0):   # step envelope (2 beta <= 8), and the wrapped-Cauchy sampler beyond
         act = abi.lattice_action(abi.SCHWINGER, Mt, Mx, beta=beta)
         B = 1 + (Mt // 64 + Mx // 32) % 3
         x0 = ops.lattice_initialise(act, B, SEED, 0)
