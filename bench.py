@@ -177,7 +177,9 @@ def cxx_path(a, size):
     if not os.path.exists(exe):
         return {"error": "host/driver not built"}
     out = {}
-    for name, batch, samples in (("chains_32", 32, 40), ("single_chain", 1, 200)):
+    # (enough samples for the clocks to settle: the driver is the first process on the GPU; with 40 draws -- 28 ms -- the C++
+    # loop read 3-4 % slower than the Python-driven one that follows it)
+    for name, batch, samples in (("chains_32", 32, 400), ("single_chain", 1, 2000)):
         cmd = [exe, "--method", "throughput", "--action", "schwinger", "--Mt_lat", str(size), "--sampler", "heatbath",
                "--batch", str(batch), "--n_samples", str(samples), "--n_burnin", "30", "--seed", str(a.seed),
                "--n_sweep_overrelax", str(a.n_overrelax), "--n_sweep_heatbath", str(a.n_heatbath)]

@@ -8,7 +8,7 @@ timeout -k 10 400 python bench.py --steps 20 --warmup 5 > gpurun_out/bench_${TAG
 cut -c1-600 gpurun_out/bench_${TAG}.json
 # the C++ path's own records: the driver's JSON lines as printed
 for B in 32 1; do
-  N=40; [ $B = 1 ] && N=200
+  N=400; [ $B = 1 ] && N=2000
   timeout -k 10 300 host/driver --method throughput --action schwinger --Mt_lat 1024 --sampler heatbath --batch $B --n_samples $N --n_burnin 30 2> gpurun_out/driver_${TAG}_b$B.err | grep '^{' | tail -1 > gpurun_out/driver_${TAG}_b$B.json || { echo "driver b$B failed"; tail -5 gpurun_out/driver_${TAG}_b$B.err; exit 1; }
   cut -c1-300 gpurun_out/driver_${TAG}_b$B.json
 done
