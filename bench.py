@@ -263,16 +263,19 @@ def hbm_bound_probes(torch, ops, W, a, launches=20):
 
 
 def fast_path_cliff(torch, abi, ops, a, rank, headline_rate):
-    """The fused fast path (closed-form overrelaxation + step-envelope heat bath in one launch) needs 2 beta <= 8 (r05; 4 before)
+    """The fused fast path (closed-form overrelaxation + step-envelope heat bath in one launch) needs 2 beta <= 16 (r05; 4 before)
     and a lattice of at least 128 x 128; elsewhere other kernels run (VERDICT r03 missing #5: no recorded rate there).  One
     point per side of the cliff, same step (10 + 1 sweeps + QoI + record_sample, one ABI call), rate against the headline."""
     pts = []
     for name, kind, Mt, Mx, beta, B, path in (
-            ("beta = 4 (2 beta = 8: the step envelope's upper end)", "schwinger", 1024, 1024, 4.0, 32,
-             "r05: the one-launch draw with the step-envelope heat bath, which serves concentrations up to 8 now (its tables' "
+            ("beta = 4 (2 beta = 8)", "schwinger", 1024, 1024, 4.0, 32,
+             "r05: the one-launch draw with the step-envelope heat bath, which serves concentrations up to 16 now (its tables' "
              "acceptance falls from 0.78 per attempt at 2 beta = 2 to 0.67 at 8: twice the cells on the list pass); r04: the "
              "wrapped-Cauchy instance, 0.58-0.66 of the headline"),
-            ("beta = 6 (2 beta = 12 > 8)", "schwinger", 1024, 1024, 6.0, 32,
+            ("beta = 6 (2 beta = 12)", "schwinger", 1024, 1024, 6.0, 32,
+             "as beta = 4; the step envelope's eight classes are at their widest in kappa here (acceptance 0.59 per attempt, "
+             "a fifth of the cells on the list pass)"),
+            ("beta = 10 (2 beta = 20 > 16)", "schwinger", 1024, 1024, 10.0, 32,
              "the one-launch draw with the wrapped-Cauchy heat bath (schwinger_perm_heat_kernel<512, false>): that sampler costs "
              "1.3 x the step envelope per cell plus a pool round per colour phase, and the overrelaxation it stands beside got cheap"),
             ("960 x 960", "schwinger", 960, 960, 1.0, 32, "the one-launch draw (64 x 64 tiles divide the lattice)"),
@@ -405,7 +408,7 @@ class SweepWorkload:
         self.plan = or_plan(a.n_overrelax, self.fuse, self.blocks)   # [(depth, launches), ...], at most two entries
         # The last overrelaxation launch of a draw takes the heat-bath sweep (and the QoI) along -- one launch of
         # schwinger_or_heat_kernel<depth> / gff_or_heat_kernel<depth> (lattice2d.hip, sweep_draw_impl): 4 x 4 register-block
-        # geometry, depth <= 5, lattices >= 128, for the Schwinger action the step-envelope sampler (2 beta <= 8; beta = 1
+        # geometry, depth <= 5, lattices >= 128, for the Schwinger action the step-envelope sampler (2 beta <= 16; beta = 1
         # here), not switched off by MLMCPI_OR_HEAT=split.
         self.or_heat = (self.blocks and a.n_heatbath == 1 and bool(self.plan) and (self.plan[-1][0] <= 5 or self.perm)
                         and size >= 128 and os.environ.get("MLMCPI_OR_HEAT", "") != "split" and not a.no_fused_qoi)

@@ -417,7 +417,7 @@ int mlmcpi_test_expsin2(uint64_t seed, uint32_t chain, uint32_t step, const doub
                         double *d_out, void *stream);
 /* d_out[k] = a heat-bath draw for site k of the stream between x_p = d_xp[k] and x_m = d_xm[k], conditional
  * exp(scale / 2 [cos(x - x_p) + cos(x - x_m)]), from the tabulated step-envelope sampler the sweeps use for actions with
- * scale = 2 beta (Schwinger) or 2 m0 / a (rotor) <= 8 (the range the sweeps draw from this sampler: round 5; 4 before) */
+ * scale = 2 beta (Schwinger) or 2 m0 / a (rotor) <= 16 (the range the sweeps draw from this sampler: round 5; 4 before) */
 int mlmcpi_test_vs_draw(uint64_t seed, uint32_t chain, uint32_t step, double scale, const double *d_xp, const double *d_xm,
                         uint32_t n, double *d_out, void *stream);
 /* that sampler's table for an action of the given scale (host only, no GPU needed): sel[8][64] = bin of a selector

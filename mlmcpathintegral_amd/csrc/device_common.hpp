@@ -617,7 +617,7 @@ __device__ __forceinline__ void heatbath_cells(uint32_t total, const RngKey &key
 // The wrapped-Cauchy sampler above pays, per draw, an envelope square root, a division and an fp64 cosine per attempt
 // and an arccosine for the accepted one: ~300 fp64-class instructions of a ~520-instruction cell (388 lane
 // instructions per link update, the heat bath = half the step).  For moderate concentrations -- the Schwinger model at
-// beta <= 4, the rotor at 2 m0 / a <= 8 (kVsKappaMax): every BASELINE configuration -- the same von Mises law p(x) ~ exp(kappa cos x)
+// beta <= 8, the rotor at 2 m0 / a <= 16 (kVsKappaMax): every BASELINE configuration -- the same von Mises law p(x) ~ exp(kappa cos x)
 // is drawn here from a piecewise-constant envelope taken from a small table, so that an attempt costs no fp64
 // arithmetic at all and the accepted angle is a linear function of random bits:
 //     bins of |x|     edges (0, 1, 2, 3, 4, 6, 8, 12, 16) pi/16: eight bins, finer where the density is high;
@@ -641,14 +641,15 @@ __device__ __forceinline__ void heatbath_cells(uint32_t total, const RngKey &key
 // sweep launch.)  Random numbers: the same Philox calls (word pair = one attempt), fields: bit 0 sign, bits 1..22 leading
 // bits of u2, bits 23..57 position inside the bin (35 bits: 2 10^-11 rad), bits 58..63 selector.
 // host rule (lattice2d.hip / path1d.hip; the oracle applies the same): this sampler where the action's largest concentration,
-// 2 beta or 2 m0 / a, is <= kVsKappaMax; the wrapped-Cauchy sampler beyond.  r05: 8 (4 before).  The eight classes split
+// 2 beta or 2 m0 / a, is <= kVsKappaMax; the wrapped-Cauchy sampler beyond.  r05: 16 (4 until then).  The eight classes split
 // [0, scale] by sin(2 pi c / 32), so they get wider in kappa with the scale and a table, built for the smallest
 // concentration of its class, fits the largest one less well: acceptance per attempt 0.78 on average at scale 2, 0.74 at 4,
-// 0.67 at 8 (0.36 at worst), a pair fails for 5 % / 7 % / 11 % of the cells.  At 8 that is still a draw of the fused
-// Schwinger launch in 0.70 ms against 1.18 ms with the wrapped-Cauchy sampler (1024^2 x 32, beta = 4); the error budget
-// of the screening test below scales with kappa' = scale log2 e through the band, and |log2 a| <= 2 kappa' + |lw| <= 30 is
-// far from fp32's exponent range.
-constexpr double kVsKappaMax = 8.0;
+// 0.67 at 8, 0.59 at 12, 0.58 at 16 (0.24 at worst), a pair fails for 5 / 7 / 11 / 18 / 20 % of the cells.  Even so a draw of
+// the fused Schwinger launch (1024^2 x 32) takes 0.70 ms at beta = 4, 0.82 at 6 and 0.75 at 8 against 1.18 - 1.19 ms with the
+// wrapped-Cauchy sampler; beyond 16 the eight bins (the finest pi / 16 wide) are too coarse for the target.  The error
+// budget of the screening test below scales with kappa' = scale log2 e through the band, and |log2 a| <= 2 kappa' + |lw| <= 55
+// is far from fp32's exponent range.
+constexpr double kVsKappaMax = 16.0;
 constexpr int kVsClasses = 8, kVsBins = 8, kVsSel = 64;
 constexpr uint32_t kVsU2Bits = 22;  // leading bits of the acceptance uniform carried by the attempt itself
 // The 64 bits (lo, hi) of an attempt (r04 layout: every field is one shift or one conversion away from its use):

@@ -1039,7 +1039,7 @@ struct OrHeatGeom {
   // in front of the image: the sampler's tables and the list of open cells -- a colour phase leaves about 5 % of its ~2200
   // cells on it at beta = 1 (110 entries on average; a list that overflows leaves cells to their own lanes, measured at
   // +20 % on the launch with 64 entries)
-  static constexpr uint32_t pool_cap = 448, hb_pool_cap = 128;   // step-envelope list (r05: 256 -> 448 for concentrations up to 8: a phase leaves 11 % of its cells there; the bytes are the wrapped-Cauchy pool's either way); wrapped-Cauchy pool (24 B per entry)
+  static constexpr uint32_t pool_cap = 544, hb_pool_cap = 128;   // step-envelope list (r05: 256 -> 544 for concentrations up to 16: a phase leaves up to a fifth of its ~2200 cells there; as many entries as the register-block geometry's LDS bound below admits); wrapped-Cauchy pool (24 B per entry)
   static constexpr size_t pool_bytes_of(size_t a, size_t b) { return ((a > b ? a : b) + 15) / 16 * 16; }
   static constexpr size_t pool_bytes = pool_bytes_of(VsPool<uint32_t>::bytes(pool_cap), HbPool::bytes(hb_pool_cap));
   static constexpr size_t hb_bytes = image_bytes + pool_bytes;

@@ -214,7 +214,7 @@ inline double dev_vonmises(const DevRng &rng, uint32_t site, double kappa, uint3
 // of u2 from the refine call); of the 52 bits above them the top six select the bin (selector value s belongs to bin k
 // when q_0 + ... + q_{k-1} <= s < q_0 + ... + q_k) and the other 46 are the position inside it.  The test is taken in
 // logarithms, exactly as the device's exact path does.
-constexpr double kVsKappaMax = 8.0;   // (round 5; 4 before: the device's rule, device_common.hpp)
+constexpr double kVsKappaMax = 16.0;   // (round 5; 4 before: the device's rule, device_common.hpp)
 constexpr int kVsClasses = 8, kVsBins = 8, kVsSel = 64;
 struct VsTables {
   int q[kVsClasses][kVsBins];

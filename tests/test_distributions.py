@@ -53,7 +53,8 @@ def test_expsin2_device_order_equals_reference_distribution(orc, sigma):
 
 @pytest.mark.parametrize("scale,d", [(2.0, 0.0), (2.0, 0.5), (2.0, 1.2), (2.0, 2.0), (2.0, 2.6), (2.0, 3.0), (2.0, 3.14159265),
                                      (4.0, 0.3), (4.0, 4.5), (0.6, 1.0), (0.0, 1.0), (3.0, -7.0),
-                                     (6.0, 0.2), (6.0, 2.2), (8.0, 0.0), (8.0, 0.9), (8.0, 2.8), (8.0, 3.3)])   # r05: concentrations up to 8
+                                     (6.0, 0.2), (6.0, 2.2), (8.0, 0.0), (8.0, 0.9), (8.0, 2.8), (8.0, 3.3),
+                                     (12.0, 0.4), (12.0, 2.5), (16.0, 0.0), (16.0, 1.1), (16.0, 2.9)])   # r05: concentrations up to 16
 def test_step_envelope_sampler_draws_the_von_mises_law(orc, scale, d):
     """The sweeps' sampler for actions of moderate concentration (oracle dev_vonmises_table = the device's tabulated step
     envelope), over all concentration classes: KS against the analytic CDF and against the reference's own ExpSin2
@@ -77,7 +78,7 @@ def test_step_envelope_sampler_draws_the_von_mises_law(orc, scale, d):
     assert abs(m - i1e(kappa) / i0e(kappa)) < 4.5 * se, (m, i1e(kappa) / i0e(kappa), se)
 
 
-@pytest.mark.parametrize("scale", [0.0, 0.5, 2.0, 2.5, 4.0, 6.0, 8.0])
+@pytest.mark.parametrize("scale", [0.0, 0.5, 2.0, 2.5, 4.0, 6.0, 8.0, 12.0, 16.0])
 def test_step_envelope_tables(orc, scale):
     """The product's table (mlmcpi_vs_table, host code of libmlmcpi_hip.so) against the oracle's own construction: same
     selector counts, same acceptance factors; and the properties that make it a sampler at all -- 64 selector values per
@@ -110,16 +111,16 @@ def test_step_envelope_tables(orc, scale):
             dens = (q[k] / 64.0) / np.diff(edges)[k]                                               # proposal density on |x|
             rate = np.trapezoid(acc * dens, grid)
             # 0.67 ... 0.89 at scale 2 (beta = 1); the classes of scale 4 are twice as wide in kappa: 0.53 at worst; scale 8
-            # (r05): 0.36 at the upper end of the widest class, 0.67 on average over the classes
-            assert acc.max() <= 1.0 + 1e-12 and rate > (0.65 if scale <= 2.0 else 0.5 if scale <= 4.0 else 0.34), (c, kappa, rate)
+            # (r05): 0.36 at the upper end of the widest class, 0.67 on average over the classes; scale 16: 0.24 / 0.58
+            assert acc.max() <= 1.0 + 1e-12 and rate > (0.65 if scale <= 2.0 else 0.5 if scale <= 4.0 else 0.34 if scale <= 8.0 else 0.22), (c, kappa, rate)
 
 
 def test_sweep_sampler_rule_follows_the_largest_concentration(orc):
-    """dev_sweep picks the sampler from the action (2 beta, 2 m0 / a <= 8: step envelope; r05, 4 before): a Schwinger heat-bath
-    update at beta <= 4 must be the tabulated sampler's draw between the staples, at beta = 4.5 the wrapped-Cauchy one."""
+    """dev_sweep picks the sampler from the action (2 beta, 2 m0 / a <= 16: step envelope; r05, 4 before): a Schwinger heat-bath
+    update at beta <= 8 must be the tabulated sampler's draw between the staples, at beta = 8.5 the wrapped-Cauchy one."""
     import ctypes as C
     L = orc.lib()
-    for beta, step in ((1.0, True), (2.0, True), (2.5, True), (4.0, True), (4.5, False)):
+    for beta, step in ((1.0, True), (2.0, True), (2.5, True), (4.0, True), (6.0, True), (8.0, True), (8.5, False)):
         A = orc.Action(orc.SCHWINGER, Mt=4, Mx=4, beta=beta)
         x = np.sin(np.arange(32) + 1.0)
         y = x.copy()
@@ -127,7 +128,7 @@ def test_sweep_sampler_rule_follows_the_largest_concentration(orc):
         # link 0 is updated first (colour 0): rebuild its draw from the initial staples
         tp, tm = C.c_double(), C.c_double()
         L.orc_action_staples(A.h, x, 0, C.byref(tp), C.byref(tm))
-        d = L.orc_dev_vs_draw(77, 3, 5, 0, min(2 * beta, 8.0), tp.value, tm.value) - y[0]
+        d = L.orc_dev_vs_draw(77, 3, 5, 0, min(2 * beta, 16.0), tp.value, tm.value) - y[0]
         d -= 2 * np.pi * np.round(d / (2 * np.pi))
         assert (abs(d) < 1e-13) == step, (beta, d)
 

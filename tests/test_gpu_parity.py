@@ -557,8 +557,9 @@ SWEEP_CASES = [
     ("schwinger", 130, 70, dict(beta=1.0), 1),
     ("schwinger", 64, 64, dict(beta=2.0), 2),    # one 64 x 64 tile of the 4 x 4 register-block kernel: the buffer wraps onto itself
     ("schwinger", 192, 128, dict(beta=1.0), 1),  # 3 x 2 tiles of it
-    ("schwinger", 128, 128, dict(beta=3.0), 1),  # 4 < 2 beta <= 8: the step envelope since r05 (wrapped Cauchy before)
-    ("schwinger", 128, 128, dict(beta=5.0), 1),  # 2 beta > 8: the fused launch with the wrapped-Cauchy sampler (r04)
+    ("schwinger", 128, 128, dict(beta=3.0), 1),  # 4 < 2 beta <= 16: the step envelope since r05 (wrapped Cauchy before)
+    ("schwinger", 128, 128, dict(beta=5.0), 1),
+    ("schwinger", 128, 128, dict(beta=9.0), 1),  # 2 beta > 16: the fused launch with the wrapped-Cauchy sampler (r04)
     ("schwinger", 16, 16, dict(beta=0.0), 2),    # flat conditionals: kappa is clamped, the draw is uniform
     ("schwinger", 16, 16, dict(beta=40.0), 2),   # sharply peaked conditionals (kappa up to 80)
     ("gff", 16, 16, dict(mass=0.0), 2),          # massless field: kappa = 4
@@ -591,7 +592,8 @@ def test_lattice_sweeps_match_oracle(gpu_ops, orc, kind, Mt, Mx, kw, B, fuse):
 
 
 @pytest.mark.parametrize("Mt,Mx,B,beta", [(64, 64, 2, 1.0), (128, 128, 2, 1.0), (192, 128, 1, 2.0), (128, 256, 2, 3.0), (128, 192, 1, 4.0),
-                                          (128, 128, 2, 5.5),                     # 2 beta > 8: wrapped Cauchy
+                                          (128, 128, 2, 5.5), (192, 128, 1, 8.0), # the step envelope's upper range
+                                          (128, 128, 2, 9.5),                     # 2 beta > 16: wrapped Cauchy
                                           (64, 32, 2, 1.0), (192, 96, 1, 1.0),   # the last two: 64 x 32 tiles
                                           # r05: lattices no tile divides (masked edge tiles): 64 x 32 tiles + heat-bath launch
                                           # (an extent below 128), the one-launch draw on 64 x 64 tiles (both >= 128)
@@ -633,9 +635,10 @@ def test_closed_form_overrelaxation_matches_oracle(gpu_ops, orc, Mt, Mx, B, beta
 
 
 @pytest.mark.parametrize("Mt,Mx,B,beta", [(128, 128, 3, 1.0), (192, 128, 2, 2.0), (256, 128, 2, 0.3), (1024, 1024, 2, 1.0),
-                                          # r04: beyond the step envelope's range (2 beta = 8 since r05) the fused launch draws
+                                          # r04: beyond the step envelope's range (2 beta = 16 since r05) the fused launch draws
                                           # from the wrapped-Cauchy envelope
-                                          (128, 192, 2, 3.0), (128, 128, 2, 4.0), (192, 128, 2, 5.0), (256, 256, 2, 40.0),
+                                          (128, 192, 2, 3.0), (128, 128, 2, 4.0), (192, 128, 2, 5.0), (128, 128, 2, 8.0), (128, 192, 2, 10.0),
+                                          (256, 256, 2, 40.0),
                                           (200, 136, 2, 1.0), (130, 262, 1, 1.0)])   # r05: masked edge tiles of the fused launch
 def test_overrelaxation_and_heat_bath_in_one_launch_equal_two_launches(gpu_ops, Mt, Mx, B, beta):
     """schwinger_or_heat_kernel<K> (the last K <= 5 overrelaxation sweeps of a draw, the heat-bath sweep behind them and
@@ -739,14 +742,14 @@ def test_heatbath_retry_pool_with_several_passes_per_phase(gpu_ops, tile):
         assert torch.equal(want, got), f"tile {tile}, beta {beta}: heat-bath result depends on the tile geometry"
 
 
-@pytest.mark.parametrize("kind,Mt,Mx,kw", [("schwinger", 8, 6, dict(beta=1.0)), ("schwinger", 6, 6, dict(beta=3.0)), ("schwinger", 6, 8, dict(beta=6.0)),
+@pytest.mark.parametrize("kind,Mt,Mx,kw", [("schwinger", 8, 6, dict(beta=1.0)), ("schwinger", 6, 6, dict(beta=3.0)), ("schwinger", 6, 8, dict(beta=6.0)), ("schwinger", 8, 8, dict(beta=10.0)),
                                            ("gff", 8, 8, dict(mass=3.0)), ("rotor", 32, 0, dict(T_final=4.0, m0=0.25)),
                                            ("rotor", 16, 0, dict(T_final=1.0, m0=1.0))])
 def test_site_at_a_time_updates_match_oracle(gpu_ops, orc, kind, Mt, Mx, kw):
     """Action::heatbath_update / overrelaxation_update(state, l) (action/action.hh:73-96) through
     mlmcpi_{path,lattice}_site_updates: a shuffled index list walked sequentially per chain -- the loop of
     overrelaxedheatbathsampler.cc:8-31 with random_order -- against the oracle's single-site updates applied in the
-    same order; both samplers (beta = 1, 3: tabulated step envelope, beta = 6 / m0/a = 16: wrapped Cauchy)."""
+    same order; both samplers (beta = 1, 3, 6: tabulated step envelope, beta = 10 / m0/a = 16: wrapped Cauchy)."""
     from mlmcpathintegral_amd import abi
     B = 3
     if kind == "rotor":
@@ -1247,13 +1250,14 @@ def _vonmises_cdf(kappa):
 
 _VS_CASES = [(2.0, 0.0), (2.0, 0.45), (2.0, 0.85), (2.0, 1.25), (2.0, 1.65), (2.0, 2.05), (2.0, 2.45), (2.0, 2.8), (2.0, 3.1),
              (4.0, 0.2), (4.0, 1.9), (4.0, 4.5), (0.6, 1.0), (3.0, -7.0), (0.0, 1.0),
-             (6.0, 0.3), (6.0, 2.3), (8.0, 0.0), (8.0, 0.9), (8.0, 2.0), (8.0, 2.8), (8.0, 3.3)]   # r05: concentrations up to 8
+             (6.0, 0.3), (6.0, 2.3), (8.0, 0.0), (8.0, 0.9), (8.0, 2.0), (8.0, 2.8), (8.0, 3.3),
+             (12.0, 0.5), (12.0, 2.4), (16.0, 0.0), (16.0, 1.0), (16.0, 2.6), (16.0, 3.2)]   # r05: concentrations up to 16
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("scale,d", _VS_CASES)
 def test_device_step_envelope_draws_follow_the_von_mises_law(gpu_ops, scale, d):
-    """mlmcpi_test_vs_draw (the sweeps' sampler at 2 beta, 2 m0 / a <= 8; r05, 4 before) over all eight concentration classes
+    """mlmcpi_test_vs_draw (the sweeps' sampler at 2 beta, 2 m0 / a <= 16; r05, 4 before) over all eight concentration classes
     (class = floor(32 | |d / 4 pi| mod 1/2 - 1/4 |): d = 0 ... pi walks from class 7 down to class 0)."""
     from scipy import stats
     from scipy.special import i0e, i1e
@@ -1278,7 +1282,7 @@ def test_device_step_envelope_draws_follow_the_von_mises_law(gpu_ops, scale, d):
 @pytest.mark.gpu
 @pytest.mark.parametrize("beta,d", [(1.0, 0.7), (1.0, 2.9), (2.5, 0.3), (2.5, 2.2), (6.0, 1.5), (40.0, 0.1), (0.05, 1.0)])
 def test_device_expcos_draws_follow_the_von_mises_law(gpu_ops, beta, d):
-    """mlmcpi_test_expcos: the wrapped-Cauchy sampler the sweeps use beyond 2 beta = 8 (and the two-level fill-ins always)"""
+    """mlmcpi_test_expcos: the wrapped-Cauchy sampler the sweeps use beyond 2 beta = 16 (and the two-level fill-ins always)"""
     from scipy import stats
     from scipy.special import i0e, i1e
     from conftest import zcheck
